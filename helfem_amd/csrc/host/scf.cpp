@@ -1,0 +1,249 @@
+#include "scf.h"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <deque>
+
+namespace helfem {
+namespace scf {
+
+namespace {
+double wall() {
+  using namespace std::chrono;
+  return duration_cast<duration<double> >(steady_clock::now().time_since_epoch()).count();
+}
+
+// Pulay DIIS on the commutator error e = Sinvh^T (FPS - SPF) Sinvh (reference: diis.cpp:129-168
+// builds the same error matrix; its ADIIS admixture only changes the path to convergence).
+struct DIIS {
+  size_t imax;
+  std::deque<Mat> Fs, errs;
+  explicit DIIS(size_t n) : imax(n) {}
+  void push(const Mat &F, const Mat &err) {
+    if (Fs.size() == imax) {
+      Fs.pop_front();
+      errs.pop_front();
+    }
+    Fs.push_back(F);
+    errs.push_back(err);
+  }
+  Mat solve() const {
+    size_t n = Fs.size();
+    if (n == 1) return Fs[0];
+    size_t m = n + 1;
+    std::vector<double> A(m * m, 0.0), rhs(m, 0.0);
+    for (size_t i = 0; i < n; i++)
+      for (size_t j = 0; j <= i; j++) {
+        double s = 0.0;
+        for (size_t k = 0; k < errs[i].d.size(); k++) s += errs[i].d[k] * errs[j].d[k];
+        A[i * m + j] = A[j * m + i] = s;
+      }
+    for (size_t i = 0; i < n; i++) A[i * m + n] = A[n * m + i] = 1.0;
+    rhs[n] = 1.0;
+    // Gaussian elimination with partial pivoting
+    std::vector<size_t> piv(m);
+    for (size_t i = 0; i < m; i++) piv[i] = i;
+    for (size_t c = 0; c < m; c++) {
+      size_t p = c;
+      for (size_t r = c + 1; r < m; r++)
+        if (fabs(A[r * m + c]) > fabs(A[p * m + c])) p = r;
+      if (p != c) {
+        for (size_t k = 0; k < m; k++) std::swap(A[c * m + k], A[p * m + k]);
+        std::swap(rhs[c], rhs[p]);
+      }
+      if (A[c * m + c] == 0.0) return Fs.back();
+      for (size_t r = c + 1; r < m; r++) {
+        double f = A[r * m + c] / A[c * m + c];
+        for (size_t k = c; k < m; k++) A[r * m + k] -= f * A[c * m + k];
+        rhs[r] -= f * rhs[c];
+      }
+    }
+    std::vector<double> x(m);
+    for (size_t ii = m; ii-- > 0;) {
+      double s = rhs[ii];
+      for (size_t k = ii + 1; k < m; k++) s -= A[ii * m + k] * x[k];
+      x[ii] = s / A[ii * m + ii];
+    }
+    Mat F(Fs[0].n_rows, Fs[0].n_cols);
+    for (size_t i = 0; i < n; i++)
+      for (size_t k = 0; k < F.d.size(); k++) F.d[k] += x[i] * Fs[i].d[k];
+    return F;
+  }
+};
+
+Mat form_density(const Mat &C, size_t nocc) {
+  Mat P(C.n_rows, C.n_rows);
+  for (size_t o = 0; o < nocc; o++)
+    for (size_t j = 0; j < C.n_rows; j++) {
+      double cj = C(j, o);
+      for (size_t i = 0; i < C.n_rows; i++) P(i, j) += C(i, o) * cj;
+    }
+  return P;
+}
+
+Mat enforce_sym(const Mat &F, const std::vector<std::vector<size_t> > &sym) {
+  Mat out(F.n_rows, F.n_cols);
+  for (const auto &idx : sym)
+    for (size_t j : idx)
+      for (size_t i : idx) out(i, j) = F(i, j);
+  return out;
+}
+}  // namespace
+
+Result run_diatomic(const Options &opt, Backend &be) {
+  Result res;
+  const bool verbose = opt.verbose;
+  int nel = opt.Z1 + opt.Z2;
+  if (nel % 2) throw std::logic_error("Open-shell (unrestricted/ROHF) runs are not implemented in this build.\n");
+  const size_t nocc = nel / 2;
+
+  int Nquad = opt.nquad;
+  if (Nquad == 0) Nquad = 5 * opt.nnodes;
+  else if (Nquad < 2 * opt.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
+
+  IVec lval, mval;
+  diatomic::lm_to_l_m(opt.lmmax, lval, mval);
+  double Rhalf = 0.5 * opt.Rbond;
+  double mumax = arcosh(opt.Rmax / Rhalf);
+  Vec bval = get_grid(mumax, opt.nelem, opt.igrid, opt.zexp);
+
+  diatomic::TwoDBasis basis(opt.Z1, opt.Z2, Rhalf, opt.nnodes, Nquad, bval, lval, mval, opt.lpad);
+  res.Nbf = basis.Nbf();
+  if (verbose)
+    printf("Basis set consists of %i angular shells composed of %i radial functions, totaling %i basis functions\n",
+           (int)basis.Nang(), (int)basis.Nrad(), (int)basis.Nbf());
+  res.Enucr = opt.Z1 * opt.Z2 / opt.Rbond;
+
+  const bool dft = (opt.x_func > 0 || opt.c_func > 0);
+  int ldft = opt.ldft, mdft = opt.mdft;
+  if (dft) {
+    int lmaxmax = 0;
+    for (int l : opt.lmmax) lmaxmax = std::max(lmaxmax, l);
+    if (ldft == 0) ldft = 4 * lmaxmax + 12;
+    if (ldft < 2 * lmaxmax + 2) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
+    if (mdft == 0) mdft = 4 * (int)opt.lmmax.size() + 5;
+    if (mdft < 2 * (int)opt.lmmax.size()) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
+  }
+
+  std::vector<std::vector<size_t> > dsym;
+  int symm = opt.symmetry;
+  if (symm == 2 && opt.Z1 != opt.Z2) symm = 1;
+  dsym = basis.get_sym_idx(symm);
+
+  Mat S(basis.overlap()), T(basis.kinetic()), Vnuc(basis.nuclear());
+  Mat H0(T + Vnuc);
+  double t0 = wall();
+  Mat Sinvh(be.Sinvh(S, !opt.diag, dsym));
+  if (verbose) printf("Half-inverse formed in %.6f\n", wall() - t0);
+
+  // core guess (main.cpp:655-660 with point nuclei == T+Vnuc)
+  Vec E;
+  Mat C;
+  if (verbose) printf("Guess orbitals from core Hamiltonian\n");
+  be.eig_gsym_sub(E, C, H0, Sinvh, dsym);
+
+  if (verbose) printf("Computing two-electron integrals\n");
+  t0 = wall();
+  basis.compute_tei(opt.kfrac != 0.0);
+  be.prepare(basis, opt.kfrac != 0.0, ldft, mdft);
+  if (verbose) printf("Done in %.6f\n", wall() - t0);
+
+  DIIS diis(opt.diisorder);
+  double Eold = 0.0;
+  Mat P, F;
+  for (int it = 1; it <= opt.maxit; it++) {
+    if (verbose) printf("\n**** Iteration %i ****\n\n", it);
+    Mat Pa = form_density(C, nocc);
+    P = 2.0 * Pa;
+    if (verbose) printf("Tr Pa = %f\n", trace_prod(Pa, S));
+    res.Ekin = trace_prod(P, T);
+    res.Epot = trace_prod(P, Vnuc);
+
+    t0 = wall();
+    Mat J(be.coulomb(P));
+    res.tJ = wall() - t0;
+    res.Ecoul = 0.5 * trace_prod(P, J);
+    if (verbose) printf("Coulomb energy %.10e % .6f\n", res.Ecoul, res.tJ);
+
+    Mat Ka;
+    res.Exx = 0.0;
+    if (opt.kfrac != 0.0) {
+      t0 = wall();
+      Ka = opt.kfrac * be.exchange(Pa);
+      res.tK = wall() - t0;
+      res.Exx = trace_prod(Pa, Ka);  // 0.5 Tr PaKa + 0.5 Tr PbKb with Kb=Ka
+      if (verbose) printf("Exchange energy %.10e % .6f\n", res.Exx, res.tK);
+    }
+
+    Mat XC;
+    res.Exc = 0.0;
+    if (dft) {
+      t0 = wall();
+      double nelnum = 0, ekin = 0;
+      be.eval_Fxc(opt.x_func, opt.c_func, P, XC, res.Exc, nelnum, ekin, opt.dftthr);
+      res.tXC = wall() - t0;
+      if (verbose) {
+        printf("DFT energy %.10e % .6f\n", res.Exc, res.tXC);
+        printf("Error in integrated number of electrons % e\n", nelnum - nel);
+      }
+    }
+
+    F = H0 + J;
+    if (Ka.n_rows == F.n_rows) F += Ka;
+    if (dft) F += XC;
+    if (symm) F = enforce_sym(F, dsym);
+
+    res.Etot = res.Ekin + res.Epot + res.Ecoul + res.Exx + res.Exc + res.Enucr;
+    double dE = res.Etot - Eold;
+    if (verbose) {
+      printf("Total energy is % .10f\n", res.Etot);
+      if (it > 1) printf("Energy changed by %e\n", dE);
+    }
+    Eold = res.Etot;
+
+    // DIIS error Sinvh^T (F Pa S - S Pa F) Sinvh
+    t0 = wall();
+    Mat FPS = be.gemm(be.gemm(F, false, Pa, false), false, S, false);
+    Mat err = FPS - FPS.t();
+    err = be.gemm(be.gemm(Sinvh, true, err, false), false, Sinvh, false);
+    double diiserr = 0.0;
+    for (double v : err.d) diiserr = std::max(diiserr, fabs(v));
+    if (verbose) printf("DIIS error is %e, update done in %.6f\n", diiserr, wall() - t0);
+    diis.push(F, err);
+    Mat Fd = diis.solve();
+
+    bool convd = (diiserr < opt.convthr) && (fabs(dE) < opt.convthr);
+
+    t0 = wall();
+    be.eig_gsym_sub(E, C, Fd, Sinvh, dsym);
+    res.tdiag = wall() - t0;
+    if (verbose) {
+      printf("%s diagonalization done in %.6f\n", symm ? "Subspace" : "Full", res.tdiag);
+      if (E.size() > nocc) printf("Alpha HOMO-LUMO gap is % .3f eV\n", (E[nocc] - E[nocc - 1]) * 27.211386);
+      fflush(stdout);
+    }
+    res.iterations = it;
+    if (convd) {
+      res.converged = true;
+      break;
+    }
+  }
+  res.E = E;
+  res.C = C;
+  res.P = P;
+  res.F = F;
+  if (verbose) {
+    printf("%-21s energy: % .16f\n", "Kinetic", res.Ekin);
+    printf("%-21s energy: % .16f\n", "Nuclear attraction", res.Epot);
+    printf("%-21s energy: % .16f\n", "Nuclear repulsion", res.Enucr);
+    printf("%-21s energy: % .16f\n", "Coulomb", res.Ecoul);
+    printf("%-21s energy: % .16f\n", "Exact exchange", res.Exx);
+    printf("%-21s energy: % .16f\n", "Exchange-correlation", res.Exc);
+    printf("%-21s energy: % .16f\n", "Total", res.Etot);
+    printf("%-21s energy: % .16f\n", "Virial ratio", -res.Etot / res.Ekin);
+  }
+  return res;
+}
+
+}  // namespace scf
+}  // namespace helfem

@@ -1,0 +1,67 @@
+// Restricted closed-shell SCF driver for the diatomic program, written against an abstract
+// backend so that the same loop runs on the GPU entry points (product: src/diatomic_main.cpp)
+// and on the CPU oracle (tests).  Mirrors the control flow, energy expression and printed lines
+// of the reference driver (/root/reference/src/diatomic/main.cpp:402-1009):
+//   S,T,Vnuc -> Sinvh -> guess (core Hamiltonian, --iguess 0) -> compute_tei ->
+//   loop { P = C_occ C_occ^T; J; K; XC; F; E; DIIS; eig_gsym_sub } -> energy table.
+// Open-shell / unrestricted runs, external fields, finite nuclei, checkpoints and the SAP/GSZ/TF
+// guesses are outside the hot-path scope and are rejected loudly.
+#pragma once
+#include "diatomic_basis.h"
+#include <string>
+
+namespace helfem {
+namespace scf {
+
+struct Backend {
+  virtual ~Backend() {}
+  virtual const char *name() const = 0;
+  /// upload / prepare tables after compute_tei
+  virtual void prepare(const diatomic::TwoDBasis &basis, bool exchange, int ldft, int mdft) = 0;
+  virtual Mat coulomb(const Mat &P) = 0;
+  virtual Mat exchange(const Mat &P) = 0;
+  virtual void eval_Fxc(int x_func, int c_func, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin,
+                        double thr) = 0;
+  virtual void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh,
+                            const std::vector<std::vector<size_t> > &sym) = 0;
+  virtual Mat Sinvh(const Mat &S, bool chol, const std::vector<std::vector<size_t> > &sym) = 0;
+  /// C = op(A) op(B)
+  virtual Mat gemm(const Mat &A, bool tA, const Mat &B, bool tB) = 0;
+};
+
+struct Options {
+  int Z1 = 1, Z2 = 1;
+  double Rbond = 1.4;
+  IVec lmmax;  // per |m|
+  int lpad = 10;
+  double Rmax = 40.0;
+  int igrid = 4;
+  double zexp = 1.0;
+  int nelem = 3, nnodes = 15, nquad = 0;
+  int maxit = 50;
+  double convthr = 1e-7;
+  bool diag = true;
+  std::string method = "HF";
+  int x_func = -1, c_func = 0;  // filled by the caller from method
+  double kfrac = 1.0;
+  int ldft = 0, mdft = 0;
+  double dftthr = 1e-12;
+  int symmetry = 1;
+  int diisorder = 5;
+  bool verbose = true;
+};
+
+struct Result {
+  double Ekin = 0, Epot = 0, Enucr = 0, Ecoul = 0, Exx = 0, Exc = 0, Etot = 0;
+  int iterations = 0;
+  bool converged = false;
+  double tJ = 0, tK = 0, tXC = 0, tdiag = 0;  // seconds of the last iteration
+  Vec E;       // orbital energies
+  Mat C, P, F;  // final orbitals, density, Fock
+  size_t Nbf = 0;
+};
+
+Result run_diatomic(const Options &opt, Backend &be);
+
+}  // namespace scf
+}  // namespace helfem

@@ -1,0 +1,61 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the reference's per-SCF-iteration hot path.  Only tests/, the smoke check
+// of __graft_entry__.py and bench.py's cpu_baseline leg may link or call this; the product
+// (helfem_amd/csrc) never does.  Each function cites the reference code it follows
+// (paths relative to /root/reference).
+//
+// Parity status: the reference hot path itself cannot be built in this image (needs Armadillo,
+// GSL, libxc).  What pins this oracle: the reference's gaunt_test values, the Neumann-expansion
+// identity of legendre_test.cpp, the Fortran Legendre library compiled from the reference into
+// oracle/_ref, the Maple rationals of atomic/inttest.cpp, the drivers' run-time identities
+// (grid overlap/kinetic, Tr PS, electron count) and literature HF/LDA total energies.
+// libxc arithmetic (functional values) is restated from the published formulas: PARITY UNPINNED
+// for PBE/VWN beyond those literature energies.
+#pragma once
+#include "../helfem_amd/csrc/host/diatomic_basis.h"
+#include "../helfem_amd/csrc/host/linalg.h"
+
+namespace oracle {
+using helfem::Mat;
+using helfem::Vec;
+
+// ---- dense symmetric eigenproblems (stand-in for arma::eig_sym = LAPACK dsyevd) ----
+/// eigenvalues ascending, eigenvectors in columns
+void eig_sym(Vec &E, Mat &C, const Mat &A);
+/// scf::eig_gsym            src/general/scf_helpers.cpp:131-140
+void eig_gsym(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh);
+/// scf::eig_gsym_sub        src/general/scf_helpers.cpp:142-186
+void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh, const std::vector<std::vector<size_t> > &m_idx);
+/// utils::invh              libhelfem/src/utils.cpp:160-183
+Mat invh(Mat S, bool chol);
+/// TwoDBasis::Sinvh         src/diatomic/basis.cpp:627-652
+Mat form_Sinvh(const Mat &S, bool chol, const std::vector<std::vector<size_t> > &sym_idx);
+/// scf::form_density        src/general/scf_helpers.cpp:22-29
+Mat form_density(const Mat &C, size_t nocc);
+/// scf::enforce_fock_symmetry  src/general/scf_helpers.cpp:249-261
+Mat enforce_fock_symmetry(const Mat &F, const std::vector<std::vector<size_t> > &m_idx);
+
+// ---- diatomic Fock build ----
+/// TwoDBasis::coulomb       src/diatomic/basis.cpp:1359-1530
+Mat coulomb(const helfem::diatomic::TwoDBasis &b, const Mat &P0);
+/// TwoDBasis::exchange      src/diatomic/basis.cpp:1532-1733
+Mat exchange(const helfem::diatomic::TwoDBasis &b, const Mat &P0);
+/// DFTGrid::eval_Fxc (restricted)  src/diatomic/dftgrid.cpp:769-810; radial points
+/// [q_begin,q_end) of the E*nq list only (q_end<0: all) so that the bench can time a bounded sample
+void eval_Fxc(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P,
+              Mat &H, double &Exc, double &Nel, double &Ekin, double thr, long q_begin = 0, long q_end = -1);
+/// DFTGrid::eval_overlap / eval_kinetic  src/diatomic/dftgrid.cpp:858-896
+Mat grid_overlap(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
+Mat grid_kinetic(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
+
+// ---- exchange-correlation functionals, spin-unpolarised, libxc conventions ----
+// ids follow libxc: 1 = lda_x, 7 = lda_c_vwn (VWN5), 12 = lda_c_pw, 101 = gga_x_pbe, 130 = gga_c_pbe
+// exc: energy per particle; vrho = d(rho exc)/d rho; vsigma = d(rho exc)/d sigma
+bool xc_is_gga(int func_id);
+void xc_unpolarized(int func_id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
+                    double *vsigma, double dens_threshold);
+/// "lda_x-lda_c_vwn", "gga_x_pbe-gga_c_pbe", "HF", "none", or numeric ids  (dftfuncs.cpp:64-118)
+void parse_xc_func(int &x_func, int &c_func, const std::string &method);
+
+}  // namespace oracle

@@ -1,0 +1,215 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).  C entry points for ctypes (tests, bench
+// cpu_baseline, smoke).  Plain pointers, column-major doubles, int status (0 = ok).
+#include "oracle.h"
+#include "../helfem_amd/csrc/host/scf.h"
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+using namespace oracle;
+using helfem::diatomic::TwoDBasis;
+
+static thread_local std::string g_err;
+#define ORC_TRY try {
+#define ORC_CATCH                   \
+  }                                 \
+  catch (const std::exception &e) { \
+    g_err = e.what();               \
+    return 1;                       \
+  }                                 \
+  return 0;
+
+static Mat to_mat(const double *p, size_t r, size_t c) {
+  Mat M(r, c);
+  memcpy(M.memptr(), p, sizeof(double) * r * c);
+  return M;
+}
+static std::vector<std::vector<size_t> > to_blocks(int nblk, const int64_t *ptr, const int64_t *idx) {
+  std::vector<std::vector<size_t> > b(nblk);
+  for (int i = 0; i < nblk; i++)
+    for (int64_t k = ptr[i]; k < ptr[i + 1]; k++) b[i].push_back((size_t)idx[k]);
+  return b;
+}
+
+namespace {
+struct OracleBackend : public helfem::scf::Backend {
+  const TwoDBasis *b = nullptr;
+  int ldft = 0, mdft = 0;
+  const char *name() const override { return "oracle"; }
+  void prepare(const TwoDBasis &basis, bool, int l, int m) override {
+    b = &basis;
+    ldft = l;
+    mdft = m;
+  }
+  Mat coulomb(const Mat &P) override { return oracle::coulomb(*b, P); }
+  Mat exchange(const Mat &P) override { return oracle::exchange(*b, P); }
+  void eval_Fxc(int x, int c, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin, double thr) override {
+    oracle::eval_Fxc(*b, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
+  }
+  void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh, const std::vector<std::vector<size_t> > &sym) override {
+    oracle::eig_gsym_sub(E, C, F, Sinvh, sym);
+  }
+  Mat Sinvh(const Mat &S, bool chol, const std::vector<std::vector<size_t> > &sym) override {
+    return oracle::form_Sinvh(S, chol, sym);
+  }
+  Mat gemm(const Mat &A, bool tA, const Mat &B, bool tB) override { return helfem::matmul(A, tA, B, tB); }
+};
+}  // namespace
+
+extern "C" {
+
+const char *orc_last_error() { return g_err.c_str(); }
+
+int orc_basis_create(int Z1, int Z2, double Rhalf, int nnodes, int nquad, const double *bval, int nbval,
+                     const int *lval, const int *mval, int nang, int lpad, void **out) {
+  ORC_TRY
+  *out = new TwoDBasis(Z1, Z2, Rhalf, nnodes, nquad, Vec(bval, bval + nbval), helfem::IVec(lval, lval + nang),
+                       helfem::IVec(mval, mval + nang), lpad);
+  ORC_CATCH
+}
+int orc_basis_destroy(void *h) {
+  delete (TwoDBasis *)h;
+  return 0;
+}
+int orc_basis_dims(void *h, int64_t *Nbf, int64_t *Ndummy, int64_t *Nrad, int64_t *Nang, int64_t *Nel) {
+  TwoDBasis *b = (TwoDBasis *)h;
+  *Nbf = b->Nbf();
+  *Ndummy = b->Ndummy();
+  *Nrad = b->Nrad();
+  *Nang = b->Nang();
+  *Nel = b->Nel();
+  return 0;
+}
+int orc_compute_tei(void *h, int exchange) {
+  ORC_TRY((TwoDBasis *)h)->compute_tei(exchange != 0);
+  ORC_CATCH
+}
+int orc_coulomb(void *h, const double *P, double *J) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  Mat Jm = coulomb(*b, to_mat(P, N, N));
+  memcpy(J, Jm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_exchange(void *h, const double *P, double *K) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  Mat Km = exchange(*b, to_mat(P, N, N));
+  memcpy(K, Km.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_eval_fxc(void *h, int lang, int mang, int x_func, int c_func, const double *P, double *H, double *Exc,
+                 double *Nel, double *Ekin, double thr, long q_begin, long q_end) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  Mat Hm;
+  eval_Fxc(*b, lang, mang, x_func, c_func, to_mat(P, N, N), Hm, *Exc, *Nel, *Ekin, thr, q_begin, q_end);
+  memcpy(H, Hm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_grid_overlap(void *h, int lang, int mang, double *S) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  Mat Sm = grid_overlap(*b, lang, mang);
+  memcpy(S, Sm.memptr(), sizeof(double) * Sm.n_elem());
+  ORC_CATCH
+}
+int orc_grid_kinetic(void *h, int lang, int mang, double *T) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  Mat Tm = grid_kinetic(*b, lang, mang);
+  memcpy(T, Tm.memptr(), sizeof(double) * Tm.n_elem());
+  ORC_CATCH
+}
+int orc_eig_sym(int64_t n, const double *A, double *E, double *C) {
+  ORC_TRY
+  Vec Ev;
+  Mat Cm;
+  eig_sym(Ev, Cm, to_mat(A, n, n));
+  memcpy(E, Ev.data(), sizeof(double) * n);
+  memcpy(C, Cm.memptr(), sizeof(double) * n * n);
+  ORC_CATCH
+}
+int orc_eig_gsym(int64_t N, int64_t n, const double *F, const double *Sinvh, double *E, double *C) {
+  ORC_TRY
+  Vec Ev;
+  Mat Cm;
+  eig_gsym(Ev, Cm, to_mat(F, N, N), to_mat(Sinvh, N, n));
+  memcpy(E, Ev.data(), sizeof(double) * n);
+  memcpy(C, Cm.memptr(), sizeof(double) * N * n);
+  ORC_CATCH
+}
+int orc_eig_gsym_sub(int64_t N, const double *F, const double *Sinvh, int nblk, const int64_t *blk_ptr,
+                     const int64_t *blk_idx, double *E, double *C) {
+  ORC_TRY
+  Vec Ev;
+  Mat Cm;
+  eig_gsym_sub(Ev, Cm, to_mat(F, N, N), to_mat(Sinvh, N, N), to_blocks(nblk, blk_ptr, blk_idx));
+  memcpy(E, Ev.data(), sizeof(double) * N);
+  memcpy(C, Cm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_form_sinvh(int64_t N, const double *S, int chol, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
+                   double *Sinvh) {
+  ORC_TRY
+  Mat X = form_Sinvh(to_mat(S, N, N), chol != 0, to_blocks(nblk, blk_ptr, blk_idx));
+  memcpy(Sinvh, X.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_form_density(int64_t N, int64_t ncols, const double *C, int64_t nocc, double *P) {
+  ORC_TRY
+  Mat Pm = form_density(to_mat(C, N, ncols), nocc);
+  memcpy(P, Pm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_xc_unpolarized(int func_id, int64_t N, const double *rho, const double *sigma, double *exc, double *vrho,
+                       double *vsigma, double thr) {
+  ORC_TRY
+  xc_unpolarized(func_id, N, rho, sigma, exc, vrho, vsigma, thr);
+  ORC_CATCH
+}
+
+/// Restricted closed-shell diatomic SCF on the CPU oracle.  out[0..7] = Etot, Ekin, Epot, Ecoul, Exx, Exc,
+/// Enucr, iterations(+0.5 if converged)
+int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, int nelem, int nnodes, int nquad,
+                     double Rmax, int igrid, double zexp, int lpad, const char *method, int ldft, int mdft,
+                     int symmetry, int maxit, double convthr, int verbose, double *out) {
+  ORC_TRY
+  helfem::scf::Options o;
+  o.Z1 = Z1;
+  o.Z2 = Z2;
+  o.Rbond = Rbond;
+  o.lmmax.assign(lmmax, lmmax + nlm);
+  o.nelem = nelem;
+  o.nnodes = nnodes;
+  o.nquad = nquad;
+  o.Rmax = Rmax;
+  o.igrid = igrid;
+  o.zexp = zexp;
+  o.lpad = lpad;
+  o.method = method;
+  parse_xc_func(o.x_func, o.c_func, o.method);
+  o.kfrac = (o.x_func == -1) ? 1.0 : 0.0;
+  o.ldft = ldft;
+  o.mdft = mdft;
+  o.symmetry = symmetry;
+  o.maxit = maxit;
+  o.convthr = convthr;
+  o.verbose = verbose != 0;
+  OracleBackend be;
+  helfem::scf::Result r = helfem::scf::run_diatomic(o, be);
+  out[0] = r.Etot;
+  out[1] = r.Ekin;
+  out[2] = r.Epot;
+  out[3] = r.Ecoul;
+  out[4] = r.Exx;
+  out[5] = r.Exc;
+  out[6] = r.Enucr;
+  out[7] = r.iterations + (r.converged ? 0.5 : 0.0);
+  ORC_CATCH
+}
+
+}  // extern "C"
