@@ -1,0 +1,380 @@
+"""helfem_amd — MI355X-native (gfx950) implementation of HelFEM's SCF hot path.
+
+Thin ctypes binding over the C ABI of include/helfem_gpu.h (helfem_amd/lib/libhelfem_amd.so).  The
+class and method names mirror the reference's C++ interface for this path so that tests and drivers
+read like the reference's own code:
+
+    reference (C++)                                   here
+    ------------------------------------------------  ---------------------------------------------
+    diatomic::basis::TwoDBasis(Z1,Z2,Rhalf,poly,      TwoDBasis(Z1,Z2,Rhalf,nnodes,nquad,bval,lval,mval,lpad)
+        n_quad,bval,lval,mval,lpad)   basis.cpp:307
+    basis.overlap()/kinetic()/nuclear()               same
+    basis.compute_tei(exchange)        basis.cpp:1166  same
+    basis.coulomb(P) / exchange(P)     basis.cpp:1359  same (numpy in / numpy out)
+    dftgrid::DFTGrid(&basis,ldft,mdft).eval_Fxc(...)  DFTGrid(basis,ldft,mdft).eval_Fxc(x_func,c_func,P,thr)
+    scf::eig_gsym / eig_gsym_sub / form_density       scf.eig_gsym / scf.eig_gsym_sub / scf.form_density
+
+There is no CPU fallback: every compute call needs a gfx950 device and raises RuntimeError otherwise.
+Matrices are numpy float64 arrays in Fortran (column-major) order, i.e. arma::mat memory.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libhelfem_amd.so")
+_lib = None
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+class hfg_diatomic_desc(ctypes.Structure):
+    _fields_ = [("Z1", ctypes.c_int), ("Z2", ctypes.c_int), ("Rhalf", ctypes.c_double), ("primbas", ctypes.c_int),
+                ("nnodes", ctypes.c_int), ("nquad", ctypes.c_int), ("bval", c_double_p), ("nbval", ctypes.c_int),
+                ("lval", c_int_p), ("mval", c_int_p), ("nang", ctypes.c_int), ("lpad", ctypes.c_int)]
+
+
+def lib():
+    """Load the native library (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError("%s is missing: run `python -m helfem_amd.build` (or __graft_entry__.build()) first; "
+                               "there is no Python/CPU fallback for the hot path" % _LIB_PATH)
+        L = ctypes.CDLL(_LIB_PATH)
+        L.hfg_last_error.restype = ctypes.c_char_p
+        L.hfg_version.restype = ctypes.c_char_p
+        L.hfg_gaunt_coefficient.restype = ctypes.c_double
+        L.hfg_gaunt_coefficient.argtypes = [ctypes.c_int] * 6
+        L.hfg_modified_gaunt_coefficient.restype = ctypes.c_double
+        L.hfg_modified_gaunt_coefficient.argtypes = [ctypes.c_int] * 6
+        L.hfg_theta_lm.restype = ctypes.c_double
+        L.hfg_theta_lm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.hfg_legendre_PQ.restype = None
+        L.hfg_legendre_PQ.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p]
+        L.hfg_chebyshev_rule.restype = None
+        L.hfg_chebyshev_rule.argtypes = [ctypes.c_int, c_double_p, c_double_p]
+        L.hfg_lobatto_nodes.restype = None
+        L.hfg_lobatto_nodes.argtypes = [ctypes.c_int, c_double_p]
+        L.hfg_radial_grid.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p]
+        L.hfg_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]
+        L.hfg_xc_fock.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                  c_double_p, c_double_p, c_double_p, ctypes.c_double]
+        L.hfg_xc_fock_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+        L.hfg_profile_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, c_double_p, c_i64_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().hfg_last_error().decode())
+
+
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def device_count():
+    return int(lib().hfg_device_count())
+
+
+class Context(object):
+    """hfg_ctx: one device + one stream."""
+
+    def __init__(self, device=0, stream=None):
+        h = ctypes.c_void_p()
+        _check(lib().hfg_ctx_create(ctypes.byref(h), int(device), ctypes.c_void_p(stream) if stream else None))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().hfg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().hfg_ctx_synchronize(self.h))
+
+    def set_shard(self, rank, nranks):
+        _check(lib().hfg_ctx_set_shard(self.h, int(rank), int(nranks)))
+
+    def profile(self, on=True):
+        _check(lib().hfg_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(lib().hfg_profile_reset(self.h))
+
+    def profile_get(self, name):
+        ms = ctypes.c_double()
+        n = ctypes.c_int64()
+        _check(lib().hfg_profile_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def lm_to_l_m(lmmax):
+    """diatomic::basis::lm_to_l_m (basis.cpp:287)."""
+    lmmax = list(lmmax)
+    cap = sum(2 * (l + 1) for l in lmmax) + 4
+    lv = (ctypes.c_int * cap)()
+    mv = (ctypes.c_int * cap)()
+    n = ctypes.c_int(cap)
+    arr = (ctypes.c_int * len(lmmax))(*lmmax)
+    _check(lib().hfg_lm_list(arr, len(lmmax), lv, mv, ctypes.byref(n)))
+    return list(lv[:n.value]), list(mv[:n.value])
+
+
+def get_grid(mumax, nelem, igrid=4, zexp=1.0):
+    """utils::get_grid (libhelfem/src/grid.cpp:18)."""
+    b = np.zeros(nelem + 1)
+    _check(lib().hfg_radial_grid(float(mumax), int(nelem), int(igrid), float(zexp), _p(b)))
+    return b
+
+
+class TwoDBasis(object):
+    """diatomic::basis::TwoDBasis — setup on the host, coulomb/exchange on the GPU."""
+
+    def __init__(self, Z1, Z2, Rhalf, nnodes, nquad, bval, lval, mval, lpad=10, ctx=None):
+        self._bval = np.ascontiguousarray(bval, dtype=np.float64)
+        self._lval = (ctypes.c_int * len(lval))(*lval)
+        self._mval = (ctypes.c_int * len(mval))(*mval)
+        d = hfg_diatomic_desc(int(Z1), int(Z2), float(Rhalf), 4, int(nnodes), int(nquad), _p(self._bval),
+                              len(self._bval), self._lval, self._mval, len(lval), int(lpad))
+        h = ctypes.c_void_p()
+        _check(lib().hfg_diatomic_basis_create(ctypes.byref(d), ctypes.byref(h)))
+        self.h = h
+        self.ctx = ctx
+        self.lval, self.mval = list(lval), list(mval)
+        self._uploaded = None
+        dims = [ctypes.c_int64() for _ in range(5)]
+        _check(lib().hfg_basis_dims(self.h, *[ctypes.byref(x) for x in dims]))
+        self._Nbf, self._Ndummy, self._Nrad, self._Nang, self._Nel = [x.value for x in dims]
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().hfg_basis_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def Nbf(self):
+        return self._Nbf
+
+    def Ndummy(self):
+        return self._Ndummy
+
+    def Nrad(self):
+        return self._Nrad
+
+    def Nang(self):
+        return self._Nang
+
+    def Nel(self):
+        return self._Nel
+
+    def _mat(self, fn):
+        M = np.zeros((self._Nbf, self._Nbf), order="F")
+        _check(fn(self.h, _p(M)))
+        return M
+
+    def overlap(self):
+        return self._mat(lib().hfg_basis_overlap)
+
+    def kinetic(self):
+        return self._mat(lib().hfg_basis_kinetic)
+
+    def nuclear(self):
+        return self._mat(lib().hfg_basis_nuclear)
+
+    def get_sym_idx(self, symm):
+        n = ctypes.c_int()
+        _check(lib().hfg_basis_sym_blocks(self.h, int(symm), ctypes.byref(n), None, None))
+        ptr = np.zeros(n.value + 1, dtype=np.int64)
+        idx = np.zeros(self._Nbf, dtype=np.int64)
+        _check(lib().hfg_basis_sym_blocks(self.h, int(symm), ctypes.byref(n), ptr.ctypes.data_as(c_i64_p),
+                                          idx.ctypes.data_as(c_i64_p)))
+        return [idx[ptr[i]:ptr[i + 1]].copy() for i in range(n.value)]
+
+    def compute_tei(self, exchange=True):
+        _check(lib().hfg_compute_tei(self.h, 1 if exchange else 0))
+        self._uploaded = None
+
+    def upload(self, ldft=0, mdft=0, ctx=None):
+        """tables -> HBM (also sets up the XC grid of DFTGrid(basis, ldft, mdft))"""
+        ctx = ctx or self.ctx or default_context()
+        self.ctx = ctx
+        _check(lib().hfg_basis_upload(ctx.h, self.h, int(ldft), int(mdft)))
+        self._uploaded = (ldft, mdft)
+
+    def _ensure(self):
+        if self._uploaded is None:
+            self.upload()
+        return self.ctx
+
+    def coulomb(self, P):
+        ctx = self._ensure()
+        P = _f(P)
+        J = np.zeros_like(P, order="F")
+        _check(lib().hfg_coulomb(ctx.h, self.h, _p(P), _p(J)))
+        return J
+
+    def exchange(self, P):
+        ctx = self._ensure()
+        P = _f(P)
+        K = np.zeros_like(P, order="F")
+        _check(lib().hfg_exchange(ctx.h, self.h, _p(P), _p(K)))
+        return K
+
+
+class DFTGrid(object):
+    """diatomic::dftgrid::DFTGrid (dftgrid.cpp:760)."""
+
+    def __init__(self, basis, ldft, mdft):
+        self.basis, self.ldft, self.mdft = basis, int(ldft), int(mdft)
+
+    def eval_Fxc(self, x_func, c_func, P, thr=1e-12):
+        """returns (H, Exc, Nel, Ekin) — DFTGrid::eval_Fxc, restricted (dftgrid.cpp:769)."""
+        b = self.basis
+        if b._uploaded != (self.ldft, self.mdft):
+            b.upload(self.ldft, self.mdft)
+        P = _f(P)
+        H = np.zeros_like(P, order="F")
+        exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(lib().hfg_xc_fock(b.ctx.h, b.h, int(x_func), int(c_func), _p(P), _p(H), ctypes.byref(exc),
+                                 ctypes.byref(nel), ctypes.byref(ekin), float(thr)))
+        return H, exc.value, nel.value, ekin.value
+
+
+class scf(object):
+    """namespace helfem::scf (src/general/scf_helpers.h)."""
+
+    @staticmethod
+    def _blocks(m_idx):
+        ptr = np.zeros(len(m_idx) + 1, dtype=np.int64)
+        for i, b in enumerate(m_idx):
+            ptr[i + 1] = ptr[i] + len(b)
+        idx = np.concatenate([np.asarray(b, dtype=np.int64) for b in m_idx]) if len(m_idx) else np.zeros(0, np.int64)
+        return ptr, np.ascontiguousarray(idx)
+
+    @staticmethod
+    def eig_gsym(F, Sinvh, ctx=None):
+        ctx = ctx or default_context()
+        F, Sinvh = _f(F), _f(Sinvh)
+        N, n = Sinvh.shape
+        E = np.zeros(n)
+        C = np.zeros((N, n), order="F")
+        _check(lib().hfg_eig_gsym(ctx.h, ctypes.c_int64(N), ctypes.c_int64(n), _p(F), _p(Sinvh), _p(E), _p(C)))
+        return E, C
+
+    @staticmethod
+    def eig_gsym_sub(F, Sinvh, m_idx, ctx=None):
+        ctx = ctx or default_context()
+        F, Sinvh = _f(F), _f(Sinvh)
+        N = F.shape[0]
+        ptr, idx = scf._blocks(m_idx)
+        E = np.zeros(N)
+        C = np.zeros((N, N), order="F")
+        _check(lib().hfg_eig_gsym_sub(ctx.h, ctypes.c_int64(N), _p(F), _p(Sinvh), len(m_idx),
+                                      ptr.ctypes.data_as(c_i64_p), idx.ctypes.data_as(c_i64_p), _p(E), _p(C)))
+        return E, C
+
+    @staticmethod
+    def eig_sym(A, ctx=None):
+        ctx = ctx or default_context()
+        A = _f(A)
+        n = A.shape[0]
+        E = np.zeros(n)
+        C = np.zeros((n, n), order="F")
+        _check(lib().hfg_eig_sym(ctx.h, ctypes.c_int64(n), _p(A), _p(E), _p(C)))
+        return E, C
+
+    @staticmethod
+    def form_Sinvh(S, chol, m_idx, ctx=None):
+        ctx = ctx or default_context()
+        S = _f(S)
+        N = S.shape[0]
+        ptr, idx = scf._blocks(m_idx)
+        X = np.zeros((N, N), order="F")
+        _check(lib().hfg_form_sinvh(ctx.h, ctypes.c_int64(N), _p(S), 1 if chol else 0, len(m_idx),
+                                    ptr.ctypes.data_as(c_i64_p), idx.ctypes.data_as(c_i64_p), _p(X)))
+        return X
+
+    @staticmethod
+    def form_density(C, nocc, ctx=None):
+        ctx = ctx or default_context()
+        C = _f(C)
+        N, nc = C.shape
+        P = np.zeros((N, N), order="F")
+        _check(lib().hfg_form_density(ctx.h, ctypes.c_int64(N), ctypes.c_int64(nc), _p(C), ctypes.c_int64(nocc), _p(P)))
+        return P
+
+    @staticmethod
+    def gemm(A, B, transA=False, transB=False, ctx=None):
+        ctx = ctx or default_context()
+        A, B = _f(A), _f(B)
+        m = A.shape[1] if transA else A.shape[0]
+        k = A.shape[0] if transA else A.shape[1]
+        n = B.shape[0] if transB else B.shape[1]
+        C = np.zeros((m, n), order="F")
+        _check(lib().hfg_gemm(ctx.h, int(transA), int(transB), ctypes.c_int64(m), ctypes.c_int64(n), ctypes.c_int64(k),
+                              _p(A), ctypes.c_int64(A.shape[0]), _p(B), ctypes.c_int64(B.shape[0]), _p(C),
+                              ctypes.c_int64(m)))
+        return C
+
+
+# ---- host-side special functions (pinned against the reference's known-answer tests) ----
+def gaunt_coefficient(L, M, l, m, lp, mp):
+    return lib().hfg_gaunt_coefficient(L, M, l, m, lp, mp)
+
+
+def modified_gaunt_coefficient(lj, mj, L, M, li, mi):
+    return lib().hfg_modified_gaunt_coefficient(lj, mj, L, M, li, mi)
+
+
+def legendre_PQ(Lmax, Mmax, xi):
+    """(P, Q) arrays [L, M] — layout of the Fortran wrapper calc_Plm_arr / calc_Qlm_arr."""
+    P = np.zeros((Mmax + 1, Lmax + 1))
+    Q = np.zeros((Mmax + 1, Lmax + 1))
+    lib().hfg_legendre_PQ(int(Lmax), int(Mmax), float(xi), _p(P), _p(Q))
+    return P.T.copy(), Q.T.copy()
+
+
+def theta_lm(l, m, cth):
+    return lib().hfg_theta_lm(int(l), int(m), float(cth))
+
+
+def chebyshev(n):
+    x, w = np.zeros(n), np.zeros(n)
+    lib().hfg_chebyshev_rule(int(n), _p(x), _p(w))
+    return x, w
+
+
+def lobatto_nodes(n):
+    x = np.zeros(n)
+    lib().hfg_lobatto_nodes(int(n), _p(x))
+    return x

@@ -1,0 +1,89 @@
+"""In-tree build of the native libraries.
+
+  helfem_amd/lib/libhelfem_amd.so   product: host setup code + HIP kernels + C ABI (hipcc, gfx950)
+  oracle/liboracle.so               test-only CPU checker (g++)
+  oracle/_ref/libref_legendre.so    the one buildable piece of the reference (only if /root/reference exists)
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only container too.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "helfem_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "helfem_amd", "lib")
+OBJDIR = os.path.join(ROOT, "helfem_amd", "build")
+
+HOST_SRCS = ["host/fem.cpp", "host/special.cpp", "host/diatomic_basis.cpp", "host/scf.cpp"]
+HIP_SRCS = ["hip/tables.cpp", "hip/capi.cpp", "hip/fock.hip", "hip/exchange.hip", "hip/gemm.hip", "hip/eig.hip",
+            "hip/misc.hip"]
+
+
+def _newer(src, dst, extra_deps=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(s) > t for s in (src,) + tuple(extra_deps))
+
+
+def _headers():
+    hs = []
+    for d in ("host", "hip"):
+        dd = os.path.join(CSRC, d)
+        hs += [os.path.join(dd, f) for f in os.listdir(dd) if f.endswith(".h")]
+    hs.append(os.path.join(ROOT, "include", "helfem_gpu.h"))
+    return hs
+
+
+def build_product(verbose=True, force=False):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = _headers()
+    objs = []
+    procs = []
+    for rel in HOST_SRCS + HIP_SRCS:
+        src = os.path.join(CSRC, rel)
+        obj = os.path.join(OBJDIR, rel.replace("/", "_") + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj, hdrs):
+            cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-result", "-c", src, "-o", obj]
+            if not rel.endswith(".hip"):
+                cmd.insert(1, "-x")
+                cmd.insert(2, "hip")
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((rel, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for rel, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("---- %s ----\n%s\n" % (rel, out))
+        elif verbose and "error" in out:
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    lib = os.path.join(LIBDIR, "libhelfem_amd.so")
+    if force or procs or not os.path.exists(lib):
+        cmd = [hipcc, "-shared", "--offload-arch=gfx950", "-o", lib] + objs + ["-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return lib
+
+
+def build_oracle(verbose=True):
+    cmd = ["make", "-C", os.path.join(ROOT, "oracle"), "-j8"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    ref = os.path.join(ROOT, "oracle", "build_ref.sh")
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["bash", ref], stdout=None if verbose else subprocess.DEVNULL)
+    return os.path.join(ROOT, "oracle", "liboracle.so")
+
+
+if __name__ == "__main__":
+    build_product(force="--force" in sys.argv)
+    build_oracle()

@@ -1,0 +1,470 @@
+// C ABI (include/helfem_gpu.h): contexts, host-side basis API, host-pointer and device-pointer
+// entry points.  No torch types, no exceptions across the boundary.
+#include "common.h"
+#include "tables.h"
+#include <cstring>
+#include <mutex>
+
+namespace hfg {
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+// implemented in the .hip translation units
+void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
+void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
+                 double thr);
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+void fock_release(hfg_dev_tables *t);
+void exchange_release(hfg_dev_tables *t);
+void eig_release(hfg_ctx *ctx);
+void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
+              const double *B, int ldb, double beta, double *C, int ldc);
+void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
+void eig_gsym_dev(hfg_ctx *ctx, int N, int n, const double *dF, const double *dS, double *dE, double *dC);
+void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                      const int64_t *blk_idx, double *dE, double *dC);
+void form_sinvh_dev(hfg_ctx *ctx, int N, const double *dS, bool chol, int nblk, const int64_t *blk_ptr,
+                    const int64_t *blk_idx, double *dSinvh);
+void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc, double *dP);
+}  // namespace hfg
+
+using namespace hfg;
+
+#define HFG_TRY try {
+#define HFG_CATCH                   \
+  }                                 \
+  catch (const std::exception &e) { \
+    hfg::set_error(e.what());       \
+    return 1;                       \
+  }                                 \
+  return 0;
+
+// ---- context helpers ---------------------------------------------------------------------------
+void *hfg_ctx::pinned_buf(size_t bytes) {
+  if (bytes > pinned_bytes) {
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    HFG_HIP_CHECK(hipHostMalloc((void **)&pinned, bytes, hipHostMallocDefault));
+    pinned_bytes = bytes;
+  }
+  return pinned;
+}
+hipEvent_t hfg_ctx::get_event() {
+  if (!event_pool.empty()) {
+    hipEvent_t e = event_pool.back();
+    event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HFG_HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+void hfg_ctx::prof_begin(const char *name) {
+  hipEvent_t a = get_event(), b = get_event();
+  HFG_HIP_CHECK(hipEventRecord(a, stream));
+  prof[name].pending.push_back(std::make_pair(a, b));
+}
+void hfg_ctx::prof_end(const char *name) {
+  ProfEntry &p = prof[name];
+  HFG_HIP_CHECK(hipEventRecord(p.pending.back().second, stream));
+  p.launches++;
+}
+void hfg_ctx::prof_collect() {
+  for (auto &kv : prof) {
+    for (auto &ev : kv.second.pending) {
+      float ms = 0.f;
+      HFG_HIP_CHECK(hipEventSynchronize(ev.second));
+      HFG_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+      kv.second.ms += ms;
+      event_pool.push_back(ev.first);
+      event_pool.push_back(ev.second);
+    }
+    kv.second.pending.clear();
+  }
+}
+
+namespace {
+// scoped device staging of host matrices
+struct Stage {
+  hfg_ctx *ctx;
+  std::vector<double *> bufs;
+  explicit Stage(hfg_ctx *c) : ctx(c) { HFG_HIP_CHECK(hipSetDevice(c->device)); }
+  ~Stage() {
+    for (double *p : bufs) (void)hipFree(p);
+  }
+  double *alloc(size_t n) {
+    double *p = nullptr;
+    HFG_HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(double)));
+    bufs.push_back(p);
+    return p;
+  }
+  double *up(const double *h, size_t n) {
+    double *p = alloc(n);
+    HFG_HIP_CHECK(hipMemcpyAsync(p, h, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return p;
+  }
+  void down(double *h, const double *d, size_t n) {
+    HFG_HIP_CHECK(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  void sync() { HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+};
+
+void require_gpu() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw std::runtime_error("no usable HIP device: the helfem_amd hot path has no CPU fallback");
+}
+}  // namespace
+
+extern "C" {
+
+const char *hfg_last_error(void) { return g_err.c_str(); }
+const char *hfg_version(void) { return "helfem_amd 0.1 (gfx950)"; }
+
+int hfg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int hfg_ctx_create(hfg_ctx **out, int device, void *stream) {
+  HFG_TRY
+  require_gpu();
+  HFG_HIP_CHECK(hipSetDevice(device));
+  hfg_ctx *c = new hfg_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+  } else {
+    HFG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  *out = c;
+  HFG_CATCH
+}
+
+int hfg_ctx_destroy(hfg_ctx *c) {
+  HFG_TRY
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  eig_release(c);
+  for (auto &kv : c->prof)
+    for (auto &ev : kv.second.pending) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  HFG_CATCH
+}
+
+int hfg_ctx_synchronize(hfg_ctx *c) {
+  HFG_TRY
+  HFG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  HFG_CATCH
+}
+
+int hfg_ctx_set_shard(hfg_ctx *c, int rank, int nranks) {
+  HFG_TRY
+  if (nranks < 1 || rank < 0 || rank >= nranks) throw std::logic_error("invalid shard");
+  c->shard_rank = rank;
+  c->shard_n = nranks;
+  HFG_CATCH
+}
+
+// ---- basis ---------------------------------------------------------------------------------------
+int hfg_diatomic_basis_create(const hfg_diatomic_desc *d, hfg_basis **out) {
+  HFG_TRY
+  if (d->primbas != 4) throw std::logic_error("Unsupported primitive basis.\n");
+  hfg_basis *b = new hfg_basis();
+  b->b = helfem::diatomic::TwoDBasis(d->Z1, d->Z2, d->Rhalf, d->nnodes, d->nquad,
+                                     helfem::Vec(d->bval, d->bval + d->nbval),
+                                     helfem::IVec(d->lval, d->lval + d->nang),
+                                     helfem::IVec(d->mval, d->mval + d->nang), d->lpad);
+  *out = b;
+  HFG_CATCH
+}
+
+int hfg_basis_destroy(hfg_basis *b) {
+  HFG_TRY
+  if (!b) return 0;
+  if (b->dev) {
+    fock_release(b->dev);
+    exchange_release(b->dev);
+    delete b->dev;
+  }
+  delete b;
+  HFG_CATCH
+}
+
+int hfg_basis_dims(const hfg_basis *b, int64_t *Nbf, int64_t *Ndummy, int64_t *Nrad, int64_t *Nang, int64_t *Nel) {
+  if (Nbf) *Nbf = b->b.Nbf();
+  if (Ndummy) *Ndummy = b->b.Ndummy();
+  if (Nrad) *Nrad = b->b.Nrad();
+  if (Nang) *Nang = b->b.Nang();
+  if (Nel) *Nel = b->b.Nel();
+  return 0;
+}
+
+static int copy_out(const helfem::Mat &M, double *out) {
+  memcpy(out, M.memptr(), sizeof(double) * M.n_elem());
+  return 0;
+}
+int hfg_basis_overlap(const hfg_basis *b, double *S) {
+  HFG_TRY copy_out(b->b.overlap(), S);
+  HFG_CATCH
+}
+int hfg_basis_kinetic(const hfg_basis *b, double *T) {
+  HFG_TRY copy_out(b->b.kinetic(), T);
+  HFG_CATCH
+}
+int hfg_basis_nuclear(const hfg_basis *b, double *V) {
+  HFG_TRY copy_out(b->b.nuclear(), V);
+  HFG_CATCH
+}
+
+int hfg_basis_sym_blocks(const hfg_basis *b, int symm, int *nblk, int64_t *blk_ptr, int64_t *blk_idx) {
+  HFG_TRY
+  auto idx = b->b.get_sym_idx(symm);
+  *nblk = (int)idx.size();
+  if (blk_ptr) {
+    int64_t off = 0;
+    for (size_t i = 0; i < idx.size(); i++) {
+      blk_ptr[i] = off;
+      for (size_t k = 0; k < idx[i].size(); k++) blk_idx[off + k] = (int64_t)idx[i][k];
+      off += idx[i].size();
+    }
+    blk_ptr[idx.size()] = off;
+  }
+  HFG_CATCH
+}
+
+int hfg_compute_tei(hfg_basis *b, int exchange) {
+  HFG_TRY b->b.compute_tei(exchange != 0);
+  HFG_CATCH
+}
+
+int hfg_radial_grid(double mumax, int nelem, int igrid, double zexp, double *bval) {
+  HFG_TRY
+  helfem::Vec g = helfem::get_grid(mumax, nelem, igrid, zexp);
+  memcpy(bval, g.data(), sizeof(double) * g.size());
+  HFG_CATCH
+}
+
+int hfg_lm_list(const int *lmmax, int nlm, int *lval, int *mval, int *nang) {
+  HFG_TRY
+  helfem::IVec l, m;
+  helfem::diatomic::lm_to_l_m(helfem::IVec(lmmax, lmmax + nlm), l, m);
+  if ((int)l.size() > *nang) {
+    *nang = (int)l.size();
+    throw std::logic_error("hfg_lm_list: output capacity too small");
+  }
+  *nang = (int)l.size();
+  for (size_t i = 0; i < l.size(); i++) {
+    lval[i] = l[i];
+    mval[i] = m[i];
+  }
+  HFG_CATCH
+}
+
+double hfg_gaunt_coefficient(int L, int M, int l, int m, int lp, int mp) {
+  return helfem::gaunt_coefficient(L, M, l, m, lp, mp);
+}
+double hfg_modified_gaunt_coefficient(int lj, int mj, int L, int M, int li, int mi) {
+  helfem::Gaunt g;
+  return g.mod_coeff(lj, mj, L, M, li, mi);
+}
+void hfg_legendre_PQ(int Lmax, int Mmax, double xi, double *P, double *Q) { helfem::legendre_PQ(Lmax, Mmax, xi, P, Q); }
+double hfg_theta_lm(int l, int m, double cth) { return helfem::theta_lm(l, m, cth); }
+void hfg_chebyshev_rule(int n, double *x, double *w) {
+  helfem::Vec xv, wv;
+  helfem::chebyshev_rule(n, xv, wv);
+  memcpy(x, xv.data(), sizeof(double) * n);
+  memcpy(w, wv.data(), sizeof(double) * n);
+}
+void hfg_lobatto_nodes(int n, double *x) {
+  helfem::Vec xv = helfem::lobatto_nodes(n);
+  memcpy(x, xv.data(), sizeof(double) * n);
+}
+
+int hfg_basis_upload(hfg_ctx *ctx, hfg_basis *b, int ldft, int mdft) {
+  HFG_TRY
+  if (b->dev) {
+    fock_release(b->dev);
+    exchange_release(b->dev);
+  }
+  upload_tables(ctx, b, ldft, mdft);
+  HFG_CATCH
+}
+
+// ---- device-pointer API --------------------------------------------------------------------------
+int hfg_coulomb_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, double *dJ) {
+  HFG_TRY coulomb_dev(ctx, b, dP, dJ);
+  HFG_CATCH
+}
+int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, double *dK) {
+  HFG_TRY exchange_dev(ctx, b, dP, dK);
+  HFG_CATCH
+}
+int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *dP, double *dH, double *dScal,
+                    double thr) {
+  HFG_TRY xc_fock_dev(ctx, b, x_func, c_func, dP, dH, dScal, thr);
+  HFG_CATCH
+}
+int hfg_eig_gsym_sub_dev(hfg_ctx *ctx, int64_t N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                         const int64_t *blk_idx, double *dE, double *dC) {
+  HFG_TRY eig_gsym_sub_dev(ctx, (int)N, dF, dS, nblk, blk_ptr, blk_idx, dE, dC);
+  HFG_CATCH
+}
+int hfg_form_density_dev(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *dC, int64_t nocc, double *dP) {
+  HFG_TRY form_density_dev(ctx, (int)N, (int)ncols, dC, (int)nocc, dP);
+  HFG_CATCH
+}
+int hfg_gemm_dev(hfg_ctx *ctx, int tA, int tB, int64_t m, int64_t n, int64_t k, const double *dA, int64_t lda,
+                 const double *dB, int64_t ldb, double *dC, int64_t ldc) {
+  HFG_TRY gemm_dev(ctx, tA != 0, tB != 0, (int)m, (int)n, (int)k, 1.0, dA, (int)lda, dB, (int)ldb, 0.0, dC, (int)ldc);
+  HFG_CATCH
+}
+
+// ---- host-pointer API ------------------------------------------------------------------------------
+int hfg_coulomb(hfg_ctx *ctx, hfg_basis *b, const double *P, double *J) {
+  HFG_TRY
+  size_t N = b->b.Nbf();
+  Stage st(ctx);
+  double *dP = st.up(P, N * N), *dJ = st.alloc(N * N);
+  coulomb_dev(ctx, b, dP, dJ);
+  st.down(J, dJ, N * N);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
+  HFG_TRY
+  size_t N = b->b.Nbf();
+  Stage st(ctx);
+  double *dP = st.up(P, N * N), *dK = st.alloc(N * N);
+  exchange_dev(ctx, b, dP, dK);
+  st.down(K, dK, N * N);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *P, double *H, double *Exc,
+                double *Nel, double *Ekin, double thr) {
+  HFG_TRY
+  size_t N = b->b.Nbf();
+  Stage st(ctx);
+  double *dP = st.up(P, N * N), *dH = st.alloc(N * N), *dS = st.alloc(3);
+  xc_fock_dev(ctx, b, x_func, c_func, dP, dH, dS, thr);
+  double sc[3];
+  st.down(H, dH, N * N);
+  st.down(sc, dS, 3);
+  st.sync();
+  *Exc = sc[0];
+  *Nel = sc[1];
+  *Ekin = sc[2];
+  HFG_CATCH
+}
+int hfg_eig_sym(hfg_ctx *ctx, int64_t n, const double *A, double *E, double *C) {
+  HFG_TRY
+  Stage st(ctx);
+  double *dA = st.up(A, n * n), *dE = st.alloc(n), *dC = st.alloc(n * n);
+  eig_sym_dev(ctx, (int)n, dA, dE, dC);
+  st.down(E, dE, n);
+  st.down(C, dC, n * n);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_eig_gsym(hfg_ctx *ctx, int64_t N, int64_t n, const double *F, const double *S, double *E, double *C) {
+  HFG_TRY
+  Stage st(ctx);
+  double *dF = st.up(F, N * N), *dS = st.up(S, N * n), *dE = st.alloc(n), *dC = st.alloc(N * n);
+  eig_gsym_dev(ctx, (int)N, (int)n, dF, dS, dE, dC);
+  st.down(E, dE, n);
+  st.down(C, dC, N * n);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_eig_gsym_sub(hfg_ctx *ctx, int64_t N, const double *F, const double *S, int nblk, const int64_t *blk_ptr,
+                     const int64_t *blk_idx, double *E, double *C) {
+  HFG_TRY
+  Stage st(ctx);
+  double *dF = st.up(F, N * N), *dS = st.up(S, N * N), *dE = st.alloc(N), *dC = st.alloc(N * N);
+  eig_gsym_sub_dev(ctx, (int)N, dF, dS, nblk, blk_ptr, blk_idx, dE, dC);
+  st.down(E, dE, N);
+  st.down(C, dC, N * N);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_form_sinvh(hfg_ctx *ctx, int64_t N, const double *S, int chol, int nblk, const int64_t *blk_ptr,
+                   const int64_t *blk_idx, double *Sinvh) {
+  HFG_TRY
+  Stage st(ctx);
+  double *dS = st.up(S, N * N), *dX = st.alloc(N * N);
+  form_sinvh_dev(ctx, (int)N, dS, chol != 0, nblk, blk_ptr, blk_idx, dX);
+  st.down(Sinvh, dX, N * N);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_form_density(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *C, int64_t nocc, double *P) {
+  HFG_TRY
+  Stage st(ctx);
+  double *dC = st.up(C, N * ncols), *dP = st.alloc(N * N);
+  form_density_dev(ctx, (int)N, (int)ncols, dC, (int)nocc, dP);
+  st.down(P, dP, N * N);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_gemm(hfg_ctx *ctx, int tA, int tB, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,
+             const double *B, int64_t ldb, double *C, int64_t ldc) {
+  HFG_TRY
+  Stage st(ctx);
+  size_t na = (size_t)lda * (tA ? m : k), nb = (size_t)ldb * (tB ? k : n);
+  double *dA = st.up(A, na), *dB = st.up(B, nb), *dC = st.alloc((size_t)ldc * n);
+  gemm_dev(ctx, tA != 0, tB != 0, (int)m, (int)n, (int)k, 1.0, dA, (int)lda, dB, (int)ldb, 0.0, dC, (int)ldc);
+  st.down(C, dC, (size_t)ldc * n);
+  st.sync();
+  HFG_CATCH
+}
+
+// ---- measurement -----------------------------------------------------------------------------------
+int hfg_profile_enable(hfg_ctx *ctx, int on) {
+  ctx->profiling = on != 0;
+  return 0;
+}
+int hfg_profile_reset(hfg_ctx *ctx) {
+  HFG_TRY
+  ctx->prof_collect();
+  for (auto &kv : ctx->prof) {
+    kv.second.ms = 0.0;
+    kv.second.launches = 0;
+  }
+  HFG_CATCH
+}
+int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches) {
+  HFG_TRY
+  ctx->prof_collect();
+  auto it = ctx->prof.find(name);
+  if (it == ctx->prof.end()) {
+    *ms = 0.0;
+    *launches = 0;
+  } else {
+    *ms = it->second.ms;
+    *launches = it->second.launches;
+  }
+  HFG_CATCH
+}
+
+int hfg_pin(void *p, size_t bytes) {
+  HFG_TRY HFG_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  HFG_CATCH
+}
+int hfg_unpin(void *p) {
+  HFG_TRY HFG_HIP_CHECK(hipHostUnregister(p));
+  HFG_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Shared declarations of the HIP side: context, error handling, device buffers, profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/helfem_gpu.h"
+#include "../host/diatomic_basis.h"
+
+namespace hfg {
+
+void set_error(const std::string &msg);
+
+#define HFG_HIP_CHECK(expr)                                                                          \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " in " + #expr + \
+                               " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")");              \
+  } while (0)
+
+// RAII device buffer
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void resize(size_t count) {
+    if (count <= n) return;
+    release();
+    HFG_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+  void upload(const std::vector<T> &h, hipStream_t s) {
+    resize(h.size() ? h.size() : 1);
+    if (h.size()) HFG_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+};
+
+struct ProfEntry {
+  double ms = 0.0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;
+};
+
+}  // namespace hfg
+
+// Flattened device-side description of a diatomic basis (see tables.cpp for the layouts)
+struct hfg_dev_tables;
+
+struct hfg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int shard_rank = 0, shard_n = 1;
+  bool profiling = false;
+  std::map<std::string, hfg::ProfEntry> prof;
+  std::vector<hipEvent_t> event_pool;
+  // scratch
+  hfg::DevBuf<double> ws[8];
+  hfg::DevBuf<double> hstage;  // unused placeholder
+  double *pinned = nullptr;
+  size_t pinned_bytes = 0;
+
+  void *pinned_buf(size_t bytes);
+  hipEvent_t get_event();
+  void prof_begin(const char *name);
+  void prof_end(const char *name);
+  void prof_collect();
+};
+
+struct hfg_basis {
+  helfem::diatomic::TwoDBasis b;
+  hfg_dev_tables *dev = nullptr;
+  int dev_device = -1;
+};
+
+namespace hfg {
+struct ProfScope {
+  hfg_ctx *c;
+  const char *n;
+  ProfScope(hfg_ctx *ctx, const char *name) : c(ctx), n(name) {
+    if (c->profiling) c->prof_begin(n);
+  }
+  ~ProfScope() {
+    if (c->profiling) c->prof_end(n);
+  }
+};
+}  // namespace hfg

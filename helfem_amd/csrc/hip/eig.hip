@@ -1,0 +1,674 @@
+// Dense symmetric / symmetric-definite generalized eigensolver on gfx950.
+//
+// Replaces (reference, /root/reference):
+//   scf::eig_gsym      src/general/scf_helpers.cpp:131-140   Forth = Sinvh^T F Sinvh; eig_sym; C = Sinvh C
+//   scf::eig_gsym_sub  src/general/scf_helpers.cpp:142-186   the same per symmetry block + global sort
+//   arma::eig_sym      (LAPACK dsyevd) as called there and in utils::invh, libhelfem/src/utils.cpp:172
+//
+// Pipeline per (symmetry) block, all blocks batched in the same launches (grid.y = block):
+//   1. gather F(idx,idx), Sinvh(idx,cols)                       k_gather_block
+//   2. Forth = X^T (F X)                                        FP64 MFMA GEMM (gemm.hip)
+//   3. Householder tridiagonalisation, two launches per column   k_trd_gemv / k_trd_update
+//        (symv-like sweep over the trailing matrix: bandwidth bound, matrix resident in L2/MALL)
+//   4. tridiagonal eigenproblem                                  implicit QL, rotations logged then
+//                                                                applied row-parallel (k_tql_*)
+//   5. back-transformation Z <- H_0 ... H_{n-3} Z                k_backtransform (column-parallel, no
+//                                                                inter-workgroup dependency at all)
+//   6. C = X Z                                                   GEMM, then rank sort + scatter
+#include "common.h"
+
+namespace hfg {
+
+void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
+              const double *B, int ldb, double beta, double *C, int ldc);
+
+constexpr int MAXB = 8;
+struct EigBatch {
+  int nblk;
+  int n[MAXB];
+  double *A[MAXB];    // n x n, lda = n; on exit Householder vectors below the subdiagonal
+  double *d[MAXB];    // n
+  double *e[MAXB];    // n
+  double *tau[MAXB];  // n
+  double *v[MAXB];    // n   current Householder vector (v[0]=1 stored explicitly)
+  double *pp[MAXB];   // NCS x n partial gemv results
+  double *dots[MAXB];  // partial v^T A v per gemv workgroup
+  double *Z[MAXB];    // n x n eigenvectors
+  double *rot[MAXB];  // rotation log (c,s pairs)
+  int *sweeps[MAXB];  // (l, m, offset, count) per QL sweep; sweeps[0] = number of sweeps, [1]=status
+  long rotcap[MAXB];
+};
+
+constexpr int TRD_NCS = 8;  // column slabs of the gemv
+
+// ---- 1. gather -----------------------------------------------------------------------------------
+__global__ void k_gather_block(const double *__restrict__ F, const double *__restrict__ S, int N,
+                               const int64_t *__restrict__ rows, const int64_t *__restrict__ cols, int n,
+                               double *__restrict__ Fb, double *__restrict__ Xb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y;
+  if (i >= n) return;
+  Fb[(size_t)j * n + i] = F[(size_t)rows[j] * N + rows[i]];
+  Xb[(size_t)j * n + i] = S[(size_t)cols[j] * N + rows[i]];
+}
+
+// column support of Sinvh on the block rows (scf_helpers.cpp:150-157): flag[c] = any(Sinvh(rows,c) != 0)
+__global__ void k_col_support(const double *__restrict__ S, int N, const int64_t *__restrict__ rows, int n,
+                              int *__restrict__ flag) {
+  int c = blockIdx.x;
+  int any = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (S[(size_t)c * N + rows[i]] != 0.0) any = 1;
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) flag[c] = any;
+}
+
+// ---- 3. tridiagonalisation -----------------------------------------------------------------------
+// Householder vector of column k (LAPACK dlarfg), computed identically by every workgroup.
+__device__ inline void householder_of_column(const double *__restrict__ A, int n, int k, double *vsh, double *red,
+                                             double &tau, double &beta) {
+  const int m = n - k - 1;  // length of x = A[k+1:n, k]
+  const double *x = A + (size_t)k * n + k + 1;
+  double s = 0.0;
+  for (int i = 1 + threadIdx.x; i < m; i += blockDim.x) s += x[i] * x[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  int nwave = blockDim.x / 64;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double xn2 = 0.0;
+  for (int w = 0; w < nwave; w++) xn2 += red[w];
+  double alpha = x[0];
+  double scale;
+  if (xn2 == 0.0) {
+    tau = 0.0;
+    beta = alpha;
+    scale = 0.0;
+  } else {
+    double nrm = sqrt(alpha * alpha + xn2);
+    beta = (alpha >= 0.0) ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  for (int i = threadIdx.x; i < m; i += blockDim.x) vsh[i] = (i == 0) ? 1.0 : x[i] * scale;
+  __syncthreads();
+}
+
+// S1: partial p = A22 v over (64-row slab) x (column slab); partial v^T A22 v
+__global__ __launch_bounds__(256) void k_trd_gemv(EigBatch b, int k) {
+  extern __shared__ double sh[];  // v[nmax], red[4*64 + 8]
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  if (k > n - 3) return;
+  const int m = n - k - 1;
+  const int nrs = (m + 63) / 64;
+  const int rs = blockIdx.x / TRD_NCS, cs = blockIdx.x % TRD_NCS;
+  if (rs >= nrs) return;
+  double *A = b.A[blk];
+  double *vsh = sh;
+  double *red = sh + n;
+  double tau, beta;
+  householder_of_column(A, n, k, vsh, red, tau, beta);
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < m; i += blockDim.x) b.v[blk][i] = vsh[i];
+    if (threadIdx.x == 0) {
+      b.tau[blk][k] = tau;
+      b.e[blk][k] = beta;
+      b.d[blk][k] = A[(size_t)k * n + k];
+    }
+  }
+  const int cchunk = (m + TRD_NCS - 1) / TRD_NCS;
+  const int c0 = cs * cchunk, c1 = min(m, c0 + cchunk);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = rs * 64 + lane;  // local index in trailing block
+  double acc = 0.0;
+  if (row < m) {
+    const double *a = A + (size_t)(k + 1) * n + (k + 1) + row;  // A22(row, 0)
+    for (int c = c0 + wave; c < c1; c += 4) acc += a[(size_t)c * n] * vsh[c];
+  }
+  __syncthreads();
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    double p = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+    if (row < m) b.pp[blk][(size_t)cs * n + row] = p;
+    double dv = (row < m) ? p * vsh[row] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) dv += __shfl_down(dv, o, 64);
+    if (lane == 0) b.dots[blk][blockIdx.x] = dv;
+  }
+}
+
+// S2: w = tau*p - (tau^2/2)(v^T A v) v ; A22 -= v w^T + w v^T on a 64x64 tile; first tile stores v into column k
+__global__ __launch_bounds__(256) void k_trd_update(EigBatch b, int k) {
+  __shared__ double vr[64], vc[64], wr[64], wc[64];
+  __shared__ double Ksh;
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  if (k > n - 3) return;
+  const int m = n - k - 1;
+  const int nt = (m + 63) / 64;
+  if ((int)blockIdx.x >= nt * nt) return;
+  const int tr = blockIdx.x % nt, tc = blockIdx.x / nt;
+  double *A = b.A[blk];
+  const double tau = b.tau[blk][k];
+  if (threadIdx.x == 0) {
+    const int nrs = (m + 63) / 64;
+    double s = 0.0;
+    for (int i = 0; i < nrs * TRD_NCS; i++) s += b.dots[blk][i];
+    Ksh = 0.5 * tau * tau * s;  // (tau/2) * p^T v with p = tau A v
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    int which = threadIdx.x >> 6, l = threadIdx.x & 63;
+    int idx = (which ? tc : tr) * 64 + l;
+    double v = 0.0, w = 0.0;
+    if (idx < m) {
+      v = b.v[blk][idx];
+      double p = 0.0;
+      for (int cs = 0; cs < TRD_NCS; cs++) p += b.pp[blk][(size_t)cs * n + idx];
+      w = tau * p - Ksh * v;
+    }
+    if (which) {
+      vc[l] = v;
+      wc[l] = w;
+    } else {
+      vr[l] = v;
+      wr[l] = w;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = tr * 64 + lane;
+  if (row < m) {
+    double *a = A + (size_t)(k + 1) * n + (k + 1) + row;
+    for (int c = wave; c < 64; c += 4) {
+      int col = tc * 64 + c;
+      if (col < m) a[(size_t)col * n] -= vr[lane] * wc[c] + wr[lane] * vc[c];
+    }
+  }
+  if (blockIdx.x == 0) {
+    // store v (without the implicit leading 1) below the subdiagonal of column k, beta on the subdiagonal
+    for (int i = 1 + threadIdx.x; i < m; i += blockDim.x) A[(size_t)k * n + k + 1 + i] = b.v[blk][i];
+  }
+}
+
+__global__ void k_trd_finish(EigBatch b) {
+  int blk = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  int n = b.n[blk];
+  double *A = b.A[blk];
+  if (n >= 2) {
+    b.d[blk][n - 2] = A[(size_t)(n - 2) * n + (n - 2)];
+    b.e[blk][n - 2] = A[(size_t)(n - 2) * n + (n - 1)];
+    b.tau[blk][n - 2] = 0.0;
+  }
+  b.d[blk][n - 1] = A[(size_t)(n - 1) * n + (n - 1)];
+  b.e[blk][n - 1] = 0.0;
+}
+
+// ---- 4. tridiagonal eigenproblem: implicit-shift QL, rotations logged --------------------------------
+__global__ void k_tql_values(EigBatch b) {
+  int blk = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const int n = b.n[blk];
+  double *d = b.d[blk], *e = b.e[blk];
+  double *rot = b.rot[blk];
+  int *sw = b.sweeps[blk];
+  long nrot = 0;
+  int nsw = 0;
+  int status = 0;
+  const long cap = b.rotcap[blk];
+  for (int l = 0; l < n && !status; l++) {
+    int iter = 0;
+    int m;
+    do {
+      for (m = l; m + 1 < n; m++) {
+        double dd = fabs(d[m]) + fabs(d[m + 1]);
+        if (fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 300) {
+          status = 1;
+          break;
+        }
+        if (nrot + (m - l) > cap || 4 * (nsw + 1) + 2 >= 4 * 64 * n) {
+          status = 2;
+          break;
+        }
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int cnt = 0;
+        bool under = false;
+        int i;
+        for (i = m - 1; i >= l; i--) {
+          double f = s * e[i], bb = c * e[i];
+          r = hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            under = true;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * bb;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - bb;
+          rot[2 * (nrot + cnt)] = c;
+          rot[2 * (nrot + cnt) + 1] = s;
+          cnt++;
+        }
+        sw[2 + 4 * nsw + 0] = l;
+        sw[2 + 4 * nsw + 1] = m;
+        sw[2 + 4 * nsw + 2] = (int)(nrot & 0x7fffffff);
+        sw[2 + 4 * nsw + 3] = cnt;
+        // offsets beyond 2^31 are reconstructed by the consumer as a running sum of cnt
+        nsw++;
+        nrot += cnt;
+        if (under) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  sw[0] = nsw;
+  sw[1] = status;
+}
+
+__global__ void k_set_identity(EigBatch b) {
+  int blk = blockIdx.z;
+  int n = b.n[blk];
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < n && j < n) b.Z[blk][(size_t)j * n + i] = (i == j) ? 1.0 : 0.0;
+}
+
+// apply the logged rotations to the rows of Z; one thread per row, columns walked as tql2 does
+__global__ void k_tql_apply(EigBatch b) {
+  int blk = blockIdx.y;
+  int n = b.n[blk];
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double *Z = b.Z[blk] + k;
+  const double *rot = b.rot[blk];
+  const int *sw = b.sweeps[blk];
+  int nsw = sw[0];
+  long off = 0;
+  for (int q = 0; q < nsw; q++) {
+    int m = sw[2 + 4 * q + 1], cnt = sw[2 + 4 * q + 3];
+    double hi = Z[(size_t)m * n];
+    int i = m - 1;
+    for (int t = 0; t < cnt; t++, i--) {
+      double c = rot[2 * (off + t)], s = rot[2 * (off + t) + 1];
+      double lo = Z[(size_t)i * n];
+      Z[(size_t)(i + 1) * n] = s * lo + c * hi;
+      hi = c * lo - s * hi;
+    }
+    Z[(size_t)(i + 1) * n] = hi;
+    off += cnt;
+  }
+}
+
+// ---- 5. back-transformation ----------------------------------------------------------------------------
+// Each wave owns one column z of Z (kept in registers, strided over the lanes) and applies
+// H_{n-3} ... H_0 in turn:  z[k+1:] -= tau_k v_k (v_k^T z[k+1:]).
+template <int NR>
+__global__ __launch_bounds__(256) void k_backtransform(EigBatch b) {
+  int blk = blockIdx.y;
+  int n = b.n[blk];
+  int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (col >= n) return;
+  const double *A = b.A[blk];
+  const double *tau = b.tau[blk];
+  double *z = b.Z[blk] + (size_t)col * n;
+  double zr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    int i = lane + 64 * r;
+    zr[r] = (i < n) ? z[i] : 0.0;
+  }
+  for (int k = n - 3; k >= 0; k--) {
+    double t = tau[k];
+    if (t == 0.0) continue;
+    const double *v = A + (size_t)k * n;  // v_i for i>k+1 at v[i], v_{k+1}=1
+    double s = 0.0;
+    double vr[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      int i = lane + 64 * r;
+      double vi = 0.0;
+      if (i == k + 1) vi = 1.0;
+      else if (i > k + 1 && i < n) vi = v[i];
+      vr[r] = vi;
+      s += vi * zr[r];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s *= t;
+#pragma unroll
+    for (int r = 0; r < NR; r++) zr[r] -= s * vr[r];
+  }
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    int i = lane + 64 * r;
+    if (i < n) z[i] = zr[r];
+  }
+}
+
+// generic (any n) version: column kept in LDS
+__global__ __launch_bounds__(256) void k_backtransform_lds(EigBatch b) {
+  extern __shared__ double sh[];  // 4 * n
+  int blk = blockIdx.y;
+  int n = b.n[blk];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int col = blockIdx.x * 4 + wave;
+  if (col >= n) return;
+  const double *A = b.A[blk];
+  const double *tau = b.tau[blk];
+  double *z = b.Z[blk] + (size_t)col * n;
+  double *zs = sh + (size_t)wave * n;
+  for (int i = lane; i < n; i += 64) zs[i] = z[i];
+  for (int k = n - 3; k >= 0; k--) {
+    double t = tau[k];
+    if (t == 0.0) continue;
+    const double *v = A + (size_t)k * n;
+    double s = 0.0;
+    for (int i = k + 1 + lane; i < n; i += 64) s += ((i == k + 1) ? 1.0 : v[i]) * zs[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s *= t;
+    for (int i = k + 1 + lane; i < n; i += 64) zs[i] -= s * ((i == k + 1) ? 1.0 : v[i]);
+  }
+  for (int i = lane; i < n; i += 64) z[i] = zs[i];
+}
+
+// ---- 6. sort + scatter ---------------------------------------------------------------------------------
+__global__ void k_rank(const double *__restrict__ E, int n, int *__restrict__ rank) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double ei = E[i];
+  int r = 0;
+  for (int j = 0; j < n; j++) {
+    double ej = E[j];
+    r += (ej < ei) || (ej == ei && j < i);
+  }
+  rank[i] = r;
+}
+
+// Cout(rows[i], rank[coff+j]) = Cb(i,j) ; Eout[rank[coff+j]] = Eb[j]   (rows==nullptr: identity)
+__global__ void k_scatter_cols(const double *__restrict__ Cb, int nrow, int ncol, const int64_t *__restrict__ rows,
+                               const int *__restrict__ rank, int coff, const double *__restrict__ Eb, int ldc,
+                               double *__restrict__ Cout, double *__restrict__ Eout) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = blockIdx.y;
+  if (i >= nrow) return;
+  int c = rank[coff + j];
+  size_t r = rows ? (size_t)rows[i] : (size_t)i;
+  Cout[(size_t)c * ldc + r] = Cb[(size_t)j * nrow + i];
+  if (i == 0) Eout[c] = Eb[j];
+}
+
+// -------------------------------------------------------------------------------------------------
+// host-side drivers
+// -------------------------------------------------------------------------------------------------
+struct EigWork {
+  DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
+  DevBuf<int> sweeps[MAXB];
+  DevBuf<int> ibuf1, ibuf2;
+};
+static std::map<hfg_ctx *, EigWork *> g_work;
+static EigWork &work_for(hfg_ctx *ctx) {
+  auto it = g_work.find(ctx);
+  if (it != g_work.end()) return *it->second;
+  EigWork *w = new EigWork();
+  g_work[ctx] = w;
+  return *w;
+}
+void eig_release(hfg_ctx *ctx) {
+  auto it = g_work.find(ctx);
+  if (it != g_work.end()) {
+    delete it->second;
+    g_work.erase(it);
+  }
+}
+
+/// Eigen-decomposition of nblk symmetric matrices already in w.A[blk] (n x n); eigenvalues end up in
+/// w.d[blk] (unsorted), eigenvectors in w.Z[blk].
+static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
+  EigBatch b;
+  b.nblk = nblk;
+  int nmax = 0;
+  for (int i = 0; i < nblk; i++) {
+    int n = ns[i];
+    nmax = std::max(nmax, n);
+    b.n[i] = n;
+    w.d[i].resize(n);
+    w.e[i].resize(n);
+    w.tau[i].resize(n);
+    w.v[i].resize(n);
+    w.pp[i].resize((size_t)TRD_NCS * n);
+    w.dots[i].resize((size_t)TRD_NCS * ((n + 63) / 64) + 8);
+    w.Z[i].resize((size_t)n * n);
+    long cap = 3L * n * n + 1024;
+    w.rot[i].resize(2 * (size_t)cap);
+    w.sweeps[i].resize((size_t)4 * 64 * n + 8);
+    b.rotcap[i] = cap;
+    b.A[i] = w.A[i].p;
+    b.d[i] = w.d[i].p;
+    b.e[i] = w.e[i].p;
+    b.tau[i] = w.tau[i].p;
+    b.v[i] = w.v[i].p;
+    b.pp[i] = w.pp[i].p;
+    b.dots[i] = w.dots[i].p;
+    b.Z[i] = w.Z[i].p;
+    b.rot[i] = w.rot[i].p;
+    b.sweeps[i] = w.sweeps[i].p;
+  }
+  hipStream_t s = ctx->stream;
+  {
+    ProfScope ps(ctx, "eig_tridiag");
+    size_t shb = (size_t)(nmax + 4 * 64 + 8) * sizeof(double);
+    if (shb > 64 * 1024)
+      HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_trd_gemv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+    for (int k = 0; k <= nmax - 3; k++) {
+      int m = nmax - k - 1;
+      int nrs = (m + 63) / 64;
+      hipLaunchKernelGGL(k_trd_gemv, dim3(nrs * TRD_NCS, nblk), dim3(256), shb, s, b, k);
+      hipLaunchKernelGGL(k_trd_update, dim3(nrs * nrs, nblk), dim3(256), 0, s, b, k);
+    }
+    hipLaunchKernelGGL(k_trd_finish, dim3(nblk), dim3(64), 0, s, b);
+  }
+  {
+    ProfScope ps(ctx, "eig_tridiag_solve");
+    hipLaunchKernelGGL(k_set_identity, dim3((nmax + 255) / 256, nmax, nblk), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_tql_values, dim3(nblk), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_tql_apply, dim3((nmax + 63) / 64, nblk), dim3(64), 0, s, b);
+  }
+  {
+    ProfScope ps(ctx, "eig_backtransform");
+    dim3 grid((nmax + 3) / 4, nblk);
+    if (nmax <= 64 * 8)
+      hipLaunchKernelGGL(k_backtransform<8>, grid, dim3(256), 0, s, b);
+    else if (nmax <= 64 * 24)
+      hipLaunchKernelGGL(k_backtransform<24>, grid, dim3(256), 0, s, b);
+    else {
+      size_t shb = (size_t)4 * nmax * sizeof(double);
+      if (shb > 64 * 1024)
+        HFG_HIP_CHECK(
+            hipFuncSetAttribute((const void *)k_backtransform_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+      hipLaunchKernelGGL(k_backtransform_lds, grid, dim3(256), shb, s, b);
+    }
+  }
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+static void check_status(hfg_ctx *ctx, EigWork &w, int nblk) {
+  for (int i = 0; i < nblk; i++) {
+    int st[2];
+    HFG_HIP_CHECK(hipMemcpyAsync(st, w.sweeps[i].p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (st[1] != 0) throw std::logic_error("Eigendecomposition failed!\n");
+  }
+}
+
+// E (n), C (n x n) <- eig_sym(A) ; all device pointers
+void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC) {
+  EigWork &w = work_for(ctx);
+  w.A[0].resize((size_t)n * n);
+  HFG_HIP_CHECK(hipMemcpyAsync(w.A[0].p, dA, sizeof(double) * n * n, hipMemcpyDeviceToDevice, ctx->stream));
+  eig_sym_batch(ctx, w, 1, &n);
+  DevBuf<int> &rank = w.ibuf1;
+  rank.resize(n + 8);
+  hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w.d[0].p, n, rank.p);
+  hipLaunchKernelGGL(k_scatter_cols, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, w.Z[0].p, n, n,
+                     (const int64_t *)nullptr, rank.p, 0, w.d[0].p, n, dC, dE);
+  check_status(ctx, w, 1);
+}
+
+// scf::eig_gsym: F N x N, Sinvh N x n  ->  E (n), C (N x n)
+void eig_gsym_dev(hfg_ctx *ctx, int N, int n, const double *dF, const double *dS, double *dE, double *dC) {
+  EigWork &w = work_for(ctx);
+  w.A[0].resize((size_t)n * n);
+  DevBuf<double> &T1 = ctx->ws[0];
+  DevBuf<double> &Ctmp = ctx->ws[1];
+  T1.resize((size_t)N * n);
+  Ctmp.resize((size_t)N * n);
+  {
+    ProfScope ps(ctx, "eig_reduce");
+    gemm_dev(ctx, false, false, N, n, N, 1.0, dF, N, dS, N, 0.0, T1.p, N);
+    gemm_dev(ctx, true, false, n, n, N, 1.0, dS, N, T1.p, N, 0.0, w.A[0].p, n);
+  }
+  eig_sym_batch(ctx, w, 1, &n);
+  {
+    ProfScope ps(ctx, "eig_backtransform");
+    gemm_dev(ctx, false, false, N, n, n, 1.0, dS, N, w.Z[0].p, n, 0.0, Ctmp.p, N);
+  }
+  DevBuf<int> &rank = w.ibuf1;
+  rank.resize(n + 8);
+  hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w.d[0].p, n, rank.p);
+  hipLaunchKernelGGL(k_scatter_cols, dim3((N + 255) / 256, n), dim3(256), 0, ctx->stream, Ctmp.p, N, n,
+                     (const int64_t *)nullptr, rank.p, 0, w.d[0].p, N, dC, dE);
+  check_status(ctx, w, 1);
+}
+
+// scf::eig_gsym_sub
+void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                      const int64_t *blk_idx, double *dE, double *dC) {
+  EigWork &w = work_for(ctx);
+  hipStream_t s = ctx->stream;
+  if (nblk > MAXB) throw std::logic_error("eig_gsym_sub: more than 8 symmetry blocks not supported yet\n");
+  // block row indices on the device
+  DevBuf<double> &idxbuf = ctx->ws[2];  // reused as raw storage for int64 rows + cols
+  idxbuf.resize(2 * (size_t)N + 16);
+  int64_t *drows = (int64_t *)idxbuf.p;
+  int64_t *dcols = drows + N;
+  HFG_HIP_CHECK(hipMemcpyAsync(drows, blk_idx, sizeof(int64_t) * blk_ptr[nblk], hipMemcpyHostToDevice, s));
+  if (blk_ptr[nblk] != N) throw std::logic_error("Symmetry mismatch in eig_gsym_sub\n");
+
+  // column support of every block (scf_helpers.cpp:150-157)
+  DevBuf<int> &flag = w.ibuf2;
+  flag.resize((size_t)N * nblk + N + 8);
+  for (int ib = 0; ib < nblk; ib++) {
+    int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
+    if (n == 0) continue;
+    hipLaunchKernelGGL(k_col_support, dim3(N), dim3(256), 0, s, dS, N, drows + blk_ptr[ib], n, flag.p + (size_t)ib * N);
+  }
+  std::vector<int> hflag((size_t)N * nblk);
+  HFG_HIP_CHECK(hipMemcpyAsync(hflag.data(), flag.p, sizeof(int) * hflag.size(), hipMemcpyDeviceToHost, s));
+  HFG_HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<std::vector<int64_t> > cols(nblk);
+  std::vector<int64_t> allcols;
+  std::vector<int> coff(nblk + 1, 0);
+  for (int ib = 0; ib < nblk; ib++) {
+    for (int c = 0; c < N; c++)
+      if (hflag[(size_t)ib * N + c]) cols[ib].push_back(c);
+    coff[ib + 1] = coff[ib] + (int)cols[ib].size();
+    int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
+    if ((int)cols[ib].size() != n)
+      throw std::logic_error("eig_gsym_sub: Sinvh is not block structured (columns with support != block size)\n");
+    allcols.insert(allcols.end(), cols[ib].begin(), cols[ib].end());
+  }
+  if (coff[nblk] != N) throw std::logic_error("Symmetry mismatch in eig_gsym_sub\n");
+  HFG_HIP_CHECK(hipMemcpyAsync(dcols, allcols.data(), sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
+
+  DevBuf<double> &Etmp = ctx->ws[3];
+  Etmp.resize(N);
+  DevBuf<double> &Xall = ctx->ws[4];  // X blocks back to back
+  DevBuf<double> &Fb = ctx->ws[5];
+  DevBuf<double> &T1 = ctx->ws[0];
+  DevBuf<double> &Cb = ctx->ws[1];
+  size_t xtot = 0, nmax = 0;
+  for (int ib = 0; ib < nblk; ib++) {
+    size_t n = blk_ptr[ib + 1] - blk_ptr[ib];
+    xtot += n * n;
+    nmax = std::max(nmax, n);
+  }
+  Xall.resize(xtot);
+  Fb.resize(nmax * nmax);
+  T1.resize(nmax * nmax);
+  Cb.resize(nmax * nmax);
+
+  for (int c0 = 0; c0 < nblk; c0 += MAXB) {
+    int nb = std::min(MAXB, nblk - c0);
+    std::vector<int> ns(nb);
+    std::vector<size_t> xoff(nb);
+    size_t xo = 0;
+    for (int ib = 0; ib < c0; ib++) {
+      size_t n = blk_ptr[ib + 1] - blk_ptr[ib];
+      xo += n * n;
+    }
+    {
+      ProfScope ps(ctx, "eig_reduce");
+      for (int k = 0; k < nb; k++) {
+        int ib = c0 + k;
+        int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
+        ns[k] = n;
+        xoff[k] = xo;
+        xo += (size_t)n * n;
+        if (n == 0) continue;
+        w.A[k].resize((size_t)n * n);
+        double *Xb = Xall.p + xoff[k];
+        hipLaunchKernelGGL(k_gather_block, dim3((n + 255) / 256, n), dim3(256), 0, s, dF, dS, N, drows + blk_ptr[ib],
+                           dcols + coff[ib], n, Fb.p, Xb);
+        gemm_dev(ctx, false, false, n, n, n, 1.0, Fb.p, n, Xb, n, 0.0, T1.p, n);
+        gemm_dev(ctx, true, false, n, n, n, 1.0, Xb, n, T1.p, n, 0.0, w.A[k].p, n);
+      }
+    }
+    // empty blocks are not supported inside a batch: compact them away
+    std::vector<int> live;
+    for (int k = 0; k < nb; k++)
+      if (ns[k] > 0) live.push_back(k);
+    if (live.size() != (size_t)nb) throw std::logic_error("eig_gsym_sub: empty symmetry block\n");
+    eig_sym_batch(ctx, w, nb, ns.data());
+    {
+      ProfScope ps(ctx, "eig_backtransform");
+      for (int k = 0; k < nb; k++) {
+        int ib = c0 + k;
+        int n = ns[k];
+        // C block = X Z, kept in Z's place via Cb then copied; eigenvalues gathered into Etmp
+        gemm_dev(ctx, false, false, n, n, n, 1.0, Xall.p + xoff[k], n, w.Z[k].p, n, 0.0, Cb.p, n);
+        HFG_HIP_CHECK(hipMemcpyAsync(w.Z[k].p, Cb.p, sizeof(double) * n * n, hipMemcpyDeviceToDevice, s));
+        HFG_HIP_CHECK(hipMemcpyAsync(Etmp.p + coff[ib], w.d[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+      }
+    }
+    check_status(ctx, w, nb);
+    // scatter needs the global ranks: deferred until all chunks are done when nblk > MAXB
+    ProfScope ps(ctx, "scatter");
+    DevBuf<int> &rank = w.ibuf1;
+    rank.resize(N + 8);
+    HFG_HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(double) * (size_t)N * N, s));
+    hipLaunchKernelGGL(k_rank, dim3((N + 255) / 256), dim3(256), 0, s, Etmp.p, N, rank.p);
+    for (int k = 0; k < nb; k++) {
+      int ib = c0 + k;
+      int n = ns[k];
+      hipLaunchKernelGGL(k_scatter_cols, dim3((n + 255) / 256, n), dim3(256), 0, s, w.Z[k].p, n, n,
+                         drows + blk_ptr[ib], rank.p, coff[ib], Etmp.p + coff[ib], N, dC, dE);
+    }
+  }
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace hfg

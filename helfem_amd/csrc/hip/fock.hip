@@ -1,0 +1,647 @@
+// Coulomb and exchange-correlation Fock-matrix kernels for the diatomic basis (gfx950).
+//
+// What they replace (reference, /root/reference):
+//   TwoDBasis::coulomb                src/diatomic/basis.cpp:1359-1530
+//   DFTGrid::eval_Fxc (restricted)    src/diatomic/dftgrid.cpp:769-810 and the worker it drives
+//                                     (:51-117 update_density, :343-458 compute_xc, :499-545 eval_Fxc,
+//                                      :669-755 compute_bf, dftgrid.h:190-253 increment_lda/gga)
+//
+// Design notes (DESIGN.md has the long version):
+//  * Both J and the XC matrix are block-banded in the radial index (two FEM functions only overlap
+//    inside one element), and both only read the element-diagonal p x p blocks of P.  All work is
+//    done on the "compact" layout X_c[x][y][e][j][i] (tables.h); dense N x N matrices appear only at
+//    the API boundary (gather_compact / scatter_dense).
+//  * XC: the reference forms the complex (A*p) x (ntheta*nphi) basis-function matrix for every radial
+//    point and runs zgemm on it.  Here the product structure  bf = B_n(mu) Theta_lm(theta) e^{i m phi}
+//    is used: contract the radial index (X1), the theta index per (m,m') group pair (X2), evaluate
+//    the functional on the grid with the phi sums folded in (X3), and go back up (X4, X5).  Same
+//    sums, different association order; ~2000x fewer flops, no O(Ng * ne) intermediates.
+//  * No atomics anywhere: every output element has exactly one writer and a fixed summation order,
+//    so results are bitwise reproducible run to run.
+#include "tables.h"
+#include "xc_device.h"
+
+namespace hfg {
+
+// -------------------------------------------------------------------------------------------------
+// dense <-> compact
+// -------------------------------------------------------------------------------------------------
+// Xc[x][y][e][j][i] = P(pure(x,e*(p-1)+i), pure(y,e*(p-1)+j))
+__global__ void k_gather_compact(const double *__restrict__ P, int N, int A, int R, int E, int p,
+                                 const int *__restrict__ shell_off, const int *__restrict__ shell_skip,
+                                 double *__restrict__ Xc) {
+  int blk = blockIdx.x;  // (x*A+y)*E+e
+  int e = blk % E;
+  int xy = blk / E;
+  int y = xy % A, x = xy / A;
+  int pp = p * p;
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+    int i = t % p, j = t / p;
+    int ni = e * (p - 1) + i, nj = e * (p - 1) + j;
+    double v = 0.0;
+    bool ok = (ni < R) && (nj < R) && !(shell_skip[x] && ni == 0) && !(shell_skip[y] && nj == 0);
+    if (ok) v = P[(size_t)(shell_off[y] + nj) * N + (shell_off[x] + ni)];
+    Xc[(size_t)blk * pp + t] = v;
+  }
+}
+
+// out(pure row, pure col) = sum over the (one or two) elements that contain both radial functions
+__global__ void k_scatter_dense(const double *__restrict__ Xc, int N, int A, int R, int E, int p,
+                                const int *__restrict__ pure_shell, const int *__restrict__ pure_n,
+                                double *__restrict__ out) {
+  int row = blockIdx.x * 64 + (threadIdx.x & 63);
+  int col = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (row >= N || col >= N) return;
+  int x = pure_shell[row], n = pure_n[row];
+  int y = pure_shell[col], m = pure_n[col];
+  int pm = p - 1, pp = p * p;
+  // candidate elements of n: e1=n/pm (local n%pm) and, on a shared node, e1-1 (local pm)
+  int e1 = n / pm, f1 = m / pm;
+  double v = 0.0;
+  const double *base = Xc + (size_t)(x * A + y) * E * pp;
+  for (int ce = 0; ce < 2; ce++) {
+    int e = e1 - ce;
+    if (e < 0 || e >= E) continue;
+    int i = n - e * pm;
+    if (i < 0 || i > pm) continue;
+    for (int cf = 0; cf < 2; cf++) {
+      int f = f1 - cf;
+      if (f != e) continue;
+      int j = m - f * pm;
+      if (j < 0 || j > pm) continue;
+      v += base[(size_t)e * pp + j * p + i];
+    }
+  }
+  out[(size_t)col * N + row] = v;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Coulomb
+// -------------------------------------------------------------------------------------------------
+// K1  ket contraction (basis.cpp:1380-1405), restricted to the element-diagonal blocks:
+//     Paux{0,2}[iLM][e][t] = sum_{(x,y) in iLM} c{0,2} * Pc[x][y][e][t]
+__global__ void k_coulomb_ket(const double *__restrict__ Pc, int A, int E, int pp, const int *__restrict__ lm_off,
+                              const int *__restrict__ lm_x, const int *__restrict__ lm_y,
+                              const double *__restrict__ lm_c0, const double *__restrict__ lm_c2, int NLM,
+                              double *__restrict__ Paux) {
+  int iLM = blockIdx.x, e = blockIdx.y;
+  int beg = lm_off[iLM], end = lm_off[iLM + 1];
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+    double a0 = 0.0, a2 = 0.0;
+    for (int k = beg; k < end; k++) {
+      double v = Pc[((size_t)(lm_x[k] * A + lm_y[k]) * E + e) * pp + t];
+      a0 += lm_c0[k] * v;
+      a2 += lm_c2[k] * v;
+    }
+    Paux[((size_t)(0 * NLM + iLM) * E + e) * pp + t] = a0;
+    Paux[((size_t)(1 * NLM + iLM) * E + e) * pp + t] = a2;
+  }
+}
+
+// K2b in-element integrals (basis.cpp:1472-1485): Y[tt][iLM][e][:] = tei_tt[ilm][e] * vec(Paux_{tt&1 ? 2:0}[iLM][e])
+//     for iLM=(L,+|M|) and its partner (L,-|M|) in one pass over the p^2 x p^2 table (HBM-bound:
+//     this is where the 4*Nlm*E*p^4*8 bytes of primitive integrals are streamed once per build).
+__global__ void k_coulomb_tei(const double *__restrict__ tei, const double *__restrict__ Paux, int Nlm, int NLM,
+                              int E, int pp, const int *__restrict__ lmpos /* [Nlm][2] iLM of +M and -M */,
+                              double *__restrict__ Y) {
+  extern __shared__ double sh[];  // x_plus[pp], x_minus[pp]
+  int ilm = blockIdx.x / E, e = blockIdx.x % E;
+  int tt = blockIdx.y;  // 0:00 1:02 2:20 3:22
+  int iLMp = lmpos[2 * ilm], iLMm = lmpos[2 * ilm + 1];
+  int which = (tt & 1);  // 00,20 act on Paux0 ; 02,22 act on Paux2
+  double *xp = sh, *xm = sh + pp;
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+    xp[t] = (iLMp >= 0) ? Paux[((size_t)(which * NLM + iLMp) * E + e) * pp + t] : 0.0;
+    xm[t] = (iLMm >= 0) ? Paux[((size_t)(which * NLM + iLMm) * E + e) * pp + t] : 0.0;
+  }
+  __syncthreads();
+  const double *T = tei + (((size_t)tt * Nlm + ilm) * E + e) * (size_t)pp * pp;
+  for (int r = threadIdx.x; r < pp; r += blockDim.x) {
+    double yp = 0.0, ym = 0.0;
+#pragma unroll 5
+    for (int c = 0; c < pp; c++) {
+      double v = T[(size_t)c * pp + r];
+      yp += v * xp[c];
+      ym += v * xm[c];
+    }
+    if (iLMp >= 0) Y[((size_t)(tt * NLM + iLMp) * E + e) * pp + r] = yp;
+    if (iLMm >= 0) Y[((size_t)(tt * NLM + iLMm) * E + e) * pp + r] = ym;
+  }
+}
+
+// K2c per (L,M): disjoint (cross-element) part via the trace scalars + in-element part (basis.cpp:1424-1494)
+__global__ void k_coulomb_radial(const double *__restrict__ Paux, const double *__restrict__ Y,
+                                 const double *__restrict__ disj, const int *__restrict__ LM_ilm,
+                                 const double *__restrict__ LM_fac, int Nlm, int NLM, int E, int p,
+                                 double *__restrict__ Jaux) {
+  extern __shared__ double sh[];  // red[4*E*nwave], sc[4*E], big[E], small[E]
+  int iLM = blockIdx.x;
+  int ilm = LM_ilm[iLM];
+  double fac = LM_fac[iLM];
+  int pp = p * p;
+  int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+  double *red = sh;
+  double *sc = red + 4 * E * nwave;
+  double *big = sc + 4 * E, *small = big + E;
+  // traces: js[k][e], k: 0 small0=tr(P0*Psub0) 1 big0=tr(Q0*Psub0) 2 small2=tr(P2*Psub2) 3 big2=tr(Q2*Psub2)
+  for (int e = 0; e < E; e++) {
+    double a[4] = {0, 0, 0, 0};
+    for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+      int i = t % p, j = t / p;
+      double x0 = Paux[((size_t)(0 * NLM + iLM) * E + e) * pp + (i * p + j)];  // Psub(j,i)
+      double x2 = Paux[((size_t)(1 * NLM + iLM) * E + e) * pp + (i * p + j)];
+      a[0] += disj[(((size_t)0 * Nlm + ilm) * E + e) * pp + t] * x0;
+      a[1] += disj[(((size_t)2 * Nlm + ilm) * E + e) * pp + t] * x0;
+      a[2] += disj[(((size_t)1 * Nlm + ilm) * E + e) * pp + t] * x2;
+      a[3] += disj[(((size_t)3 * Nlm + ilm) * E + e) * pp + t] * x2;
+    }
+    for (int k = 0; k < 4; k++) {
+      double v = a[k];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) red[(k * E + e) * nwave + wave] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * E) {
+    double v = 0.0;
+    for (int w = 0; w < nwave; w++) v += red[threadIdx.x * nwave + w];
+    sc[threadIdx.x] = fac * v;
+  }
+  __syncthreads();
+  if (threadIdx.x < E) {
+    int e = threadIdx.x;
+    // contributions to element e from jel>e use "big" of jel, from jel<e use "small" of jel
+    double sb = 0.0, ss = 0.0;
+    for (int jel = e + 1; jel < E; jel++) sb += sc[1 * E + jel] - sc[3 * E + jel];  // jbig0 - jbig2
+    for (int jel = 0; jel < e; jel++) ss += sc[0 * E + jel] - sc[2 * E + jel];      // jsmall0 - jsmall2
+    big[e] = sb;
+    small[e] = ss;
+  }
+  __syncthreads();
+  for (int e = 0; e < E; e++)
+    for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+      double P0 = disj[(((size_t)0 * Nlm + ilm) * E + e) * pp + t], P2 = disj[(((size_t)1 * Nlm + ilm) * E + e) * pp + t];
+      double Q0 = disj[(((size_t)2 * Nlm + ilm) * E + e) * pp + t], Q2 = disj[(((size_t)3 * Nlm + ilm) * E + e) * pp + t];
+      double y00 = Y[((size_t)(0 * NLM + iLM) * E + e) * pp + t], y02 = Y[((size_t)(1 * NLM + iLM) * E + e) * pp + t];
+      double y20 = Y[((size_t)(2 * NLM + iLM) * E + e) * pp + t], y22 = Y[((size_t)(3 * NLM + iLM) * E + e) * pp + t];
+      double j0 = P0 * big[e] + Q0 * small[e] + fac * y00 - fac * y02;
+      double j2 = -P2 * big[e] - Q2 * small[e] - fac * y20 + fac * y22;
+      Jaux[((size_t)(0 * NLM + iLM) * E + e) * pp + t] = j0;
+      Jaux[((size_t)(1 * NLM + iLM) * E + e) * pp + t] = j2;
+    }
+}
+
+// K3 bra expansion (basis.cpp:1498-1527): Jc[i][j][e][:] = sum_L c0(j,i,L) Jaux0[iLM] + c2(j,i,L) Jaux2[iLM]
+__global__ void k_coulomb_bra(const double *__restrict__ Jaux, int A, int E, int pp, int NLM,
+                              const int *__restrict__ pair_off, const int *__restrict__ ent_iLM,
+                              const double *__restrict__ ent_c0, const double *__restrict__ ent_c2,
+                              double *__restrict__ Jc) {
+  int ij = blockIdx.x, e = blockIdx.y;
+  int iang = ij / A, jang = ij % A;
+  int pr = jang * A + iang;  // pair (x=jang, y=iang)
+  int beg = pair_off[pr], end = pair_off[pr + 1];
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+    double acc = 0.0;
+    for (int k = beg; k < end; k++) {
+      int iLM = ent_iLM[k];
+      acc += ent_c0[k] * Jaux[((size_t)(0 * NLM + iLM) * E + e) * pp + t] +
+             ent_c2[k] * Jaux[((size_t)(1 * NLM + iLM) * E + e) * pp + t];
+    }
+    Jc[((size_t)ij * E + e) * pp + t] = acc;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// XC
+// -------------------------------------------------------------------------------------------------
+// X1 radial contraction of the density: D0[Q][x][y] = sum_ij B_i(q) Pc[x][y][e][j][i] B_j(q),
+//    D1[Q][x][y] = sum_ij B'_i(q) Pc[..][j][i] B_j(q)            (replaces Pv = P conj(bf), dftgrid.cpp:62)
+__global__ void k_xc_density_radial(const double *__restrict__ Pc, const double *__restrict__ B,
+                                    const double *__restrict__ dB, int A, int E, int p, int nq, int do_grad,
+                                    double *__restrict__ D0, double *__restrict__ D1) {
+  extern __shared__ double sh[];  // P[pp]
+  int xy = blockIdx.x, e = blockIdx.y;
+  int pp = p * p;
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) sh[t] = Pc[((size_t)xy * E + e) * pp + t];
+  __syncthreads();
+  size_t AA = (size_t)A * A;
+  for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+    const double *b = B + ((size_t)e * nq + q) * p;
+    const double *db = dB + ((size_t)e * nq + q) * p;
+    double d0 = 0.0, d1 = 0.0;
+    for (int j = 0; j < p; j++) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int i = 0; i < p; i++) {
+        double pv = sh[j * p + i];
+        s0 += b[i] * pv;
+        s1 += db[i] * pv;
+      }
+      d0 += s0 * b[j];
+      d1 += s1 * b[j];
+    }
+    size_t Q = (size_t)e * nq + q;
+    D0[Q * AA + xy] = d0;
+    if (do_grad) D1[Q * AA + xy] = d1;
+  }
+}
+
+// X2 theta contraction per (m-group pair): V[k][Q][ga][gb][i],
+//    k=0: sum Theta_a D0_ab Theta_b ; k=1: sum dTheta_a D0_ab Theta_b ; k=2: sum Theta_a D1_ab Theta_b
+__global__ void k_xc_density_theta(const double *__restrict__ D0, const double *__restrict__ D1,
+                                   const double *__restrict__ Th, const double *__restrict__ dTh, int A, int nth,
+                                   int G, const int *__restrict__ grp_off, const int *__restrict__ grp_shell,
+                                   int do_grad, size_t NQ, double *__restrict__ V) {
+  extern __shared__ double sh[];  // d0[na*nb], d1[na*nb]
+  size_t Q = blockIdx.x;
+  int ga = blockIdx.y / G, gb = blockIdx.y % G;
+  int a0 = grp_off[ga], na = grp_off[ga + 1] - a0;
+  int b0 = grp_off[gb], nb = grp_off[gb + 1] - b0;
+  double *d0 = sh, *d1 = sh + na * nb;
+  size_t AA = (size_t)A * A;
+  for (int t = threadIdx.x; t < na * nb; t += blockDim.x) {
+    int ia = t / nb, ib = t % nb;
+    int a = grp_shell[a0 + ia], b = grp_shell[b0 + ib];
+    d0[t] = D0[Q * AA + (size_t)a * A + b];
+    d1[t] = do_grad ? D1[Q * AA + (size_t)a * A + b] : 0.0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nth; i += blockDim.x) {
+    double r = 0.0, s = 0.0, u = 0.0;
+    for (int ia = 0; ia < na; ia++) {
+      int a = grp_shell[a0 + ia];
+      double s0 = 0.0, s1 = 0.0;
+      for (int ib = 0; ib < nb; ib++) {
+        double tb = Th[(size_t)grp_shell[b0 + ib] * nth + i];
+        s0 += d0[ia * nb + ib] * tb;
+        s1 += d1[ia * nb + ib] * tb;
+      }
+      double ta = Th[(size_t)a * nth + i];
+      r += ta * s0;
+      if (do_grad) {
+        s += dTh[(size_t)a * nth + i] * s0;
+        u += ta * s1;
+      }
+    }
+    size_t o = ((Q * G + ga) * G + gb) * nth + i;
+    size_t stride = NQ * G * G * nth;
+    V[o] = r;
+    if (do_grad) {
+      V[stride + o] = s;
+      V[2 * stride + o] = u;
+    }
+  }
+}
+
+// X3 grid evaluation at one radial point: density & gradient on the (theta,phi) grid, functional,
+//    energy/electron partial sums, and the phi-transformed potentials
+//       Fo[0][Q][ga][gb][i] = sum_j (1/2 w vrho cos(D phi_j) - m_ga gr_phi sin(D phi_j))
+//       Fo[1][..]           = sum_j gr_nu cos(D phi_j)
+//       Fo[2][..]           = sum_j gr_mu cos(D phi_j)            D = m_ga - m_gb
+//    (dftgrid.cpp:69-86, 412-416, 471-477, 510-531, 693-707)
+__global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict__ rad_w,
+                          const double *__restrict__ rad_sh, const double *__restrict__ th_s,
+                          const double *__restrict__ th_w, const int *__restrict__ grp_m,
+                          const double *__restrict__ cosd, const double *__restrict__ sind, int Dmax, int G, int nth,
+                          int nphi, double Rh, int x_func, int c_func, int do_grad, double thr, size_t NQ,
+                          double *__restrict__ Fo, double *__restrict__ partial /* [2][NQ] */) {
+  extern __shared__ double sh[];  // pot[4][nth*nphi], red[2*nwave]
+  size_t Q = blockIdx.x;
+  int ng = nth * nphi;
+  double *p0 = sh, *p1 = sh + ng, *p2 = sh + 2 * ng, *p3 = sh + 3 * ng;
+  double *red = sh + 4 * ng;
+  double shm = rad_sh[Q], wr = rad_w[Q];
+  double dphi = 2.0 * HFG_PI / nphi;
+  size_t stride = NQ * G * G * nth;
+  double nel = 0.0, exc_sum = 0.0;
+  for (int pt = threadIdx.x; pt < ng; pt += blockDim.x) {
+    int i = pt / nphi, j = pt % nphi;
+    double sth = th_s[i];
+    double h2 = shm * shm + sth * sth;
+    double hmu = Rh * sqrt(h2);
+    double hphi = Rh * shm * sth;
+    double w = th_w[i] * dphi * wr * Rh * Rh * Rh * shm * h2;
+    double rho = 0.0, gmu = 0.0, gnu = 0.0, gphi = 0.0;
+    for (int ga = 0; ga < G; ga++)
+      for (int gb = 0; gb < G; gb++) {
+        int D = grp_m[ga] - grp_m[gb];
+        double cd = cosd[(size_t)(D + Dmax) * nphi + j];
+        size_t o = ((Q * G + ga) * G + gb) * nth + i;
+        double vr = V[o];
+        rho += cd * vr;
+        if (do_grad) {
+          double sd = sind[(size_t)(D + Dmax) * nphi + j];
+          gnu += cd * V[stride + o];
+          gmu += cd * V[2 * stride + o];
+          gphi -= grp_m[ga] * sd * vr;
+        }
+      }
+    double sigma = 0.0;
+    if (do_grad) {
+      gmu *= 2.0 / hmu;
+      gnu *= 2.0 / hmu;
+      gphi *= 2.0 / hphi;
+      sigma = gmu * gmu + gnu * gnu + gphi * gphi;
+    }
+    double exc = 0.0, vrho = 0.0, vsig = 0.0;
+    if (rho >= thr && rho > 0.0) {
+      if (x_func > 0) xc::eval_add(x_func, rho, sigma, exc, vrho, vsig);
+      if (c_func > 0) xc::eval_add(c_func, rho, sigma, exc, vrho, vsig);
+    }
+    nel += w * rho;
+    exc_sum += w * exc * rho;
+    p0[pt] = w * vrho;
+    if (do_grad) {
+      double f = 2.0 * w * vsig;
+      p1[pt] = f * gmu / hmu;
+      p2[pt] = f * gnu / hmu;
+      p3[pt] = f * gphi / hphi;
+    }
+  }
+  // block reduction of the two scalars (fixed order -> deterministic)
+  int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+  for (int o = 32; o > 0; o >>= 1) {
+    nel += __shfl_down(nel, o, 64);
+    exc_sum += __shfl_down(exc_sum, o, 64);
+  }
+  if (lane == 0) {
+    red[wave] = nel;
+    red[nwave + wave] = exc_sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < nwave; w++) {
+      a += red[w];
+      b += red[nwave + w];
+    }
+    partial[Q] = a;
+    partial[NQ + Q] = b;
+  }
+  // phi transforms
+  int nout = G * G * nth;
+  for (int t = threadIdx.x; t < nout; t += blockDim.x) {
+    int i = t % nth;
+    int gab = t / nth;
+    int ga = gab / G, gb = gab % G;
+    int D = grp_m[ga] - grp_m[gb];
+    const double *cd = cosd + (size_t)(D + Dmax) * nphi;
+    const double *sd = sind + (size_t)(D + Dmax) * nphi;
+    double fa = 0.0, fs = 0.0, fb = 0.0;
+    double mga = grp_m[ga];
+    for (int j = 0; j < nphi; j++) {
+      int pt = i * nphi + j;
+      fa += 0.5 * p0[pt] * cd[j];
+      if (do_grad) {
+        fa -= mga * p3[pt] * sd[j];
+        fs += p2[pt] * cd[j];
+        fb += p1[pt] * cd[j];
+      }
+    }
+    size_t o = ((Q * G + ga) * G + gb) * nth + i;
+    Fo[o] = fa;
+    if (do_grad) {
+      Fo[stride + o] = fs;
+      Fo[2 * stride + o] = fb;
+    }
+  }
+}
+
+// X4 theta expansion: GA[Q][a][b] = sum_i Theta_a Theta_b Fo0 + dTheta_a Theta_b Fo1 ; GB[Q][a][b] = sum_i Theta_a Theta_b Fo2
+__global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__restrict__ Th,
+                                const double *__restrict__ dTh, int A, int nth, int G,
+                                const int *__restrict__ grp_off, const int *__restrict__ grp_shell, int do_grad,
+                                size_t NQ, double *__restrict__ GA, double *__restrict__ GB) {
+  extern __shared__ double sh[];  // f0[nth], f1[nth], f2[nth]
+  size_t Q = blockIdx.x;
+  int ga = blockIdx.y / G, gb = blockIdx.y % G;
+  int a0 = grp_off[ga], na = grp_off[ga + 1] - a0;
+  int b0 = grp_off[gb], nb = grp_off[gb + 1] - b0;
+  size_t stride = NQ * G * G * nth;
+  size_t o = ((Q * G + ga) * G + gb) * nth;
+  double *f0 = sh, *f1 = sh + nth, *f2 = sh + 2 * nth;
+  for (int i = threadIdx.x; i < nth; i += blockDim.x) {
+    f0[i] = Fo[o + i];
+    f1[i] = do_grad ? Fo[stride + o + i] : 0.0;
+    f2[i] = do_grad ? Fo[2 * stride + o + i] : 0.0;
+  }
+  __syncthreads();
+  size_t AA = (size_t)A * A;
+  for (int t = threadIdx.x; t < na * nb; t += blockDim.x) {
+    int a = grp_shell[a0 + t / nb], b = grp_shell[b0 + t % nb];
+    const double *ta = Th + (size_t)a * nth, *tb = Th + (size_t)b * nth, *da = dTh + (size_t)a * nth;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = 0; i < nth; i++) {
+      double tbi = tb[i];
+      s0 += (ta[i] * f0[i] + da[i] * f1[i]) * tbi;
+      s1 += ta[i] * f2[i] * tbi;
+    }
+    GA[Q * AA + (size_t)a * A + b] = s0;
+    if (do_grad) GB[Q * AA + (size_t)a * A + b] = s1;
+  }
+}
+
+// X5 radial expansion into the compact Fock blocks:
+//    Hc[x][y][e][n'][n] = sum_q B_n B_n' (GA_xy + GA_yx) + B'_n B_n' GB_xy + B_n B'_n' GB_yx
+__global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__restrict__ GB,
+                                 const double *__restrict__ B, const double *__restrict__ dB, int A, int E, int p,
+                                 int nq, int do_grad, double *__restrict__ Hc) {
+  extern __shared__ double sh[];  // gs[nq], g1[nq], g2[nq]
+  int xy = blockIdx.x, e = blockIdx.y;
+  int x = xy / A, y = xy % A;
+  int yx = y * A + x;
+  size_t AA = (size_t)A * A;
+  double *gs = sh, *g1 = sh + nq, *g2 = sh + 2 * nq;
+  for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+    size_t Q = (size_t)e * nq + q;
+    gs[q] = GA[Q * AA + xy] + GA[Q * AA + yx];
+    g1[q] = do_grad ? GB[Q * AA + xy] : 0.0;
+    g2[q] = do_grad ? GB[Q * AA + yx] : 0.0;
+  }
+  __syncthreads();
+  int pp = p * p;
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+    int n = t % p, m = t / p;
+    double acc = 0.0;
+    for (int q = 0; q < nq; q++) {
+      const double *b = B + ((size_t)e * nq + q) * p;
+      const double *db = dB + ((size_t)e * nq + q) * p;
+      acc += b[n] * b[m] * gs[q] + db[n] * b[m] * g1[q] + b[n] * db[m] * g2[q];
+    }
+    Hc[((size_t)xy * E + e) * pp + t] = acc;
+  }
+}
+
+__global__ void k_xc_sum_partials(const double *__restrict__ partial, size_t NQ, double *__restrict__ scal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double nel = 0.0, exc = 0.0;
+    for (size_t q = 0; q < NQ; q++) {
+      nel += partial[q];
+      exc += partial[NQ + q];
+    }
+    scal[0] = exc;  // Exc
+    scal[1] = nel;  // Nel
+    scal[2] = 0.0;  // Ekin (tau only integrated for meta-GGAs)
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// launchers
+// -------------------------------------------------------------------------------------------------
+static int round_up64(int n) { return ((n + 63) / 64) * 64; }
+
+struct FockAux {
+  DevBuf<int> pure_shell, pure_n, lmpos;
+  DevBuf<double> Pc, Jc, Paux, Y, Jaux, D0, D1, V, Fo, GA, GB, partial, scal;
+};
+
+static std::map<hfg_dev_tables *, FockAux *> g_aux;
+
+static FockAux &aux_for(hfg_ctx *ctx, hfg_basis *basis) {
+  hfg_dev_tables *t = basis->dev;
+  auto it = g_aux.find(t);
+  if (it != g_aux.end()) return *it->second;
+  FockAux *a = new FockAux();
+  const auto &b = basis->b;
+  std::vector<int> ps(t->N), pn(t->N);
+  {
+    size_t k = 0;
+    for (int s = 0; s < t->A; s++)
+      for (int n = (b.mval[s] != 0 ? 1 : 0); n < t->R; n++, k++) {
+        ps[k] = s;
+        pn[k] = n;
+      }
+  }
+  a->pure_shell.upload(ps, ctx->stream);
+  a->pure_n.upload(pn, ctx->stream);
+  std::vector<int> lmpos(2 * t->Nlm, -1);
+  for (int i = 0; i < t->NLM; i++) {
+    int L = b.LM_map[i].first, M = b.LM_map[i].second;
+    int ilm = (int)b.lmind(L, M);
+    if (M >= 0) lmpos[2 * ilm] = i;
+    if (M < 0) lmpos[2 * ilm + 1] = i;
+  }
+  a->lmpos.upload(lmpos, ctx->stream);
+  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  g_aux[t] = a;
+  return *a;
+}
+
+void fock_release(hfg_dev_tables *t) {
+  auto it = g_aux.find(t);
+  if (it != g_aux.end()) {
+    delete it->second;
+    g_aux.erase(it);
+  }
+}
+
+static hfg_dev_tables *tables_of(hfg_ctx *ctx, hfg_basis *basis) {
+  if (!basis->dev || !basis->dev->have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
+  if (basis->dev_device != ctx->device) throw std::logic_error("basis tables live on a different device\n");
+  return basis->dev;
+}
+
+void gather_compact(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dPc) {
+  hfg_dev_tables *t = basis->dev;
+  hipLaunchKernelGGL(k_gather_compact, dim3(t->A * t->A * t->E), dim3(256), 0, ctx->stream, dP, t->N, t->A, t->R, t->E,
+                     t->p, t->shell_off.p, t->shell_skip.p, dPc);
+}
+
+void scatter_dense(hfg_ctx *ctx, hfg_basis *basis, const double *dXc, double *dOut) {
+  hfg_dev_tables *t = basis->dev;
+  FockAux &a = aux_for(ctx, basis);
+  dim3 grid((t->N + 63) / 64, (t->N + 3) / 4);
+  hipLaunchKernelGGL(k_scatter_dense, grid, dim3(256), 0, ctx->stream, dXc, t->N, t->A, t->R, t->E, t->p,
+                     a.pure_shell.p, a.pure_n.p, dOut);
+}
+
+// J (compact) from P (compact)
+void coulomb_compact(hfg_ctx *ctx, hfg_basis *basis, const double *dPc, double *dJc) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  FockAux &a = aux_for(ctx, basis);
+  const int pp = t->p * t->p;
+  const size_t nb = (size_t)t->NLM * t->E * pp;
+  a.Paux.resize(2 * nb);
+  a.Y.resize(4 * nb);
+  a.Jaux.resize(2 * nb);
+  int bs = std::min(256, round_up64(pp));
+  hipLaunchKernelGGL(k_coulomb_ket, dim3(t->NLM, t->E), dim3(bs), 0, ctx->stream, dPc, t->A, t->E, pp, t->lm_off.p,
+                     t->lm_x.p, t->lm_y.p, t->lm_c0.p, t->lm_c2.p, t->NLM, a.Paux.p);
+  hipLaunchKernelGGL(k_coulomb_tei, dim3(t->Nlm * t->E, 4), dim3(bs), 2 * pp * sizeof(double), ctx->stream, t->tei.p,
+                     a.Paux.p, t->Nlm, t->NLM, t->E, pp, a.lmpos.p, a.Y.p);
+  int nwave = bs / 64;
+  size_t shb = (size_t)(4 * t->E * nwave + 4 * t->E + 2 * t->E) * sizeof(double);
+  hipLaunchKernelGGL(k_coulomb_radial, dim3(t->NLM), dim3(bs), shb, ctx->stream, a.Paux.p, a.Y.p, t->disj.p,
+                     t->LM_ilm.p, t->LM_fac.p, t->Nlm, t->NLM, t->E, t->p, a.Jaux.p);
+  hipLaunchKernelGGL(k_coulomb_bra, dim3(t->A * t->A, t->E), dim3(bs), 0, ctx->stream, a.Jaux.p, t->A, t->E, pp,
+                     t->NLM, t->pair_off.p, t->ent_iLM.p, t->ent_c0.p, t->ent_c2.p, dJc);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  FockAux &a = aux_for(ctx, basis);
+  const size_t nc = (size_t)t->A * t->A * t->E * t->p * t->p;
+  a.Pc.resize(nc);
+  a.Jc.resize(nc);
+  ProfScope ps(ctx, "coulomb");
+  gather_compact(ctx, basis, dP, a.Pc.p);
+  coulomb_compact(ctx, basis, a.Pc.p, a.Jc.p);
+  scatter_dense(ctx, basis, a.Jc.p, dJ);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPc, double *dHc, double *dScal,
+                double thr) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  if (!t->have_xc) throw std::runtime_error("XC grid tables were not uploaded (hfg_basis_upload with ldft,mdft > 0)\n");
+  if ((x_func > 0 && !xc::is_supported(x_func)) || (c_func > 0 && !xc::is_supported(c_func)))
+    throw std::runtime_error("Functional not found!");
+  FockAux &a = aux_for(ctx, basis);
+  const int A = t->A, E = t->E, p = t->p, nq = t->nq, G = t->G, nth = t->ntheta, nphi = t->nphi;
+  const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
+  int do_grad = ((x_func > 0 && xc::is_gga(x_func)) || (c_func > 0 && xc::is_gga(c_func))) ? 1 : 0;
+  a.D0.resize(NQ * AA);
+  a.D1.resize(NQ * AA);
+  a.GA.resize(NQ * AA);
+  a.GB.resize(NQ * AA);
+  const size_t nv = NQ * G * G * nth;
+  a.V.resize(3 * nv);
+  a.Fo.resize(3 * nv);
+  a.partial.resize(2 * NQ);
+  int maxgrp = 0;
+  for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
+
+  hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(std::min(256, round_up64(nq))), p * p * sizeof(double),
+                     ctx->stream, dPc, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, a.D0.p, a.D1.p);
+  hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
+                     2 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, t->Th.p, t->dTh.p, A, nth, G,
+                     t->grp_off.p, t->grp_shell.p, do_grad, NQ, a.V.p);
+  size_t shb = (size_t)(4 * nth * nphi + 2 * 4) * sizeof(double);
+  if (shb > 64 * 1024)
+    HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+  hipLaunchKernelGGL(k_xc_grid, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
+                     t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, x_func,
+                     c_func, do_grad, thr, NQ, a.Fo.p, a.partial.p);
+  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 3 * nth * sizeof(double), ctx->stream,
+                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, NQ, a.GA.p, a.GB.p);
+  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 3 * nq * sizeof(double),
+                     ctx->stream, a.GA.p, a.GB.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, dHc);
+  hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
+                 double thr) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  FockAux &a = aux_for(ctx, basis);
+  const size_t nc = (size_t)t->A * t->A * t->E * t->p * t->p;
+  a.Pc.resize(nc);
+  a.Jc.resize(nc);
+  ProfScope ps(ctx, "xc");
+  gather_compact(ctx, basis, dP, a.Pc.p);
+  xc_compact(ctx, basis, x_func, c_func, a.Pc.p, a.Jc.p, dScal, thr);
+  scatter_dense(ctx, basis, a.Jc.p, dH);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace hfg

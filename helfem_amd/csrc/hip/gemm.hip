@@ -1,0 +1,176 @@
+// FP64 GEMM on the gfx950 matrix cores:  C = alpha * op(A) * op(B) + beta * C, column-major.
+//
+// Used for the dense products of the generalized eigensolve (reference: scf::eig_gsym,
+// src/general/scf_helpers.cpp:133 "Sinvh.t()*F*Sinvh" and :139 "C=Sinvh*C"), scf::form_density
+// (:22-29) and the DIIS error matrix (src/general/diis.cpp:139-146), i.e. the products the
+// reference hands to BLAS dgemm.
+//
+// v_mfma_f64_16x16x4_f64: one wave computes a 16x16 tile with K=4 per instruction.  Operand maps,
+// verified on hardware with exact integer data (tests/gpu_probe/mfma_probe.hip):
+//     a-operand: lane l holds X[l&15][l>>4]      b-operand: lane l holds Y[l>>4][l&15]
+//     result reg r of lane l: D[(l>>4)+4r][l&15]
+// The products are issued as D^T = B^T A^T (a-operand from the B tile, b-operand from the A tile)
+// so that lane&15 runs along the rows of C, contiguous in column-major memory, and a result
+// register stores 16 consecutive doubles (128 B) per 16-lane group.
+//
+// Tiling: 256 threads = 4 waves in a 2x2 arrangement, block tile BM x BN (128x128 or 64x64,
+// chosen by the launcher so that small problems still give >= 256 workgroups), BK = 16.
+// LDS tiles are stored [k][m] with the row padded by 16 doubles: the four k-rows a wave reads at
+// once then fall on disjoint 128-B bank groups (conflict-free ds_read_b64).
+#include "common.h"
+
+namespace hfg {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
+                                               const double *__restrict__ A, int lda, const double *__restrict__ B,
+                                               int ldb, double beta, double *__restrict__ C, int ldc) {
+  constexpr int BK = 16;
+  constexpr int PAD = 16;
+  constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int EA = BM * BK / 256, EB = BN * BK / 256;  // elements per thread per tile
+  __shared__ double As[BK][BM + PAD];
+  __shared__ double Bs[BK][BN + PAD];
+
+  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
+  // contiguous strip of tiles (they share A row panels / B column panels in that XCD's L2)
+  int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  int nwg = nbm * nbn;
+  int id = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = id % 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+  }
+  const int bm = (id % nbm) * BM, bn = (id / nbm) * BN;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = (wave & 1) * WM, wn = (wave >> 1) * WN;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  double4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  double ra[EA], rb[EB];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < EA; r++) {
+      int e = tid + 256 * r;
+      int m, k;
+      if (!transA) {
+        m = e % BM;
+        k = e / BM;
+      } else {
+        k = e % BK;
+        m = e / BK;
+      }
+      int gm = bm + m, gk = k0 + k;
+      double v = 0.0;
+      if (gm < M && gk < K) v = transA ? A[(size_t)gm * lda + gk] : A[(size_t)gk * lda + gm];
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < EB; r++) {
+      int e = tid + 256 * r;
+      int n, k;
+      if (!transB) {
+        k = e % BK;
+        n = e / BK;
+      } else {
+        n = e % BN;
+        k = e / BN;
+      }
+      int gn = bn + n, gk = k0 + k;
+      double v = 0.0;
+      if (gn < N && gk < K) v = transB ? B[(size_t)gk * ldb + gn] : B[(size_t)gn * ldb + gk];
+      rb[r] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int r = 0; r < EA; r++) {
+      int e = tid + 256 * r;
+      int m, k;
+      if (!transA) {
+        m = e % BM;
+        k = e / BM;
+      } else {
+        k = e % BK;
+        m = e / BK;
+      }
+      As[k][m] = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < EB; r++) {
+      int e = tid + 256 * r;
+      int n, k;
+      if (!transB) {
+        k = e % BK;
+        n = e / BK;
+      } else {
+        n = e % BN;
+        k = e / BN;
+      }
+      Bs[k][n] = rb[r];
+    }
+  };
+
+  load_tiles(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < K) load_tiles(k0 + BK);  // prefetch into registers while the MFMAs run
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      double fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) fa[i] = As[kk + l4][wm + i * 16 + l15];
+#pragma unroll
+      for (int j = 0; j < TN; j++) fb[j] = Bs[kk + l4][wn + j * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  // acc[i][j][r] = C[bm+wm+16i+l15][bn+wn+16j+l4+4r]
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int gm = bm + wm + i * 16 + l15, gn = bn + wn + j * 16 + l4 + 4 * r;
+        if (gm < M && gn < N) {
+          size_t o = (size_t)gn * ldc + gm;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * C[o];
+          C[o] = v;
+        }
+      }
+}
+
+void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
+              const double *B, int ldb, double beta, double *C, int ldc) {
+  if (M <= 0 || N <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (big_tiles >= 512) {
+    hipLaunchKernelGGL((k_dgemm<128, 128>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M,
+                       N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+  } else {
+    long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    hipLaunchKernelGGL((k_dgemm<64, 64>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
+                       alpha, A, lda, B, ldb, beta, C, ldc);
+  }
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace hfg

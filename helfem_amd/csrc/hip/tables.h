@@ -1,0 +1,53 @@
+// Flattened, HBM-resident form of a diatomic TwoDBasis.
+//
+// Layouts (all doubles, "fastest index last" written as C arrays):
+//   shells keep the reference order (basis.cpp:287-302); radial function n of shell a has dummy
+//   index a*R+n and boundary-cleaned ("pure") index shell_off[a]+n, absent when shell_skip[a] && n==0.
+//   Element e holds primitives i=0..p-1 <-> radial functions e*(p-1)+i; the last element has p-1
+//   functions, its missing primitive p-1 is zero padding everywhere.
+//
+//   disj[t][ilm][e][j][i]        t: 0=P0 1=P2 2=Q0 3=Q2   (disjoint_*  basis.cpp:1178-1187)
+//   tei[t][ilm][e][c][r]         t: 0=00 1=02 2=20 3=22   (prim_tei**, p^2 x p^2, col-major, r=j*p+i)
+//   pair tables: for the ordered shell pair (x,y): M=m_x-m_y, L=Lmin..Lmax,
+//        c0 = mod_coeff(l_x,m_x,L,M,l_y,m_y), c2 = coeff(...)      (basis.cpp:1395-1396, 1516-1521)
+//   "compact" matrices X_c[x][y][e][j][i]: the element-diagonal p x p blocks of shell block (x,y);
+//        these are the only non-zero blocks of J and of the XC matrix, and the only blocks of P they read.
+#pragma once
+#include "common.h"
+
+struct hfg_dev_tables {
+  int A = 0, R = 0, E = 0, p = 0, nq = 0, N = 0, Nd = 0, NLM = 0, Nlm = 0;
+  int T = 0;  // number of (pair,L) coupling entries
+  double Rhalf = 0.0;
+  bool have_tei = false, have_xc = false;
+
+  hfg::DevBuf<int> shell_l, shell_m, shell_off, shell_skip;
+  // couplings by pair (x*A+y): entries [pair_off, pair_off+1)
+  hfg::DevBuf<int> pair_off, ent_iLM;
+  hfg::DevBuf<double> ent_c0, ent_c2;
+  // couplings by iLM: entries [lm_off, lm_off+1) -> (x,y,c0,c2)
+  hfg::DevBuf<int> lm_off, lm_x, lm_y;
+  hfg::DevBuf<double> lm_c0, lm_c2;
+  hfg::DevBuf<int> LM_ilm, LM_partner;  // ilm of each (L,M); index of (L,-M) (or -1)
+  hfg::DevBuf<double> LM_fac;
+  hfg::DevBuf<double> disj, tei;
+
+  // ---- XC grid ----
+  int ntheta = 0, nphi = 0, G = 0;  // G = number of distinct m values
+  hfg::DevBuf<double> rad_B, rad_dB;       // [E][nq][p]
+  hfg::DevBuf<double> rad_w, rad_sh;       // [E][nq]  radial weight (wq*len/2), sinh(mu)
+  hfg::DevBuf<double> th_c, th_s, th_w;    // [ntheta] cos, sin, Chebyshev weight
+  hfg::DevBuf<double> Th, dTh;             // [A][ntheta]
+  hfg::DevBuf<int> grp_m, grp_off, grp_shell;  // m of group g; shells of group g = grp_shell[grp_off[g]..]
+  hfg::DevBuf<int> shell_grp;
+  hfg::DevBuf<double> cosd, sind;  // [2*Dmax+1][nphi]  cos(D phi_j), sin(D phi_j), D=-Dmax..Dmax
+  int Dmax = 0;
+
+  // host copies needed by launch logic
+  std::vector<int> h_LM_M, h_grp_off;
+};
+
+namespace hfg {
+/// build (or rebuild) the device tables of basis on the context's device
+void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
+}  // namespace hfg

@@ -1,0 +1,156 @@
+/*
+ * helfem_gpu.h — C ABI of the MI355X (gfx950) implementation of HelFEM's SCF hot path.
+ *
+ * The reference has no plugin/FFI layer: its hot path is a set of C++ member functions taking and
+ * returning arma::mat (contiguous column-major double).  Each entry point below replaces one of
+ * them; the C++ adapter with the reference's exact signatures is include/helfem_gpu_arma.hpp and
+ * the binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all matrices: column-major double, leading dimension = number of rows, caller-owned buffers;
+ *   - matrices live in the *boundary-cleaned* N x N index space of the reference (Nbf), exactly
+ *     what TwoDBasis::coulomb & friends take/return; the expansion to the Ndummy layout
+ *     (basis.cpp:1754 expand_boundaries / :1735 remove_boundaries) happens inside the kernels;
+ *   - "host" entry points take host pointers and copy through pinned staging; "_dev" entry points
+ *     take pointers to HBM (e.g. torch tensors' data_ptr()) and enqueue on the context's stream
+ *     without synchronising;
+ *   - return value: 0 = success, non-zero = error, text via hfg_last_error() (thread-local).  The
+ *     reference throws std::logic_error / std::runtime_error in the same situations
+ *     (e.g. "Primitive teis have not been computed!" basis.cpp:1361);
+ *   - a context is bound to one device + one stream; one context per host thread.
+ *   - there is NO CPU fallback: every compute entry point fails with an error when no gfx950
+ *     device is usable.
+ */
+#ifndef HELFEM_GPU_H
+#define HELFEM_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hfg_ctx hfg_ctx;
+typedef struct hfg_basis hfg_basis;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to
+ * let the context create its own non-blocking stream. */
+int hfg_ctx_create(hfg_ctx **ctx, int device, void *stream);
+int hfg_ctx_destroy(hfg_ctx *ctx);
+int hfg_ctx_synchronize(hfg_ctx *ctx);
+const char *hfg_last_error(void);
+const char *hfg_version(void);
+/* number of visible HIP devices (0 when there is none or the runtime is unusable) */
+int hfg_device_count(void);
+
+/* Multi-GPU sharding of the Fock build: this context computes only the contributions of its
+ * shard (rank of nranks); the caller sums the partial matrices over ranks (one all-reduce over
+ * RCCL).  Default (0,1) = everything. */
+int hfg_ctx_set_shard(hfg_ctx *ctx, int rank, int nranks);
+
+/* ---- basis (host-side setup; no GPU needed) ------------------------------------------------
+ * Constructor arguments of diatomic::basis::TwoDBasis (src/diatomic/basis.cpp:307):
+ * Z1,Z2,Rhalf, primitive basis (only primbas 4 = LIP on Gauss-Lobatto nodes), n_quad, element
+ * boundaries bval (mu values), angular shells (lval,mval), lpad. */
+typedef struct {
+  int Z1, Z2;
+  double Rhalf;
+  int primbas; /* must be 4 */
+  int nnodes;
+  int nquad;
+  const double *bval;
+  int nbval;
+  const int *lval;
+  const int *mval;
+  int nang;
+  int lpad;
+} hfg_diatomic_desc;
+
+int hfg_diatomic_basis_create(const hfg_diatomic_desc *desc, hfg_basis **basis);
+int hfg_basis_destroy(hfg_basis *basis);
+/* Nbf, Ndummy, Nrad, Nang, Nel (TwoDBasis::Nbf/Ndummy/Nrad/Nang, basis.cpp:457-480) */
+int hfg_basis_dims(const hfg_basis *basis, int64_t *Nbf, int64_t *Ndummy, int64_t *Nrad, int64_t *Nang,
+                   int64_t *Nel);
+/* one-electron matrices, N x N  (TwoDBasis::overlap / kinetic / nuclear, basis.cpp:677/752/780) */
+int hfg_basis_overlap(const hfg_basis *basis, double *S);
+int hfg_basis_kinetic(const hfg_basis *basis, double *T);
+int hfg_basis_nuclear(const hfg_basis *basis, double *V);
+/* symmetry blocks (TwoDBasis::get_sym_idx, basis.cpp:561): blk_ptr has nblk+1 entries, blk_idx Nbf.
+ * Pass blk_ptr = NULL to query nblk only. */
+int hfg_basis_sym_blocks(const hfg_basis *basis, int symm, int *nblk, int64_t *blk_ptr, int64_t *blk_idx);
+/* TwoDBasis::compute_tei (basis.cpp:1166): primitive two-electron integral tables (host, threaded) */
+int hfg_compute_tei(hfg_basis *basis, int exchange);
+/* helpers of main.cpp:276-277: mu grid for --grid/--zexp, and (l,m) shell list for lmmax */
+int hfg_radial_grid(double mumax, int nelem, int igrid, double zexp, double *bval /* nelem+1 */);
+int hfg_lm_list(const int *lmmax, int nlm, int *lval, int *mval, int *nang /* in: capacity, out: count */);
+
+/* host-side special functions (exposed for the parity tests against the reference's
+ * gaunt_test / legendre_test / sphtest known answers) */
+double hfg_gaunt_coefficient(int L, int M, int l, int m, int lp, int mp);          /* gaunt.cpp:35 */
+double hfg_modified_gaunt_coefficient(int lj, int mj, int L, int M, int li, int mi); /* gaunt.cpp:55 */
+void hfg_legendre_PQ(int Lmax, int Mmax, double xi, double *P, double *Q);           /* Legendre_Wrapper.f90:135,173 */
+double hfg_theta_lm(int l, int m, double cth);                                       /* spherical_harmonics.cpp:25 */
+void hfg_chebyshev_rule(int n, double *x, double *w);                                /* chebyshev.cpp:22 */
+void hfg_lobatto_nodes(int n, double *x);                                            /* lobatto.cpp:588 */
+
+/* ---- tables -> HBM ------------------------------------------------------------------------- */
+/* Uploads the Gaunt-coupling lists, disjoint/in-element integral tables and (ldft>0) the XC grid
+ * tables (DFTGrid ctor, dftgrid.cpp:760) of this basis to the context's device. */
+int hfg_basis_upload(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
+
+/* ---- per-iteration hot path, host-pointer API (drop-in for the arma::mat signatures) -------- */
+/* arma::mat TwoDBasis::coulomb(const arma::mat & P) const            basis.h:247, basis.cpp:1359 */
+int hfg_coulomb(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *J);
+/* arma::mat TwoDBasis::exchange(const arma::mat & P) const           basis.h:249, basis.cpp:1532 */
+int hfg_exchange(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *K);
+/* void DFTGrid::eval_Fxc(x_func,x_pars,c_func,c_pars,P,H,Exc,Nel,Ekin,thr)   dftgrid.h:179 (restricted).
+ * Functional ids are libxc's: 1 lda_x, 7 lda_c_vwn, 12 lda_c_pw, 101 gga_x_pbe, 130 gga_c_pbe; <=0 none. */
+int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *P, double *H, double *Exc,
+                double *Nel, double *Ekin, double dens_thr);
+/* void scf::eig_gsym(E,C,F,Sinvh): Sinvh is N x n                     scf_helpers.h:34, .cpp:131 */
+int hfg_eig_gsym(hfg_ctx *ctx, int64_t N, int64_t n, const double *F, const double *Sinvh, double *E, double *C);
+/* void scf::eig_gsym_sub(E,C,F,Sinvh,m_idx)                           scf_helpers.h:36, .cpp:142 */
+int hfg_eig_gsym_sub(hfg_ctx *ctx, int64_t N, const double *F, const double *Sinvh, int nblk,
+                     const int64_t *blk_ptr, const int64_t *blk_idx, double *E, double *C);
+/* arma::eig_sym(E,C,A) as used by utils::invh                         libhelfem/src/utils.cpp:172 */
+int hfg_eig_sym(hfg_ctx *ctx, int64_t n, const double *A, double *E, double *C);
+/* arma::mat TwoDBasis::Sinvh(bool chol, int sym) -> block-structured S^{-1/2}   basis.cpp:627 */
+int hfg_form_sinvh(hfg_ctx *ctx, int64_t N, const double *S, int chol, int nblk, const int64_t *blk_ptr,
+                   const int64_t *blk_idx, double *Sinvh);
+/* arma::mat scf::form_density(C, nocc): P = C(:,0:nocc) C(:,0:nocc)^T   scf_helpers.cpp:22 */
+int hfg_form_density(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *C, int64_t nocc, double *P);
+/* C = op(A) op(B), FP64 MFMA (the dense products around the eigensolver and in DIIS) */
+int hfg_gemm(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int64_t k, const double *A, int64_t lda,
+             const double *B, int64_t ldb, double *C, int64_t ldc);
+
+/* ---- device-resident API (pointers into HBM, asynchronous on the context's stream) ---------- */
+int hfg_coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
+int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+/* dScal: 3 doubles in HBM receiving Exc, Nel, Ekin */
+int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH,
+                    double *dScal, double dens_thr);
+int hfg_eig_gsym_sub_dev(hfg_ctx *ctx, int64_t N, const double *dF, const double *dSinvh, int nblk,
+                         const int64_t *blk_ptr, const int64_t *blk_idx, double *dE, double *dC);
+int hfg_form_density_dev(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *dC, int64_t nocc, double *dP);
+int hfg_gemm_dev(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int64_t k, const double *dA,
+                 int64_t lda, const double *dB, int64_t ldb, double *dC, int64_t ldc);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+/* When enabled, every kernel family is bracketed by hipEvents on the context's stream; the
+ * accumulated device time (ms) and launch count per family can be read back after a synchronize.
+ * names: "coulomb", "xc", "exchange", "eig_reduce", "eig_tridiag", "eig_tridiag_solve",
+ * "eig_backtransform", "gemm", "density", "scatter". */
+int hfg_profile_enable(hfg_ctx *ctx, int on);
+int hfg_profile_reset(hfg_ctx *ctx);
+int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches);
+
+/* pinned host memory for arma-owned buffers ("Armadillo matrices pinned and mirrored to HBM") */
+int hfg_pin(void *host_ptr, size_t bytes);
+int hfg_unpin(void *host_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELFEM_GPU_H */

@@ -1,0 +1,183 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so) — the CHECKER, test infrastructure only."""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+_lib = None
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-j8"])
+        L = ctypes.CDLL(_PATH)
+        L.orc_last_error.restype = ctypes.c_char_p
+        L.orc_basis_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                       c_double_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                       ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_void_p)]
+        L.orc_eval_fxc.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                                   c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_long,
+                                   ctypes.c_long]
+        L.orc_xc_unpolarized.argtypes = [ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
+                                         c_double_p, ctypes.c_double]
+        L.orc_scf_diatomic.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int),
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                       c_double_p]
+        for name in ("orc_basis_destroy", "orc_basis_dims", "orc_compute_tei", "orc_coulomb", "orc_exchange",
+                     "orc_grid_overlap", "orc_grid_kinetic"):
+            getattr(L, name).argtypes = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _blocks(m_idx):
+    ptr = np.zeros(len(m_idx) + 1, dtype=np.int64)
+    for i, b in enumerate(m_idx):
+        ptr[i + 1] = ptr[i] + len(b)
+    idx = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.int64) for b in m_idx]))
+    return ptr, idx
+
+
+class OracleBasis(object):
+    def __init__(self, Z1, Z2, Rhalf, nnodes, nquad, bval, lval, mval, lpad=10):
+        bval = np.ascontiguousarray(bval, dtype=np.float64)
+        lv = (ctypes.c_int * len(lval))(*lval)
+        mv = (ctypes.c_int * len(mval))(*mval)
+        h = ctypes.c_void_p()
+        _check(lib().orc_basis_create(Z1, Z2, Rhalf, nnodes, nquad, _p(bval), len(bval), lv, mv, len(lval), lpad,
+                                      ctypes.byref(h)))
+        self.h = h
+        dims = [ctypes.c_int64() for _ in range(5)]
+        lib().orc_basis_dims(self.h, *[ctypes.byref(x) for x in dims])
+        self.Nbf, self.Ndummy, self.Nrad, self.Nang, self.Nel = [x.value for x in dims]
+
+    def __del__(self):
+        try:
+            lib().orc_basis_destroy(self.h)
+        except Exception:
+            pass
+
+    def compute_tei(self, exchange=True):
+        _check(lib().orc_compute_tei(self.h, 1 if exchange else 0))
+
+    def coulomb(self, P):
+        P = _f(P)
+        J = np.zeros_like(P, order="F")
+        _check(lib().orc_coulomb(self.h, _p(P), _p(J)))
+        return J
+
+    def exchange(self, P):
+        P = _f(P)
+        K = np.zeros_like(P, order="F")
+        _check(lib().orc_exchange(self.h, _p(P), _p(K)))
+        return K
+
+    def eval_Fxc(self, lang, mang, x_func, c_func, P, thr=1e-12, q_begin=0, q_end=-1):
+        P = _f(P)
+        H = np.zeros_like(P, order="F")
+        exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(lib().orc_eval_fxc(self.h, lang, mang, x_func, c_func, _p(P), _p(H), ctypes.byref(exc),
+                                  ctypes.byref(nel), ctypes.byref(ekin), thr, q_begin, q_end))
+        return H, exc.value, nel.value, ekin.value
+
+    def grid_overlap(self, lang, mang):
+        S = np.zeros((self.Nbf, self.Nbf), order="F")
+        _check(lib().orc_grid_overlap(self.h, lang, mang, _p(S)))
+        return S
+
+    def grid_kinetic(self, lang, mang):
+        T = np.zeros((self.Nbf, self.Nbf), order="F")
+        _check(lib().orc_grid_kinetic(self.h, lang, mang, _p(T)))
+        return T
+
+
+def eig_sym(A):
+    A = _f(A)
+    n = A.shape[0]
+    E = np.zeros(n)
+    C = np.zeros((n, n), order="F")
+    _check(lib().orc_eig_sym(ctypes.c_int64(n), _p(A), _p(E), _p(C)))
+    return E, C
+
+
+def eig_gsym(F, Sinvh):
+    F, Sinvh = _f(F), _f(Sinvh)
+    N, n = Sinvh.shape
+    E = np.zeros(n)
+    C = np.zeros((N, n), order="F")
+    _check(lib().orc_eig_gsym(ctypes.c_int64(N), ctypes.c_int64(n), _p(F), _p(Sinvh), _p(E), _p(C)))
+    return E, C
+
+
+def eig_gsym_sub(F, Sinvh, m_idx):
+    F, Sinvh = _f(F), _f(Sinvh)
+    N = F.shape[0]
+    ptr, idx = _blocks(m_idx)
+    E = np.zeros(N)
+    C = np.zeros((N, N), order="F")
+    _check(lib().orc_eig_gsym_sub(ctypes.c_int64(N), _p(F), _p(Sinvh), len(m_idx), ptr.ctypes.data_as(c_i64_p),
+                                  idx.ctypes.data_as(c_i64_p), _p(E), _p(C)))
+    return E, C
+
+
+def form_Sinvh(S, chol, m_idx):
+    S = _f(S)
+    N = S.shape[0]
+    ptr, idx = _blocks(m_idx)
+    X = np.zeros((N, N), order="F")
+    _check(lib().orc_form_sinvh(ctypes.c_int64(N), _p(S), 1 if chol else 0, len(m_idx), ptr.ctypes.data_as(c_i64_p),
+                                idx.ctypes.data_as(c_i64_p), _p(X)))
+    return X
+
+
+def form_density(C, nocc):
+    C = _f(C)
+    N, nc = C.shape
+    P = np.zeros((N, N), order="F")
+    _check(lib().orc_form_density(ctypes.c_int64(N), ctypes.c_int64(nc), _p(C), ctypes.c_int64(nocc), _p(P)))
+    return P
+
+
+def xc_unpolarized(func_id, rho, sigma, thr=1e-12):
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    n = rho.size
+    exc, vrho, vsigma = np.zeros(n), np.zeros(n), np.zeros(n)
+    _check(lib().orc_xc_unpolarized(func_id, n, _p(rho), _p(sigma), _p(exc), _p(vrho), _p(vsigma), thr))
+    return exc, vrho, vsigma
+
+
+def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0, igrid=4, zexp=1.0, lpad=10, ldft=0,
+                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0):
+    out = np.zeros(8)
+    lm = (ctypes.c_int * len(lmmax))(*lmmax)
+    _check(lib().orc_scf_diatomic(Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
+                                  method.encode(), ldft, mdft, symmetry, maxit, convthr, verbose, _p(out)))
+    keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
+    r = dict(zip(keys, out[:7]))
+    r["iterations"] = int(out[7])
+    r["converged"] = (out[7] - int(out[7])) > 0.25
+    return r

@@ -1,0 +1,158 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hf(native_libs):
+    import helfem_amd
+    if helfem_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: the hot path has no CPU fallback")
+    return helfem_amd
+
+
+def test_gemm_all_transposes(hf):
+    rng = np.random.RandomState(0)
+    for (m, n, k) in [(5, 7, 3), (64, 64, 16), (130, 67, 45), (200, 300, 129)]:
+        for tA in (False, True):
+            for tB in (False, True):
+                A = rng.uniform(-1, 1, size=(k, m) if tA else (m, k))
+                B = rng.uniform(-1, 1, size=(n, k) if tB else (k, n))
+                C = hf.scf.gemm(A, B, tA, tB)
+                ref = (A.T if tA else A) @ (B.T if tB else B)
+                assert np.max(np.abs(C - ref)) < 1e-12 * k, (m, n, k, tA, tB)
+
+
+def test_gemm_large_tile_path(hf):
+    rng = np.random.RandomState(1)
+    A = rng.uniform(-1, 1, size=(3000, 200))
+    B = rng.uniform(-1, 1, size=(200, 2900))
+    C = hf.scf.gemm(A, B)
+    assert np.max(np.abs(C - A @ B)) < 1e-11
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 130, 400])
+def test_eig_sym_vs_lapack(hf, n):
+    rng = np.random.RandomState(n)
+    A = rng.uniform(-1, 1, size=(n, n))
+    A = A + A.T + np.diag(np.linspace(0, 50.0, n))
+    E, C = hf.scf.eig_sym(A)
+    Eref = np.linalg.eigvalsh(A)
+    scale = max(1.0, np.max(np.abs(Eref)))
+    assert np.max(np.abs(E - Eref)) < 1e-12 * scale * max(n, 10)
+    assert np.max(np.abs(C.T @ C - np.eye(n))) < 1e-12 * max(n, 10)
+    assert np.max(np.abs(A @ C - C * E)) < 1e-11 * scale * max(n, 10)
+
+
+def test_eig_sym_degenerate_and_diagonal(hf):
+    A = np.diag([3.0, 1.0, 1.0, 2.0, 1.0])
+    E, C = hf.scf.eig_sym(A)
+    assert np.allclose(E, [1, 1, 1, 2, 3], atol=1e-14)
+    assert np.max(np.abs(A @ C - C * E)) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fock build parity: diatomic J, XC, K against the oracle
+# ---------------------------------------------------------------------------------------------------
+CASES = {
+    # name: (Z1, Z2, Rbond, lmmax, nelem, nnodes)
+    "sigma_only": (1, 1, 1.4, (4,), 2, 6),
+    "sigma_pi": (7, 7, 2.068, (3, 2), 2, 5),
+    "hetero_sigma_pi_delta": (3, 9, 2.955, (3, 3, 2), 3, 4),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(CASES))
+def case(request, hf):
+    import common
+    Z1, Z2, R, lmmax, nelem, nnodes = CASES[request.param]
+    gb, ob = common.make_bases(Z1, Z2, R, lmmax, nelem, nnodes)
+    gb.compute_tei(True)
+    ob.compute_tei(True)
+    lmax = max(lmmax)
+    ldft, mdft = 4 * lmax + 12, 4 * len(lmmax) + 5
+    gb.upload(ldft, mdft)
+    return request.param, gb, ob, ldft, mdft
+
+
+def _densities(gb):
+    import common
+    N = gb.Nbf()
+    yield "general", common.random_density(N, 3, seed=11)
+    yield "m_blocked", common.random_density(N, 2, seed=12, blocks=gb.get_sym_idx(1))
+
+
+def test_coulomb_parity(case):
+    import common
+    name, gb, ob, _, _ = case
+    for tag, P in _densities(gb):
+        J = gb.coulomb(P)
+        Jo = ob.coulomb(P)
+        assert common.relerr(J, Jo) < 1e-12, (name, tag, common.relerr(J, Jo))
+
+
+def test_exchange_parity(case):
+    import common
+    name, gb, ob, _, _ = case
+    for tag, P in _densities(gb):
+        K = gb.exchange(P)
+        Ko = ob.exchange(P)
+        assert common.relerr(K, Ko) < 1e-12, (name, tag, common.relerr(K, Ko))
+
+
+@pytest.mark.parametrize("funcs", [(1, 7), (1, 0), (101, 130), (101, 0), (0, 130), (1, 12)])
+def test_xc_parity(case, hf, funcs):
+    import common
+    name, gb, ob, ldft, mdft = case
+    grid = hf.DFTGrid(gb, ldft, mdft)
+    x, c = funcs
+    for tag, P in _densities(gb):
+        if tag == "general":
+            # a general random P is not positive on the grid: scale it down onto a positive block-diagonal part
+            P = 0.05 * P + list(_densities(gb))[1][1]
+        H, Exc, Nel, _ = grid.eval_Fxc(x, c, P)
+        Ho, Exco, Nelo, _ = ob.eval_Fxc(ldft, mdft, x, c, P)
+        assert abs(Nel - Nelo) < 1e-11 * max(1.0, abs(Nelo)), (name, tag, Nel, Nelo)
+        assert abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco)), (name, tag, Exc, Exco)
+        assert common.relerr(H, Ho) < 1e-10, (name, tag, funcs, common.relerr(H, Ho))
+
+
+def test_eig_gsym_sub_parity(case, hf):
+    import common
+    import oracle_lib as orc
+    name, gb, ob, _, _ = case
+    S = gb.overlap()
+    F = gb.kinetic() + gb.nuclear()
+    for symm in (1, 0):
+        blocks = gb.get_sym_idx(symm)
+        X = hf.scf.form_Sinvh(S, False, blocks)
+        Xo = orc.form_Sinvh(S, False, blocks)
+        # S^{-1/2} is unique: compare directly
+        assert common.relerr(X, Xo) < 1e-9, (name, symm, common.relerr(X, Xo))
+        assert np.max(np.abs(X.T @ S @ X - np.eye(S.shape[0]))) < 1e-10
+        Fs = np.zeros_like(F)
+        for b in blocks:
+            Fs[np.ix_(b, b)] = F[np.ix_(b, b)]
+        E, C = hf.scf.eig_gsym_sub(Fs, Xo, blocks)
+        Eo, Co = orc.eig_gsym_sub(Fs, Xo, blocks)
+        scale = max(1.0, np.max(np.abs(Eo)))
+        assert np.max(np.abs(E - Eo)) < 1e-10 * scale, (name, symm, np.max(np.abs(E - Eo)))
+        assert np.all(np.diff(E) >= 0)
+        assert np.max(np.abs(C.T @ S @ C - np.eye(len(E)))) < 1e-9
+        assert np.max(np.abs(Fs @ C - S @ C * E)) < 1e-9 * scale
+    # eig_gsym on the full problem
+    X = orc.form_Sinvh(S, False, gb.get_sym_idx(0))
+    E, C = hf.scf.eig_gsym(F, X)
+    Eo, _ = orc.eig_gsym(F, X)
+    assert np.max(np.abs(E - Eo)) < 1e-10 * max(1.0, np.max(np.abs(Eo)))
+
+
+def test_form_density_parity(case, hf):
+    import oracle_lib as orc
+    name, gb, ob, _, _ = case
+    rng = np.random.RandomState(5)
+    C = rng.uniform(-1, 1, size=(gb.Nbf(), 9))
+    assert np.max(np.abs(hf.scf.form_density(C, 4) - orc.form_density(C, 4))) < 1e-13
+    assert np.max(np.abs(hf.scf.form_density(C, 0))) == 0.0
