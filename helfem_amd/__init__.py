@@ -378,3 +378,25 @@ def lobatto_nodes(n):
     x = np.zeros(n)
     lib().hfg_lobatto_nodes(int(n), _p(x))
     return x
+
+
+def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0, igrid=4, zexp=1.0, lpad=10, ldft=0,
+                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None):
+    """Restricted closed-shell diatomic SCF with every per-iteration step on the GPU
+    (the loop of src/diatomic/main.cpp:780-995; flags as in main.cpp:89-133)."""
+    ctx = ctx or default_context()
+    L = lib()
+    L.hfg_scf_diatomic.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                   ctypes.c_double, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p]
+    out = np.zeros(12)
+    lm = (ctypes.c_int * len(lmmax))(*lmmax)
+    _check(L.hfg_scf_diatomic(ctx.h, Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
+                              method.encode(), ldft, mdft, symmetry, maxit, convthr, verbose, _p(out)))
+    keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
+    r = dict(zip(keys, out[:7]))
+    r["iterations"] = int(out[7])
+    r["converged"] = (out[7] - int(out[7])) > 0.25
+    r["tJ"], r["tK"], r["tXC"], r["tdiag"] = out[8:12]
+    return r

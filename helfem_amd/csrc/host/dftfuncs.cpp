@@ -1,0 +1,51 @@
+#include "dftfuncs.h"
+#include <cctype>
+#include <cstdlib>
+#include <sstream>
+#include <stdexcept>
+#include <strings.h>
+
+namespace helfem {
+
+namespace {
+struct Known {
+  const char *name;
+  int id;
+};
+const Known known[] = {{"lda_x", 1}, {"lda_c_vwn", 7}, {"lda_c_pw", 12}, {"gga_x_pbe", 101}, {"gga_c_pbe", 130}};
+
+int find_func(const std::string &name) {
+  if (name.empty()) throw std::runtime_error("empty functional name\n");
+  if (isdigit(name[0])) return atoi(name.c_str());
+  if (!strcasecmp(name.c_str(), "none")) return 0;
+  if (!strcasecmp(name.c_str(), "hyb_x_hf") || !strcasecmp(name.c_str(), "HF")) return -1;
+  for (const Known &k : known)
+    if (!strcasecmp(name.c_str(), k.name)) return k.id;
+  std::ostringstream oss;
+  oss << "\nError: functional " << name << " is not available in this build!\n";
+  throw std::runtime_error(oss.str());
+}
+}  // namespace
+
+void parse_xc_func(int &x_func, int &c_func, const std::string &xc) {
+  x_func = 0;
+  c_func = 0;
+  size_t dpos = xc.find('-', 0);
+  if (dpos != std::string::npos) {
+    x_func = find_func(xc.substr(0, dpos));
+    c_func = find_func(xc.substr(dpos + 1));
+  } else
+    x_func = find_func(xc);
+}
+
+double exact_exchange(int x_func) { return x_func == -1 ? 1.0 : 0.0; }
+
+const char *xc_func_name(int id) {
+  if (id == -1) return "HF";
+  if (id == 0) return "none";
+  for (const Known &k : known)
+    if (k.id == id) return k.name;
+  return "unknown";
+}
+
+}  // namespace helfem

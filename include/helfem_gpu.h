@@ -137,6 +137,13 @@ int hfg_form_density_dev(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *d
 int hfg_gemm_dev(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int64_t k, const double *dA,
                  int64_t lda, const double *dB, int64_t ldb, double *dC, int64_t ldc);
 
+/* ---- SCF driver (restricted closed shell), the loop of src/diatomic/main.cpp:780-995 --------- */
+/* out[0..7] = Etot, Ekin, Epot, Ecoul, Exx, Exc, Enucr, iterations(+0.5 if converged); out[8..11] =
+ * seconds of the last iteration's J, K, XC and diagonalisation steps (the reference's Timer prints). */
+int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmmax, int nlm, int nelem, int nnodes,
+                     int nquad, double Rmax, int igrid, double zexp, int lpad, const char *method, int ldft, int mdft,
+                     int symmetry, int maxit, double convthr, int verbose, double *out /* 12 */);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every kernel family is bracketed by hipEvents on the context's stream; the
  * accumulated device time (ms) and launch count per family can be read back after a synchronize.

@@ -156,3 +156,27 @@ def test_form_density_parity(case, hf):
     C = rng.uniform(-1, 1, size=(gb.Nbf(), 9))
     assert np.max(np.abs(hf.scf.form_density(C, 4) - orc.form_density(C, 4))) < 1e-13
     assert np.max(np.abs(hf.scf.form_density(C, 0))) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# end-to-end SCF: converged total energies, GPU vs oracle on identical grids (north-star bar: 1e-8 Eh)
+# ---------------------------------------------------------------------------------------------------
+SCF_CASES = [
+    # BASELINE config 3: diatomic H2 at R=1.4, HF, small (mu,nu) grid
+    ("H2_HF", dict(Z1=1, Z2=1, Rbond=1.4, lmmax=[6], nelem=3, nnodes=10, method="HF"), -1.13362957, 2e-7),
+    ("H2_LDA", dict(Z1=1, Z2=1, Rbond=1.4, lmmax=[4], nelem=2, nnodes=8, method="lda_x-lda_c_vwn"), None, None),
+    ("HeH+like_PBE", dict(Z1=2, Z2=0, Rbond=2.0, lmmax=[5], nelem=3, nnodes=8, method="gga_x_pbe-gga_c_pbe"), None, None),
+]
+
+
+@pytest.mark.parametrize("name,kw,lit,littol", SCF_CASES)
+def test_scf_energy_parity(hf, name, kw, lit, littol):
+    import oracle_lib as orc
+    g = hf.scf_diatomic(convthr=1e-9, maxit=60, **kw)
+    o = orc.scf_diatomic(convthr=1e-9, maxit=60, **kw)
+    assert g["converged"] and o["converged"]
+    assert abs(g["Etot"] - o["Etot"]) < 1e-8, (name, g["Etot"], o["Etot"])
+    for k in ("Ekin", "Epot", "Ecoul", "Exx", "Exc"):
+        assert abs(g[k] - o[k]) < 1e-6, (name, k, g[k], o[k])
+    if lit is not None:
+        assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
