@@ -400,3 +400,98 @@ def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0
     r["converged"] = (out[7] - int(out[7])) > 0.25
     r["tJ"], r["tK"], r["tXC"], r["tdiag"] = out[8:12]
     return r
+
+
+class DeviceSCFStep(object):
+    """One SCF iteration's hot path, device resident (torch tensors are only used as HBM buffers):
+
+        P --(J + XC, compact, sharded)--> all-reduce --> F = sym(H0+J+XC) --(eig blocks, sharded)-->
+        all-reduce --> (E, C) --> P' = C_occ C_occ^T
+
+    i.e. main.cpp:784-788, 808-900 and 934-971 of the reference's diatomic driver without DIIS.
+    """
+
+    def __init__(self, basis, x_func, c_func, ldft, mdft, nocc, symmetry=1, device=0, rank=0, nranks=1,
+                 dens_thr=1e-12):
+        import torch
+        self.torch = torch
+        self.basis = basis
+        self.x_func, self.c_func, self.nocc, self.thr = int(x_func), int(c_func), int(nocc), float(dens_thr)
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.ctx = Context(device, stream=torch.cuda.current_stream(self.dev).cuda_stream)
+        self.ctx.set_shard(rank, nranks)
+        basis.upload(ldft, mdft, ctx=self.ctx)
+        L = lib()
+        L.hfg_fock_compact_size.restype = ctypes.c_int64
+        L.hfg_eig_block_buf_size.restype = ctypes.c_int64
+        L.hfg_fock_compact_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+        N = basis.Nbf()
+        self.N = N
+        self.blocks = basis.get_sym_idx(symmetry)
+        self.blk_ptr, self.blk_idx = scf._blocks(self.blocks)
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        blockid = np.zeros(N, dtype=np.int32)
+        for ib, b in enumerate(self.blocks):
+            blockid[b] = ib
+        self.blockid = torch.from_numpy(blockid).to(self.dev)
+        self.Fc = torch.zeros(int(L.hfg_fock_compact_size(basis.h)), **f64)
+        self.scal = torch.zeros(3, **f64)
+        self.F = torch.zeros(N * N, **f64)
+        self.E = torch.zeros(N, **f64)
+        self.C = torch.zeros(N * N, **f64)
+        self.P = torch.zeros(N * N, **f64)
+        nb = int(L.hfg_eig_block_buf_size(len(self.blocks), self.blk_ptr.ctypes.data_as(c_i64_p)))
+        self.blockbuf = torch.zeros(nb, **f64)
+        self.H0 = None
+        self.Sinvh = None
+
+    def _ptr(self, t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def set_matrices(self, H0, Sinvh):
+        t = self.torch
+        self.H0 = t.from_numpy(np.asfortranarray(H0).ravel(order="F").copy()).to(self.dev)
+        self.Sinvh = t.from_numpy(np.asfortranarray(Sinvh).ravel(order="F").copy()).to(self.dev)
+
+    def set_density(self, P):
+        self.P.copy_(self.torch.from_numpy(np.asfortranarray(P).ravel(order="F").copy()))
+
+    def fock_partial(self):
+        _check(lib().hfg_fock_compact_dev(self.ctx.h, self.basis.h, self.x_func, self.c_func, self._ptr(self.P),
+                                          self._ptr(self.Fc), self._ptr(self.scal), self.thr))
+
+    def fock_finish(self):
+        _check(lib().hfg_fock_finish_dev(self.ctx.h, self.basis.h, self._ptr(self.Fc), self._ptr(self.H0),
+                                         self._ptr(self.blockid), self._ptr(self.F)))
+
+    def eig_partial(self):
+        _check(lib().hfg_eig_blocks_dev(self.ctx.h, ctypes.c_int64(self.N), self._ptr(self.F), self._ptr(self.Sinvh),
+                                        len(self.blocks), self.blk_ptr.ctypes.data_as(c_i64_p),
+                                        self.blk_idx.ctypes.data_as(c_i64_p), self._ptr(self.blockbuf)))
+
+    def eig_finish(self):
+        _check(lib().hfg_eig_assemble_dev(self.ctx.h, ctypes.c_int64(self.N), len(self.blocks),
+                                          self.blk_ptr.ctypes.data_as(c_i64_p), self.blk_idx.ctypes.data_as(c_i64_p),
+                                          self._ptr(self.blockbuf), self._ptr(self.E), self._ptr(self.C)))
+
+    def density(self):
+        _check(lib().hfg_form_density_dev(self.ctx.h, ctypes.c_int64(self.N), ctypes.c_int64(self.N), self._ptr(self.C),
+                                          ctypes.c_int64(self.nocc), self._ptr(self.P)))
+
+    def step(self, allreduce=None):
+        """one iteration; allreduce(tensor) sums a tensor over ranks in place (None: single GPU)"""
+        self.fock_partial()
+        if allreduce is not None:
+            allreduce(self.Fc)
+            allreduce(self.scal)
+        self.fock_finish()
+        self.eig_partial()
+        if allreduce is not None:
+            allreduce(self.blockbuf)
+        self.eig_finish()
+        self.density()
+
+    def numpy(self, t, shape):
+        return t.cpu().numpy().reshape(shape, order="F")

@@ -15,6 +15,11 @@ void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const d
                  double thr);
 void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
 void fock_release(hfg_dev_tables *t);
+size_t fock_compact_size(hfg_basis *basis);
+void fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dFc,
+                      double *dScal, double thr);
+void fock_finish_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dFc, const double *dH0, const int *dBlockId,
+                     double *dF);
 void exchange_release(hfg_dev_tables *t);
 void eig_release(hfg_ctx *ctx);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
@@ -23,6 +28,11 @@ void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
 void eig_gsym_dev(hfg_ctx *ctx, int N, int n, const double *dF, const double *dS, double *dE, double *dC);
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                       const int64_t *blk_idx, double *dE, double *dC);
+size_t eig_block_buf_size(int nblk, const int64_t *blk_ptr);
+void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                    const int64_t *blk_idx, double *dBlockBuf);
+void eig_assemble_dev(hfg_ctx *ctx, int N, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
+                      const double *dBlockBuf, double *dE, double *dC);
 void form_sinvh_dev(hfg_ctx *ctx, int N, const double *dS, bool chol, int nblk, const int64_t *blk_ptr,
                     const int64_t *blk_idx, double *dSinvh);
 void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc, double *dP);
@@ -321,6 +331,17 @@ int hfg_eig_gsym_sub_dev(hfg_ctx *ctx, int64_t N, const double *dF, const double
   HFG_TRY eig_gsym_sub_dev(ctx, (int)N, dF, dS, nblk, blk_ptr, blk_idx, dE, dC);
   HFG_CATCH
 }
+int64_t hfg_eig_block_buf_size(int nblk, const int64_t *blk_ptr) { return (int64_t)eig_block_buf_size(nblk, blk_ptr); }
+int hfg_eig_blocks_dev(hfg_ctx *ctx, int64_t N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                       const int64_t *blk_idx, double *dBlockBuf) {
+  HFG_TRY eig_blocks_dev(ctx, (int)N, dF, dS, nblk, blk_ptr, blk_idx, dBlockBuf);
+  HFG_CATCH
+}
+int hfg_eig_assemble_dev(hfg_ctx *ctx, int64_t N, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
+                         const double *dBlockBuf, double *dE, double *dC) {
+  HFG_TRY eig_assemble_dev(ctx, (int)N, nblk, blk_ptr, blk_idx, dBlockBuf, dE, dC);
+  HFG_CATCH
+}
 int hfg_form_density_dev(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *dC, int64_t nocc, double *dP) {
   HFG_TRY form_density_dev(ctx, (int)N, (int)ncols, dC, (int)nocc, dP);
   HFG_CATCH
@@ -328,6 +349,18 @@ int hfg_form_density_dev(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *d
 int hfg_gemm_dev(hfg_ctx *ctx, int tA, int tB, int64_t m, int64_t n, int64_t k, const double *dA, int64_t lda,
                  const double *dB, int64_t ldb, double *dC, int64_t ldc) {
   HFG_TRY gemm_dev(ctx, tA != 0, tB != 0, (int)m, (int)n, (int)k, 1.0, dA, (int)lda, dB, (int)ldb, 0.0, dC, (int)ldc);
+  HFG_CATCH
+}
+
+int64_t hfg_fock_compact_size(hfg_basis *b) { return (int64_t)fock_compact_size(b); }
+int hfg_fock_compact_dev(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *dP, double *dFc,
+                         double *dScal, double thr) {
+  HFG_TRY fock_compact_dev(ctx, b, x_func, c_func, dP, dFc, dScal, thr);
+  HFG_CATCH
+}
+int hfg_fock_finish_dev(hfg_ctx *ctx, hfg_basis *b, const double *dFc, const double *dH0, const int *dBlockId,
+                        double *dF) {
+  HFG_TRY fock_finish_dev(ctx, b, dFc, dH0, dBlockId, dF);
   HFG_CATCH
 }
 

@@ -554,121 +554,151 @@ void eig_gsym_dev(hfg_ctx *ctx, int N, int n, const double *dF, const double *dS
   check_status(ctx, w, 1);
 }
 
-// scf::eig_gsym_sub
-void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
-                      const int64_t *blk_idx, double *dE, double *dC) {
+// scf::eig_gsym_sub, phase 1: the symmetry blocks owned by this shard (block ib belongs to rank ib % nranks).
+// dBlockBuf: nblk slots of (nmax*nmax + nmax) doubles, slot ib = [C block (n x n, ld n) | pad | eigenvalues (n) at
+// offset nmax*nmax]; slots of blocks owned by other ranks are zeroed so that a sum all-reduce over ranks
+// completes the buffer.
+size_t eig_block_buf_size(int nblk, const int64_t *blk_ptr) {
+  size_t nmax = 0;
+  for (int ib = 0; ib < nblk; ib++) nmax = std::max<size_t>(nmax, blk_ptr[ib + 1] - blk_ptr[ib]);
+  return (size_t)nblk * (nmax * nmax + nmax);
+}
+
+void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                    const int64_t *blk_idx, double *dBlockBuf) {
   EigWork &w = work_for(ctx);
   hipStream_t s = ctx->stream;
-  if (nblk > MAXB) throw std::logic_error("eig_gsym_sub: more than 8 symmetry blocks not supported yet\n");
+  if (blk_ptr[nblk] != N) throw std::logic_error("Symmetry mismatch in eig_gsym_sub\n");
   // block row indices on the device
-  DevBuf<double> &idxbuf = ctx->ws[2];  // reused as raw storage for int64 rows + cols
+  DevBuf<double> &idxbuf = ctx->ws[2];  // raw storage for int64 rows + cols
   idxbuf.resize(2 * (size_t)N + 16);
   int64_t *drows = (int64_t *)idxbuf.p;
   int64_t *dcols = drows + N;
-  HFG_HIP_CHECK(hipMemcpyAsync(drows, blk_idx, sizeof(int64_t) * blk_ptr[nblk], hipMemcpyHostToDevice, s));
-  if (blk_ptr[nblk] != N) throw std::logic_error("Symmetry mismatch in eig_gsym_sub\n");
+  HFG_HIP_CHECK(hipMemcpyAsync(drows, blk_idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
 
   // column support of every block (scf_helpers.cpp:150-157)
   DevBuf<int> &flag = w.ibuf2;
-  flag.resize((size_t)N * nblk + N + 8);
+  flag.resize((size_t)N * nblk + 8);
   for (int ib = 0; ib < nblk; ib++) {
     int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
-    if (n == 0) continue;
+    if (n == 0) throw std::logic_error("eig_gsym_sub: empty symmetry block\n");
     hipLaunchKernelGGL(k_col_support, dim3(N), dim3(256), 0, s, dS, N, drows + blk_ptr[ib], n, flag.p + (size_t)ib * N);
   }
   std::vector<int> hflag((size_t)N * nblk);
   HFG_HIP_CHECK(hipMemcpyAsync(hflag.data(), flag.p, sizeof(int) * hflag.size(), hipMemcpyDeviceToHost, s));
   HFG_HIP_CHECK(hipStreamSynchronize(s));
-  std::vector<std::vector<int64_t> > cols(nblk);
   std::vector<int64_t> allcols;
   std::vector<int> coff(nblk + 1, 0);
   for (int ib = 0; ib < nblk; ib++) {
+    int cnt = 0;
     for (int c = 0; c < N; c++)
-      if (hflag[(size_t)ib * N + c]) cols[ib].push_back(c);
-    coff[ib + 1] = coff[ib] + (int)cols[ib].size();
-    int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
-    if ((int)cols[ib].size() != n)
+      if (hflag[(size_t)ib * N + c]) {
+        allcols.push_back(c);
+        cnt++;
+      }
+    coff[ib + 1] = coff[ib] + cnt;
+    if (cnt != (int)(blk_ptr[ib + 1] - blk_ptr[ib]))
       throw std::logic_error("eig_gsym_sub: Sinvh is not block structured (columns with support != block size)\n");
-    allcols.insert(allcols.end(), cols[ib].begin(), cols[ib].end());
   }
-  if (coff[nblk] != N) throw std::logic_error("Symmetry mismatch in eig_gsym_sub\n");
   HFG_HIP_CHECK(hipMemcpyAsync(dcols, allcols.data(), sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
 
-  DevBuf<double> &Etmp = ctx->ws[3];
-  Etmp.resize(N);
-  DevBuf<double> &Xall = ctx->ws[4];  // X blocks back to back
+  size_t nmax = 0;
+  for (int ib = 0; ib < nblk; ib++) nmax = std::max<size_t>(nmax, blk_ptr[ib + 1] - blk_ptr[ib]);
+  const size_t slot = nmax * nmax + nmax;
+  HFG_HIP_CHECK(hipMemsetAsync(dBlockBuf, 0, sizeof(double) * slot * nblk, s));
+
+  std::vector<int> mine;
+  for (int ib = 0; ib < nblk; ib++)
+    if (ib % ctx->shard_n == ctx->shard_rank) mine.push_back(ib);
   DevBuf<double> &Fb = ctx->ws[5];
   DevBuf<double> &T1 = ctx->ws[0];
-  DevBuf<double> &Cb = ctx->ws[1];
-  size_t xtot = 0, nmax = 0;
-  for (int ib = 0; ib < nblk; ib++) {
-    size_t n = blk_ptr[ib + 1] - blk_ptr[ib];
-    xtot += n * n;
-    nmax = std::max(nmax, n);
-  }
-  Xall.resize(xtot);
+  DevBuf<double> &Xall = ctx->ws[4];
   Fb.resize(nmax * nmax);
   T1.resize(nmax * nmax);
-  Cb.resize(nmax * nmax);
-
-  for (int c0 = 0; c0 < nblk; c0 += MAXB) {
-    int nb = std::min(MAXB, nblk - c0);
+  Xall.resize(nmax * nmax * MAXB);
+  for (size_t c0 = 0; c0 < mine.size(); c0 += MAXB) {
+    int nb = (int)std::min<size_t>(MAXB, mine.size() - c0);
     std::vector<int> ns(nb);
-    std::vector<size_t> xoff(nb);
-    size_t xo = 0;
-    for (int ib = 0; ib < c0; ib++) {
-      size_t n = blk_ptr[ib + 1] - blk_ptr[ib];
-      xo += n * n;
-    }
     {
       ProfScope ps(ctx, "eig_reduce");
       for (int k = 0; k < nb; k++) {
-        int ib = c0 + k;
+        int ib = mine[c0 + k];
         int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
         ns[k] = n;
-        xoff[k] = xo;
-        xo += (size_t)n * n;
-        if (n == 0) continue;
         w.A[k].resize((size_t)n * n);
-        double *Xb = Xall.p + xoff[k];
+        double *Xb = Xall.p + (size_t)k * nmax * nmax;
         hipLaunchKernelGGL(k_gather_block, dim3((n + 255) / 256, n), dim3(256), 0, s, dF, dS, N, drows + blk_ptr[ib],
                            dcols + coff[ib], n, Fb.p, Xb);
         gemm_dev(ctx, false, false, n, n, n, 1.0, Fb.p, n, Xb, n, 0.0, T1.p, n);
         gemm_dev(ctx, true, false, n, n, n, 1.0, Xb, n, T1.p, n, 0.0, w.A[k].p, n);
       }
     }
-    // empty blocks are not supported inside a batch: compact them away
-    std::vector<int> live;
-    for (int k = 0; k < nb; k++)
-      if (ns[k] > 0) live.push_back(k);
-    if (live.size() != (size_t)nb) throw std::logic_error("eig_gsym_sub: empty symmetry block\n");
     eig_sym_batch(ctx, w, nb, ns.data());
     {
       ProfScope ps(ctx, "eig_backtransform");
       for (int k = 0; k < nb; k++) {
-        int ib = c0 + k;
+        int ib = mine[c0 + k];
         int n = ns[k];
-        // C block = X Z, kept in Z's place via Cb then copied; eigenvalues gathered into Etmp
-        gemm_dev(ctx, false, false, n, n, n, 1.0, Xall.p + xoff[k], n, w.Z[k].p, n, 0.0, Cb.p, n);
-        HFG_HIP_CHECK(hipMemcpyAsync(w.Z[k].p, Cb.p, sizeof(double) * n * n, hipMemcpyDeviceToDevice, s));
-        HFG_HIP_CHECK(hipMemcpyAsync(Etmp.p + coff[ib], w.d[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        double *slotp = dBlockBuf + (size_t)ib * slot;
+        gemm_dev(ctx, false, false, n, n, n, 1.0, Xall.p + (size_t)k * nmax * nmax, n, w.Z[k].p, n, 0.0, slotp, n);
+        HFG_HIP_CHECK(hipMemcpyAsync(slotp + nmax * nmax, w.d[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
       }
     }
     check_status(ctx, w, nb);
-    // scatter needs the global ranks: deferred until all chunks are done when nblk > MAXB
-    ProfScope ps(ctx, "scatter");
-    DevBuf<int> &rank = w.ibuf1;
-    rank.resize(N + 8);
-    HFG_HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(double) * (size_t)N * N, s));
-    hipLaunchKernelGGL(k_rank, dim3((N + 255) / 256), dim3(256), 0, s, Etmp.p, N, rank.p);
-    for (int k = 0; k < nb; k++) {
-      int ib = c0 + k;
-      int n = ns[k];
-      hipLaunchKernelGGL(k_scatter_cols, dim3((n + 255) / 256, n), dim3(256), 0, s, w.Z[k].p, n, n,
-                         drows + blk_ptr[ib], rank.p, coff[ib], Etmp.p + coff[ib], N, dC, dE);
-    }
   }
   HFG_HIP_CHECK(hipGetLastError());
+}
+
+// phase 2: global sort of all eigenvalues and scatter of the block eigenvectors into C (N x N)
+void eig_assemble_dev(hfg_ctx *ctx, int N, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
+                      const double *dBlockBuf, double *dE, double *dC) {
+  EigWork &w = work_for(ctx);
+  hipStream_t s = ctx->stream;
+  ProfScope ps(ctx, "scatter");
+  DevBuf<double> &idxbuf = ctx->ws[2];
+  idxbuf.resize(2 * (size_t)N + 16);
+  int64_t *drows = (int64_t *)idxbuf.p;
+  HFG_HIP_CHECK(hipMemcpyAsync(drows, blk_idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
+  size_t nmax = 0;
+  for (int ib = 0; ib < nblk; ib++) nmax = std::max<size_t>(nmax, blk_ptr[ib + 1] - blk_ptr[ib]);
+  const size_t slot = nmax * nmax + nmax;
+  DevBuf<double> &Etmp = ctx->ws[3];
+  Etmp.resize(N);
+  for (int ib = 0; ib < nblk; ib++) {
+    size_t n = blk_ptr[ib + 1] - blk_ptr[ib];
+    HFG_HIP_CHECK(hipMemcpyAsync(Etmp.p + blk_ptr[ib], dBlockBuf + (size_t)ib * slot + nmax * nmax, sizeof(double) * n,
+                                 hipMemcpyDeviceToDevice, s));
+  }
+  DevBuf<int> &rank = w.ibuf1;
+  rank.resize(N + 8);
+  HFG_HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(double) * (size_t)N * N, s));
+  hipLaunchKernelGGL(k_rank, dim3((N + 255) / 256), dim3(256), 0, s, Etmp.p, N, rank.p);
+  for (int ib = 0; ib < nblk; ib++) {
+    int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
+    hipLaunchKernelGGL(k_scatter_cols, dim3((n + 255) / 256, n), dim3(256), 0, s, dBlockBuf + (size_t)ib * slot, n, n,
+                       drows + blk_ptr[ib], rank.p, (int)blk_ptr[ib], Etmp.p + blk_ptr[ib], N, dC, dE);
+  }
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+// scf::eig_gsym_sub on one device
+void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                      const int64_t *blk_idx, double *dE, double *dC) {
+  int save_rank = ctx->shard_rank, save_n = ctx->shard_n;
+  ctx->shard_rank = 0;
+  ctx->shard_n = 1;
+  try {
+    DevBuf<double> &buf = ctx->ws[6];
+    buf.resize(eig_block_buf_size(nblk, blk_ptr));
+    eig_blocks_dev(ctx, N, dF, dS, nblk, blk_ptr, blk_idx, buf.p);
+    eig_assemble_dev(ctx, N, nblk, blk_ptr, blk_idx, buf.p, dE, dC);
+  } catch (...) {
+    ctx->shard_rank = save_rank;
+    ctx->shard_n = save_n;
+    throw;
+  }
+  ctx->shard_rank = save_rank;
+  ctx->shard_n = save_n;
 }
 
 }  // namespace hfg

@@ -75,6 +75,48 @@ __global__ void k_scatter_dense(const double *__restrict__ Xc, int N, int A, int
   out[(size_t)col * N + row] = v;
 }
 
+// F(row,col) = [blockid(row)==blockid(col)] * (H0(row,col) + scatter(Xc)(row,col))
+// (Fock assembly + scf::enforce_fock_symmetry, src/diatomic/main.cpp:871-900, scf_helpers.cpp:249)
+__global__ void k_fock_finish(const double *__restrict__ Xc, const double *__restrict__ H0,
+                              const int *__restrict__ blockid, int N, int A, int R, int E, int p,
+                              const int *__restrict__ pure_shell, const int *__restrict__ pure_n,
+                              double *__restrict__ out) {
+  int row = blockIdx.x * 64 + (threadIdx.x & 63);
+  int col = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (row >= N || col >= N) return;
+  size_t o = (size_t)col * N + row;
+  if (blockid && blockid[row] != blockid[col]) {
+    out[o] = 0.0;
+    return;
+  }
+  int x = pure_shell[row], n = pure_n[row];
+  int y = pure_shell[col], m = pure_n[col];
+  int pm = p - 1, pp = p * p;
+  int e1 = n / pm, f1 = m / pm;
+  double v = H0 ? H0[o] : 0.0;
+  const double *base = Xc + (size_t)(x * A + y) * E * pp;
+  for (int ce = 0; ce < 2; ce++) {
+    int e = e1 - ce;
+    if (e < 0 || e >= E) continue;
+    int i = n - e * pm;
+    if (i < 0 || i > pm) continue;
+    for (int cf = 0; cf < 2; cf++) {
+      int f = f1 - cf;
+      if (f != e) continue;
+      int j = m - f * pm;
+      if (j < 0 || j > pm) continue;
+      v += base[(size_t)e * pp + j * p + i];
+    }
+  }
+  out[o] = v;
+}
+
+__global__ void k_add_inplace(double *__restrict__ a, const double *__restrict__ b, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) a[i] += b[i];
+}
+
 // -------------------------------------------------------------------------------------------------
 // Coulomb
 // -------------------------------------------------------------------------------------------------
@@ -83,8 +125,9 @@ __global__ void k_scatter_dense(const double *__restrict__ Xc, int N, int A, int
 __global__ void k_coulomb_ket(const double *__restrict__ Pc, int A, int E, int pp, const int *__restrict__ lm_off,
                               const int *__restrict__ lm_x, const int *__restrict__ lm_y,
                               const double *__restrict__ lm_c0, const double *__restrict__ lm_c2, int NLM,
-                              double *__restrict__ Paux) {
+                              const int *__restrict__ LM_ilm, int rank, int nranks, double *__restrict__ Paux) {
   int iLM = blockIdx.x, e = blockIdx.y;
+  if (LM_ilm[iLM] % nranks != rank) return;  // (L,|M|) channels are the multi-GPU shards of J
   int beg = lm_off[iLM], end = lm_off[iLM + 1];
   for (int t = threadIdx.x; t < pp; t += blockDim.x) {
     double a0 = 0.0, a2 = 0.0;
@@ -103,9 +146,10 @@ __global__ void k_coulomb_ket(const double *__restrict__ Pc, int A, int E, int p
 //     this is where the 4*Nlm*E*p^4*8 bytes of primitive integrals are streamed once per build).
 __global__ void k_coulomb_tei(const double *__restrict__ tei, const double *__restrict__ Paux, int Nlm, int NLM,
                               int E, int pp, const int *__restrict__ lmpos /* [Nlm][2] iLM of +M and -M */,
-                              double *__restrict__ Y) {
+                              int rank, int nranks, double *__restrict__ Y) {
   extern __shared__ double sh[];  // x_plus[pp], x_minus[pp]
   int ilm = blockIdx.x / E, e = blockIdx.x % E;
+  if (ilm % nranks != rank) return;
   int tt = blockIdx.y;  // 0:00 1:02 2:20 3:22
   int iLMp = lmpos[2 * ilm], iLMm = lmpos[2 * ilm + 1];
   int which = (tt & 1);  // 00,20 act on Paux0 ; 02,22 act on Paux2
@@ -132,11 +176,12 @@ __global__ void k_coulomb_tei(const double *__restrict__ tei, const double *__re
 // K2c per (L,M): disjoint (cross-element) part via the trace scalars + in-element part (basis.cpp:1424-1494)
 __global__ void k_coulomb_radial(const double *__restrict__ Paux, const double *__restrict__ Y,
                                  const double *__restrict__ disj, const int *__restrict__ LM_ilm,
-                                 const double *__restrict__ LM_fac, int Nlm, int NLM, int E, int p,
-                                 double *__restrict__ Jaux) {
+                                 const double *__restrict__ LM_fac, int Nlm, int NLM, int E, int p, int rank,
+                                 int nranks, double *__restrict__ Jaux) {
   extern __shared__ double sh[];  // red[4*E*nwave], sc[4*E], big[E], small[E]
   int iLM = blockIdx.x;
   int ilm = LM_ilm[iLM];
+  if (ilm % nranks != rank) return;
   double fac = LM_fac[iLM];
   int pp = p * p;
   int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
@@ -195,7 +240,7 @@ __global__ void k_coulomb_radial(const double *__restrict__ Paux, const double *
 __global__ void k_coulomb_bra(const double *__restrict__ Jaux, int A, int E, int pp, int NLM,
                               const int *__restrict__ pair_off, const int *__restrict__ ent_iLM,
                               const double *__restrict__ ent_c0, const double *__restrict__ ent_c2,
-                              double *__restrict__ Jc) {
+                              const int *__restrict__ LM_ilm, int rank, int nranks, double *__restrict__ Jc) {
   int ij = blockIdx.x, e = blockIdx.y;
   int iang = ij / A, jang = ij % A;
   int pr = jang * A + iang;  // pair (x=jang, y=iang)
@@ -204,6 +249,7 @@ __global__ void k_coulomb_bra(const double *__restrict__ Jaux, int A, int E, int
     double acc = 0.0;
     for (int k = beg; k < end; k++) {
       int iLM = ent_iLM[k];
+      if (LM_ilm[iLM] % nranks != rank) continue;
       acc += ent_c0[k] * Jaux[((size_t)(0 * NLM + iLM) * E + e) * pp + t] +
              ent_c2[k] * Jaux[((size_t)(1 * NLM + iLM) * E + e) * pp + t];
     }
@@ -218,7 +264,7 @@ __global__ void k_coulomb_bra(const double *__restrict__ Jaux, int A, int E, int
 //    D1[Q][x][y] = sum_ij B'_i(q) Pc[..][j][i] B_j(q)            (replaces Pv = P conj(bf), dftgrid.cpp:62)
 __global__ void k_xc_density_radial(const double *__restrict__ Pc, const double *__restrict__ B,
                                     const double *__restrict__ dB, int A, int E, int p, int nq, int do_grad,
-                                    double *__restrict__ D0, double *__restrict__ D1) {
+                                    int rank, int nranks, double *__restrict__ D0, double *__restrict__ D1) {
   extern __shared__ double sh[];  // P[pp]
   int xy = blockIdx.x, e = blockIdx.y;
   int pp = p * p;
@@ -226,6 +272,7 @@ __global__ void k_xc_density_radial(const double *__restrict__ Pc, const double 
   __syncthreads();
   size_t AA = (size_t)A * A;
   for (int q = threadIdx.x; q < nq; q += blockDim.x) {
+    if ((e * nq + q) % nranks != rank) continue;  // radial quadrature points are the multi-GPU shards of XC
     const double *b = B + ((size_t)e * nq + q) * p;
     const double *db = dB + ((size_t)e * nq + q) * p;
     double d0 = 0.0, d1 = 0.0;
@@ -250,9 +297,10 @@ __global__ void k_xc_density_radial(const double *__restrict__ Pc, const double 
 __global__ void k_xc_density_theta(const double *__restrict__ D0, const double *__restrict__ D1,
                                    const double *__restrict__ Th, const double *__restrict__ dTh, int A, int nth,
                                    int G, const int *__restrict__ grp_off, const int *__restrict__ grp_shell,
-                                   int do_grad, size_t NQ, double *__restrict__ V) {
+                                   int do_grad, size_t NQ, int rank, int nranks, double *__restrict__ V) {
   extern __shared__ double sh[];  // d0[na*nb], d1[na*nb]
   size_t Q = blockIdx.x;
+  if ((int)(Q % nranks) != rank) return;
   int ga = blockIdx.y / G, gb = blockIdx.y % G;
   int a0 = grp_off[ga], na = grp_off[ga + 1] - a0;
   int b0 = grp_off[gb], nb = grp_off[gb + 1] - b0;
@@ -303,9 +351,16 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
                           const double *__restrict__ th_w, const int *__restrict__ grp_m,
                           const double *__restrict__ cosd, const double *__restrict__ sind, int Dmax, int G, int nth,
                           int nphi, double Rh, int x_func, int c_func, int do_grad, double thr, size_t NQ,
-                          double *__restrict__ Fo, double *__restrict__ partial /* [2][NQ] */) {
+                          int rank, int nranks, double *__restrict__ Fo, double *__restrict__ partial /* [2][NQ] */) {
   extern __shared__ double sh[];  // pot[4][nth*nphi], red[2*nwave]
   size_t Q = blockIdx.x;
+  if ((int)(Q % nranks) != rank) {
+    if (threadIdx.x == 0) {
+      partial[Q] = 0.0;
+      partial[NQ + Q] = 0.0;
+    }
+    return;
+  }
   int ng = nth * nphi;
   double *p0 = sh, *p1 = sh + ng, *p2 = sh + 2 * ng, *p3 = sh + 3 * ng;
   double *red = sh + 4 * ng;
@@ -410,9 +465,10 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
 __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__restrict__ Th,
                                 const double *__restrict__ dTh, int A, int nth, int G,
                                 const int *__restrict__ grp_off, const int *__restrict__ grp_shell, int do_grad,
-                                size_t NQ, double *__restrict__ GA, double *__restrict__ GB) {
+                                size_t NQ, int rank, int nranks, double *__restrict__ GA, double *__restrict__ GB) {
   extern __shared__ double sh[];  // f0[nth], f1[nth], f2[nth]
   size_t Q = blockIdx.x;
+  if ((int)(Q % nranks) != rank) return;
   int ga = blockIdx.y / G, gb = blockIdx.y % G;
   int a0 = grp_off[ga], na = grp_off[ga + 1] - a0;
   int b0 = grp_off[gb], nb = grp_off[gb + 1] - b0;
@@ -444,7 +500,7 @@ __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__r
 //    Hc[x][y][e][n'][n] = sum_q B_n B_n' (GA_xy + GA_yx) + B'_n B_n' GB_xy + B_n B'_n' GB_yx
 __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__restrict__ GB,
                                  const double *__restrict__ B, const double *__restrict__ dB, int A, int E, int p,
-                                 int nq, int do_grad, double *__restrict__ Hc) {
+                                 int nq, int do_grad, int rank, int nranks, double *__restrict__ Hc) {
   extern __shared__ double sh[];  // gs[nq], g1[nq], g2[nq]
   int xy = blockIdx.x, e = blockIdx.y;
   int x = xy / A, y = xy % A;
@@ -453,9 +509,10 @@ __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__
   double *gs = sh, *g1 = sh + nq, *g2 = sh + 2 * nq;
   for (int q = threadIdx.x; q < nq; q += blockDim.x) {
     size_t Q = (size_t)e * nq + q;
-    gs[q] = GA[Q * AA + xy] + GA[Q * AA + yx];
-    g1[q] = do_grad ? GB[Q * AA + xy] : 0.0;
-    g2[q] = do_grad ? GB[Q * AA + yx] : 0.0;
+    bool own = ((int)(Q % nranks) == rank);
+    gs[q] = own ? GA[Q * AA + xy] + GA[Q * AA + yx] : 0.0;
+    g1[q] = (own && do_grad) ? GB[Q * AA + xy] : 0.0;
+    g2[q] = (own && do_grad) ? GB[Q * AA + yx] : 0.0;
   }
   __syncthreads();
   int pp = p * p;
@@ -565,15 +622,15 @@ void coulomb_compact(hfg_ctx *ctx, hfg_basis *basis, const double *dPc, double *
   a.Jaux.resize(2 * nb);
   int bs = std::min(256, round_up64(pp));
   hipLaunchKernelGGL(k_coulomb_ket, dim3(t->NLM, t->E), dim3(bs), 0, ctx->stream, dPc, t->A, t->E, pp, t->lm_off.p,
-                     t->lm_x.p, t->lm_y.p, t->lm_c0.p, t->lm_c2.p, t->NLM, a.Paux.p);
+                     t->lm_x.p, t->lm_y.p, t->lm_c0.p, t->lm_c2.p, t->NLM, t->LM_ilm.p, ctx->shard_rank, ctx->shard_n, a.Paux.p);
   hipLaunchKernelGGL(k_coulomb_tei, dim3(t->Nlm * t->E, 4), dim3(bs), 2 * pp * sizeof(double), ctx->stream, t->tei.p,
-                     a.Paux.p, t->Nlm, t->NLM, t->E, pp, a.lmpos.p, a.Y.p);
+                     a.Paux.p, t->Nlm, t->NLM, t->E, pp, a.lmpos.p, ctx->shard_rank, ctx->shard_n, a.Y.p);
   int nwave = bs / 64;
   size_t shb = (size_t)(4 * t->E * nwave + 4 * t->E + 2 * t->E) * sizeof(double);
   hipLaunchKernelGGL(k_coulomb_radial, dim3(t->NLM), dim3(bs), shb, ctx->stream, a.Paux.p, a.Y.p, t->disj.p,
-                     t->LM_ilm.p, t->LM_fac.p, t->Nlm, t->NLM, t->E, t->p, a.Jaux.p);
+                     t->LM_ilm.p, t->LM_fac.p, t->Nlm, t->NLM, t->E, t->p, ctx->shard_rank, ctx->shard_n, a.Jaux.p);
   hipLaunchKernelGGL(k_coulomb_bra, dim3(t->A * t->A, t->E), dim3(bs), 0, ctx->stream, a.Jaux.p, t->A, t->E, pp,
-                     t->NLM, t->pair_off.p, t->ent_iLM.p, t->ent_c0.p, t->ent_c2.p, dJc);
+                     t->NLM, t->pair_off.p, t->ent_iLM.p, t->ent_c0.p, t->ent_c2.p, t->LM_ilm.p, ctx->shard_rank, ctx->shard_n, dJc);
   HFG_HIP_CHECK(hipGetLastError());
 }
 
@@ -612,20 +669,20 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
 
   hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(std::min(256, round_up64(nq))), p * p * sizeof(double),
-                     ctx->stream, dPc, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, a.D0.p, a.D1.p);
+                     ctx->stream, dPc, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank, ctx->shard_n, a.D0.p, a.D1.p);
   hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
                      2 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, t->Th.p, t->dTh.p, A, nth, G,
-                     t->grp_off.p, t->grp_shell.p, do_grad, NQ, a.V.p);
+                     t->grp_off.p, t->grp_shell.p, do_grad, NQ, ctx->shard_rank, ctx->shard_n, a.V.p);
   size_t shb = (size_t)(4 * nth * nphi + 2 * 4) * sizeof(double);
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   hipLaunchKernelGGL(k_xc_grid, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, x_func,
-                     c_func, do_grad, thr, NQ, a.Fo.p, a.partial.p);
+                     c_func, do_grad, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
   hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 3 * nth * sizeof(double), ctx->stream,
-                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, NQ, a.GA.p, a.GB.p);
+                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p);
   hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 3 * nq * sizeof(double),
-                     ctx->stream, a.GA.p, a.GB.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, dHc);
+                     ctx->stream, a.GA.p, a.GB.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank, ctx->shard_n, dHc);
   hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
   HFG_HIP_CHECK(hipGetLastError());
 }
@@ -641,6 +698,47 @@ void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const d
   gather_compact(ctx, basis, dP, a.Pc.p);
   xc_compact(ctx, basis, x_func, c_func, a.Pc.p, a.Jc.p, dScal, thr);
   scatter_dense(ctx, basis, a.Jc.p, dH);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+size_t fock_compact_size(hfg_basis *basis) {
+  const auto &b = basis->b;
+  return (size_t)b.Nang() * b.Nang() * b.Nel() * b.max_Nprim() * b.max_Nprim();
+}
+
+// This shard's part of J + XC in the compact layout (to be summed over ranks), dScal = partial (Exc, Nel, 0)
+void fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dFc,
+                      double *dScal, double thr) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  FockAux &a = aux_for(ctx, basis);
+  const size_t nc = fock_compact_size(basis);
+  a.Pc.resize(nc);
+  a.Jc.resize(nc);
+  {
+    ProfScope ps(ctx, "coulomb");
+    gather_compact(ctx, basis, dP, a.Pc.p);
+    coulomb_compact(ctx, basis, a.Pc.p, dFc);
+  }
+  if (x_func > 0 || c_func > 0) {
+    ProfScope ps(ctx, "xc");
+    xc_compact(ctx, basis, x_func, c_func, a.Pc.p, a.Jc.p, dScal, thr);
+    hipLaunchKernelGGL(k_add_inplace, dim3(2048), dim3(256), 0, ctx->stream, dFc, a.Jc.p, nc);
+  } else {
+    HFG_HIP_CHECK(hipMemsetAsync(dScal, 0, 3 * sizeof(double), ctx->stream));
+  }
+  (void)t;
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+// F = enforce_fock_symmetry(H0 + J + XC) from the (rank-summed) compact matrix
+void fock_finish_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dFc, const double *dH0, const int *dBlockId,
+                     double *dF) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  FockAux &a = aux_for(ctx, basis);
+  ProfScope ps(ctx, "scatter");
+  dim3 grid((t->N + 63) / 64, (t->N + 3) / 4);
+  hipLaunchKernelGGL(k_fock_finish, grid, dim3(256), 0, ctx->stream, dFc, dH0, dBlockId, t->N, t->A, t->R, t->E, t->p,
+                     a.pure_shell.p, a.pure_n.p, dF);
   HFG_HIP_CHECK(hipGetLastError());
 }
 

@@ -1,0 +1,62 @@
+"""One-process-per-GPU plumbing for the sharded SCF iteration (torch.distributed over RCCL).
+
+The hot path shards naturally:
+  * Coulomb: (L,|M|) channels are independent (basis.cpp:1414)      -> rank r owns channels ilm % nranks == r
+  * XC: radial quadrature points are independent (dftgrid.cpp:779)  -> rank r owns points Q % nranks == r
+  * eigensolve: symmetry blocks are independent (scf_helpers.cpp:148) -> rank r owns blocks ib % nranks == r
+Each rank produces partial results in a zero-padded buffer; one sum all-reduce of the *compact*
+(block-banded) Fock buffer and one of the eigenvector block buffer complete them on every rank.
+No other data-path collective exists.  The same functions run on CPU tensors with the gloo backend,
+which is how the N>1 logic is tested without GPUs (tests/test_parallel_gloo.py).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def owner(unit, nranks):
+    """round-robin ownership used by the kernels (fock.hip, eig.hip)"""
+    return unit % nranks
+
+
+def owned_units(nunits, rank, nranks):
+    return [u for u in range(nunits) if owner(u, nranks) == rank]
+
+
+def allreduce_sum_(t):
+    """in-place sum all-reduce (no-op for a single process)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -131,8 +131,26 @@ int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *d
 /* dScal: 3 doubles in HBM receiving Exc, Nel, Ekin */
 int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH,
                     double *dScal, double dens_thr);
+/* Fused, shardable Fock build for the SCF loop (main.cpp:808-900): J and the XC matrix are block-banded in
+ * the radial index, so each rank produces its shard's contribution in a compact layout of
+ * hfg_fock_compact_size() doubles; the caller all-reduces that buffer (and dScal) over ranks and
+ * hfg_fock_finish_dev() forms F = enforce_fock_symmetry(H0 + J + XC) (dBlockId: symmetry block of
+ * every basis function, or NULL). */
+int64_t hfg_fock_compact_size(hfg_basis *basis);
+int hfg_fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dFc,
+                         double *dScal, double dens_thr);
+int hfg_fock_finish_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dFc, const double *dH0, const int *dBlockId,
+                        double *dF);
 int hfg_eig_gsym_sub_dev(hfg_ctx *ctx, int64_t N, const double *dF, const double *dSinvh, int nblk,
                          const int64_t *blk_ptr, const int64_t *blk_idx, double *dE, double *dC);
+/* Multi-GPU form of eig_gsym_sub: symmetry blocks are independent (scf_helpers.cpp:148-175), block ib is
+ * solved by rank ib % nranks into a buffer of hfg_eig_block_buf_size() doubles (other slots zero); after a
+ * sum all-reduce of that buffer every rank calls hfg_eig_assemble_dev() for the global sort (:183-185). */
+int64_t hfg_eig_block_buf_size(int nblk, const int64_t *blk_ptr);
+int hfg_eig_blocks_dev(hfg_ctx *ctx, int64_t N, const double *dF, const double *dSinvh, int nblk,
+                       const int64_t *blk_ptr, const int64_t *blk_idx, double *dBlockBuf);
+int hfg_eig_assemble_dev(hfg_ctx *ctx, int64_t N, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
+                         const double *dBlockBuf, double *dE, double *dC);
 int hfg_form_density_dev(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *dC, int64_t nocc, double *dP);
 int hfg_gemm_dev(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int64_t k, const double *dA,
                  int64_t lda, const double *dB, int64_t ldb, double *dC, int64_t ldc);
