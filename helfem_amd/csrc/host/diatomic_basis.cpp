@@ -309,6 +309,15 @@ void TwoDBasis::compute_tei(bool exchange) {
   const size_t Nlm = lm_map.size();
   const size_t nq = xq.size();
   const int ld = Lmax + 1;
+  // P_L^M / Q_L^M evaluation (own implementation unless a test installed the reference's library)
+  const legendre_provider_t provider = get_legendre_provider();
+  const int Lm = Lmax, Mm = Mmax, lp = lpad;
+  auto legPQ = [provider, Lm, Mm, lp](double xi, double *P, double *Q) {
+    if (provider)
+      provider(Lm, Mm, lp, xi, P, Q);
+    else
+      legendre_PQ(Lm, Mm, xi, P, Q);
+  };
 
   disjoint_P0.assign(Ne * Nlm, Mat());
   disjoint_P2.assign(Ne * Nlm, Mat());
@@ -350,18 +359,18 @@ void TwoDBasis::compute_tei(bool exchange) {
         wsub[s] = wq[q] * mulen * std::sinh(mu);
         chsub[s] = ch;
         xpoly[q] = (mu - mumid0) / mulen0;
-        legendre_PQ(Lmax, Mmax, ch, &Ps[s * ld * (Mmax + 1)], Qdummy.data());
+        legPQ(ch, &Ps[s * ld * (Mmax + 1)], Qdummy.data());
       }
       Mat bf = poly.eval_dnf(xpoly, 0, mulen0);
       for (size_t q = 0; q < nq; q++)
         for (size_t j = 0; j < Ni; j++)
           for (size_t i = 0; i < Ni; i++) bbs(j * Ni + i, isub * nq + q) = bf(q, i) * bf(q, j);
-    });
+    }, provider ? 1 : 0);  // an installed test provider (Fortran library) is not re-entrant
     Vec wmain(nq), chmain(nq);
     for (size_t q = 0; q < nq; q++) {
       chmain[q] = std::cosh(mu0[q]);
       wmain[q] = wq[q] * mulen0 * std::sinh(mu0[q]);
-      legendre_PQ(Lmax, Mmax, chmain[q], &Pm[q * ld * (Mmax + 1)], &Qm[q * ld * (Mmax + 1)]);
+      legPQ(chmain[q], &Pm[q * ld * (Mmax + 1)], &Qm[q * ld * (Mmax + 1)]);
     }
     Mat bb0(Np, nq);  // products at main points
     for (size_t q = 0; q < nq; q++)

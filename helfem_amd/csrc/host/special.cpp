@@ -284,6 +284,10 @@ void legendre_PQ(int Lmax, int Mmax, double xi, double *P, double *Q) {
     for (int L = M; L <= Lmax; L++) Q[M * ld + L] = (double)q[M][L];
 }
 
+static legendre_provider_t g_legendre_provider = nullptr;
+void set_legendre_provider(legendre_provider_t fn) { g_legendre_provider = fn; }
+legendre_provider_t get_legendre_provider() { return g_legendre_provider; }
+
 void angular_chebyshev(int ltheta, int nphi, Vec &cth, Vec &phi, Vec &w) {
   // reference: angular.cpp:22-45 (compound_rule), 64-71
   Vec xl, wl;

@@ -48,6 +48,12 @@ class Gaunt {
 /// column-major (index M*(Lmax+1)+L), same layout as the Fortran wrapper's calc_Plm_arr.
 /// Entries with L<M are zero.  xi==1 gives all zeros (legendretable.cpp:73 skips it).
 void legendre_PQ(int Lmax, int Mmax, double xi, double *P, double *Q);
+/// Test hook: replace the Legendre evaluation used by compute_tei (signature of legendre_PQ plus lpad).
+/// Only the oracle's test API sets it, to measure how the limited accuracy of the reference's Fortran
+/// library (compiled into oracle/_ref) propagates into integrals and energies; the product never does.
+typedef void (*legendre_provider_t)(int Lmax, int Mmax, int lpad, double xi, double *P, double *Q);
+void set_legendre_provider(legendre_provider_t fn);
+legendre_provider_t get_legendre_provider();
 
 /// Angular product rule: cos(theta) Chebyshev nodes (ltheta of them) x nphi uniform phi
 void angular_chebyshev(int ltheta, int nphi, Vec &cth, Vec &phi, Vec &w);

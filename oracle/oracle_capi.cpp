@@ -60,6 +60,9 @@ extern "C" {
 
 const char *orc_last_error() { return g_err.c_str(); }
 
+/// test hook: evaluate P_L^M/Q_L^M through fn (e.g. the reference's Fortran library in oracle/_ref)
+void orc_set_legendre_provider(helfem::legendre_provider_t fn) { helfem::set_legendre_provider(fn); }
+
 int orc_basis_create(int Z1, int Z2, double Rhalf, int nnodes, int nquad, const double *bval, int nbval,
                      const int *lval, const int *mval, int nang, int lpad, void **out) {
   ORC_TRY
