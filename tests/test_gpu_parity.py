@@ -180,3 +180,54 @@ def test_scf_energy_parity(hf, name, kw, lit, littol):
         assert abs(g[k] - o[k]) < 1e-6, (name, k, g[k], o[k])
     if lit is not None:
         assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
+
+
+# ---------------------------------------------------------------------------------------------------
+# divide-and-conquer tridiagonal stage: hard spectra (through eig_sym on tridiagonal input)
+# ---------------------------------------------------------------------------------------------------
+def _tridiag(d, e):
+    return np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+
+
+def _hard_cases():
+    rng = np.random.RandomState(42)
+    n = 300
+    yield "near_identity", _tridiag(np.ones(n), np.full(n - 1, 1e-9))
+    yield "graded", _tridiag(np.arange(n, dtype=float) ** 3, rng.uniform(0, 1, n - 1))
+    yield "wilkinson", _tridiag(np.abs(np.arange(n) - n // 2).astype(float), np.ones(n - 1))
+    yield "toeplitz", _tridiag(np.zeros(n), np.ones(n - 1))
+    yield "decoupled", _tridiag(rng.uniform(-1, 1, n), np.where(rng.rand(n - 1) < 0.3, 0.0, rng.uniform(-1, 1, n - 1)))
+    dd = rng.uniform(-1, 1, n)
+    dd[100:140] = 0.5
+    yield "clustered", _tridiag(dd, rng.uniform(-1, 1, n - 1) * 1e-8)
+    yield "dynamic_range", _tridiag(np.exp(rng.uniform(-20, 15, n)), np.exp(rng.uniform(-20, 10, n - 1)))
+    for m in (33, 65, 97, 129, 513, 1000):
+        yield "random_%d" % m, _tridiag(rng.uniform(-1, 1, m), rng.uniform(-1, 1, m - 1))
+    # exactly degenerate blocks (the +m / -m degeneracy of the diatomic problem when symmetry is off)
+    A = rng.uniform(-1, 1, (40, 40))
+    A = A + A.T
+    Z = np.zeros_like(A)
+    yield "degenerate_pairs", np.block([[A, Z], [Z, A]])
+
+
+@pytest.mark.parametrize("name,A", list(_hard_cases()), ids=[c[0] for c in _hard_cases()])
+def test_eig_sym_hard_spectra(hf, name, A):
+    n = A.shape[0]
+    E, C = hf.scf.eig_sym(A)
+    Eref = np.linalg.eigvalsh(A)
+    scale = max(np.max(np.abs(Eref)), 1e-300)
+    assert np.max(np.abs(E - Eref)) < 5e-14 * scale * max(np.sqrt(n), 10), (name, np.max(np.abs(E - Eref)) / scale)
+    assert np.max(np.abs(C.T @ C - np.eye(n))) < 1e-12, name
+    assert np.max(np.abs(A @ C - C * E)) < 1e-12 * scale * max(np.sqrt(n), 10), name
+
+
+def test_eig_sym_1400_dense(hf):
+    rng = np.random.RandomState(7)
+    n = 1400
+    A = rng.uniform(-1, 1, (n, n))
+    A = A + A.T + np.diag(np.linspace(0, 2000.0, n))
+    E, C = hf.scf.eig_sym(A)
+    Eref = np.linalg.eigvalsh(A)
+    assert np.max(np.abs(E - Eref)) < 1e-10
+    assert np.max(np.abs(C.T @ C - np.eye(n))) < 1e-11
+    assert np.max(np.abs(A @ C - C * E)) < 1e-9
