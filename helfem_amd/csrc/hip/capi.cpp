@@ -23,6 +23,7 @@ void fock_finish_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dFc, const do
 void exchange_release(hfg_dev_tables *t);
 void eig_release(hfg_ctx *ctx);
 void dc_release(hfg_ctx *ctx);
+void trd_release(hfg_ctx *ctx);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
@@ -163,6 +164,7 @@ int hfg_ctx_destroy(hfg_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   eig_release(c);
   dc_release(c);
+  trd_release(c);
   for (auto &kv : c->prof)
     for (auto &ev : kv.second.pending) {
       (void)hipEventDestroy(ev.first);

@@ -26,6 +26,8 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
 
 void tridiag_dc_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, double *const *e, double *const *Z);
 int dc_status(hfg_ctx *ctx);
+void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
+                          double *const *tau);
 
 constexpr int MAXB = 8;
 struct EigBatch {
@@ -476,16 +478,29 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
   hipStream_t s = ctx->stream;
   {
     ProfScope ps(ctx, "eig_tridiag");
-    size_t shb = (size_t)(nmax + 4 * 64 + 8) * sizeof(double);
-    if (shb > 64 * 1024)
-      HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_trd_gemv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-    for (int k = 0; k <= nmax - 3; k++) {
-      int m = nmax - k - 1;
-      int nrs = (m + 63) / 64;
-      hipLaunchKernelGGL(k_trd_gemv, dim3(nrs * TRD_NCS, nblk), dim3(256), shb, s, b, k);
-      hipLaunchKernelGGL(k_trd_update, dim3(nrs * nrs, nblk), dim3(256), 0, s, b, k);
+    static const bool unblocked = (getenv("HELFEM_TRD") && !strcmp(getenv("HELFEM_TRD"), "unblocked"));
+    if (unblocked) {
+      // first-generation path (rank-2 update of the whole trailing matrix at every column), kept for A/B runs
+      size_t shb = (size_t)(nmax + 4 * 64 + 8) * sizeof(double);
+      if (shb > 64 * 1024)
+        HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_trd_gemv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+      for (int k = 0; k <= nmax - 3; k++) {
+        int m = nmax - k - 1;
+        int nrs = (m + 63) / 64;
+        hipLaunchKernelGGL(k_trd_gemv, dim3(nrs * TRD_NCS, nblk), dim3(256), shb, s, b, k);
+        hipLaunchKernelGGL(k_trd_update, dim3(nrs * nrs, nblk), dim3(256), 0, s, b, k);
+      }
+      hipLaunchKernelGGL(k_trd_finish, dim3(nblk), dim3(64), 0, s, b);
+    } else {
+      double *Ap[MAXB], *dp[MAXB], *ep[MAXB], *tp[MAXB];
+      for (int i = 0; i < nblk; i++) {
+        Ap[i] = w.A[i].p;
+        dp[i] = w.d[i].p;
+        ep[i] = w.e[i].p;
+        tp[i] = w.tau[i].p;
+      }
+      tridiagonalize_batch(ctx, nblk, ns, Ap, dp, ep, tp);
     }
-    hipLaunchKernelGGL(k_trd_finish, dim3(nblk), dim3(64), 0, s, b);
   }
   {
     ProfScope ps(ctx, "eig_tridiag_solve");
