@@ -38,13 +38,16 @@ Mat enforce_fock_symmetry(const Mat &F, const std::vector<std::vector<size_t> > 
 
 // ---- diatomic Fock build ----
 /// TwoDBasis::coulomb       src/diatomic/basis.cpp:1359-1530
-Mat coulomb(const helfem::diatomic::TwoDBasis &b, const Mat &P0);
+/// shard_n > 1: only the (L,|M|) channels with ilm % shard_n == shard_rank contribute (the multi-GPU shard of J)
+Mat coulomb(const helfem::diatomic::TwoDBasis &b, const Mat &P0, int shard_rank = 0, int shard_n = 1);
 /// TwoDBasis::exchange      src/diatomic/basis.cpp:1532-1733
 Mat exchange(const helfem::diatomic::TwoDBasis &b, const Mat &P0);
 /// DFTGrid::eval_Fxc (restricted)  src/diatomic/dftgrid.cpp:769-810; radial points
-/// [q_begin,q_end) of the E*nq list only (q_end<0: all) so that the bench can time a bounded sample
+/// [q_begin,q_end) of the E*nq list only (q_end<0: all) so that the bench can time a bounded sample; shard_n > 1:
+/// only the radial points with q % shard_n == shard_rank (the multi-GPU shard of the XC quadrature)
 void eval_Fxc(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P,
-              Mat &H, double &Exc, double &Nel, double &Ekin, double thr, long q_begin = 0, long q_end = -1);
+              Mat &H, double &Exc, double &Nel, double &Ekin, double thr, long q_begin = 0, long q_end = -1,
+              int shard_rank = 0, int shard_n = 1);
 /// DFTGrid::eval_overlap / eval_kinetic  src/diatomic/dftgrid.cpp:858-896
 Mat grid_overlap(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
 Mat grid_kinetic(const helfem::diatomic::TwoDBasis &b, int lang, int mang);

@@ -103,6 +103,24 @@ int orc_exchange(void *h, const double *P, double *K) {
   memcpy(K, Km.memptr(), sizeof(double) * N * N);
   ORC_CATCH
 }
+int orc_coulomb_shard(void *h, const double *P, double *J, int shard_rank, int shard_n) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  Mat Jm = coulomb(*b, to_mat(P, N, N), shard_rank, shard_n);
+  memcpy(J, Jm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_eval_fxc_shard(void *h, int lang, int mang, int x_func, int c_func, const double *P, double *H, double *Exc,
+                       double *Nel, double *Ekin, double thr, int shard_rank, int shard_n) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  Mat Hm;
+  eval_Fxc(*b, lang, mang, x_func, c_func, to_mat(P, N, N), Hm, *Exc, *Nel, *Ekin, thr, 0, -1, shard_rank, shard_n);
+  memcpy(H, Hm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
 int orc_eval_fxc(void *h, int lang, int mang, int x_func, int c_func, const double *P, double *H, double *Exc,
                  double *Nel, double *Ekin, double thr, long q_begin, long q_end) {
   ORC_TRY

@@ -33,7 +33,7 @@ static Vec matvec(const Mat &A, const Vec &x) {
   return y;
 }
 
-Mat coulomb(const TwoDBasis &b, const Mat &P0) {
+Mat coulomb(const TwoDBasis &b, const Mat &P0, int shard_rank, int shard_n) {
   if (!b.have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
   Mat P(b.expand_boundaries(P0));
   const size_t Nel = b.Nel(), Nrad = b.Nrad(), NLM = b.LM_map.size();
@@ -62,6 +62,7 @@ Mat coulomb(const TwoDBasis &b, const Mat &P0) {
   for (size_t iLM = 0; iLM < NLM; iLM++) {
     int L = b.LM_map[iLM].first, M = b.LM_map[iLM].second;
     const size_t ilm = b.lmind(L, M);
+    if ((int)(ilm % shard_n) != shard_rank) continue;  // channel owned by another rank: contributes nothing here
     const double LMfac = b.LMfac(L, M);
     for (size_t jel = 0; jel < Nel; jel++) {
       size_t jfirst, jlast;
@@ -385,7 +386,7 @@ struct GridWorker {
 }  // namespace
 
 void eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P0, Mat &Hout, double &Exc,
-              double &Nel, double &Ekin, double thr, long q_begin, long q_end) {
+              double &Nel, double &Ekin, double thr, long q_begin, long q_end, int shard_rank, int shard_n) {
   Mat H(b.Ndummy(), b.Ndummy());
   Mat P(b.expand_boundaries(P0));
   double exc = 0.0, nel = 0.0;
@@ -395,6 +396,7 @@ void eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, co
   for (size_t iel = 0; iel < b.Nel(); iel++)
     for (size_t irad = 0; irad < (size_t)b.nquad(); irad++, q++) {
       if (q < q_begin || (q_end >= 0 && q >= q_end)) continue;
+      if ((int)(q % shard_n) != shard_rank) continue;
       grid.compute_bf(iel, irad);
       grid.update_density(P);
       for (size_t ip = 0; ip < grid.Ng; ip++) nel += grid.wtot[ip] * grid.rho[ip];

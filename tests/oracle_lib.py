@@ -26,6 +26,9 @@ def lib():
         L.orc_eval_fxc.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
                                    c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double, ctypes.c_long,
                                    ctypes.c_long]
+        L.orc_eval_fxc_shard.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double,
+                                         ctypes.c_int, ctypes.c_int]
         L.orc_xc_unpolarized.argtypes = [ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
                                          c_double_p, ctypes.c_double]
         L.orc_scf_diatomic.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int),
@@ -88,6 +91,20 @@ class OracleBasis(object):
         J = np.zeros_like(P, order="F")
         _check(lib().orc_coulomb(self.h, _p(P), _p(J)))
         return J
+
+    def coulomb_shard(self, P, rank, nranks):
+        P = _f(P)
+        J = np.zeros_like(P, order="F")
+        _check(lib().orc_coulomb_shard(self.h, _p(P), _p(J), int(rank), int(nranks)))
+        return J
+
+    def eval_Fxc_shard(self, lang, mang, x_func, c_func, P, rank, nranks, thr=1e-12):
+        P = _f(P)
+        H = np.zeros_like(P, order="F")
+        exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(lib().orc_eval_fxc_shard(self.h, lang, mang, x_func, c_func, _p(P), _p(H), ctypes.byref(exc),
+                                        ctypes.byref(nel), ctypes.byref(ekin), thr, int(rank), int(nranks)))
+        return H, exc.value, nel.value, ekin.value
 
     def exchange(self, P):
         P = _f(P)

@@ -52,11 +52,69 @@ def test_legendre_PQ_vs_reference_fortran(hf):
     for c in data["cases"]:
         P, Q = hf.legendre_PQ(Lmax, Mmax, c["xi"])
         Pr, Qr = np.array(c["P"]), np.array(c["Q"])
+        # P_L^M: both sides are upward recurrences, agreement to rounding.  Q_L^M: the reference library's
+        # continued fraction loses accuracy towards xi -> 1 (measured against 40-digit mpmath: 1.5e-6 at mu=1e-3,
+        # 3e-9 at mu=0.05, <1e-12 from mu=0.3 on, even with --lpad 10); the implementation here is accurate to
+        # 1e-16 (test_legendre_PQ_vs_mpmath), so the comparison tolerance follows the REFERENCE's error.
+        qtol = 5e-6 if c["mu"] < 0.01 else (1e-8 if c["mu"] < 0.1 else 5e-12)
+        # P_L^M (M>0) of the reference carries the cancellation of xi*xi-1 near xi=1 (2e-11 at mu=1e-3)
+        ptol = 1e-10 if c["mu"] < 0.01 else (1e-12 if c["mu"] < 0.1 else 1e-13)
         for L in range(Lmax + 1):
             for M in range(min(L, Mmax) + 1):
-                assert abs(P[L, M] - Pr[L, M]) <= 1e-13 * abs(Pr[L, M]), ("P", c["mu"], L, M)
-                # the reference's continued fraction for Q is converged to ~1e-10 (Special_Functions.f90:80)
-                assert abs(Q[L, M] - Qr[L, M]) <= 2e-9 * abs(Qr[L, M]), ("Q", c["mu"], L, M, Q[L, M], Qr[L, M])
+                assert abs(P[L, M] - Pr[L, M]) <= ptol * abs(Pr[L, M]), ("P", c["mu"], L, M)
+                assert abs(Q[L, M] - Qr[L, M]) <= qtol * abs(Qr[L, M]), ("Q", c["mu"], L, M, Q[L, M], Qr[L, M])
+
+
+def test_reference_legendre_library_does_not_move_energies():
+    """Runs the oracle SCF twice: with the product's P/Q implementation and with the reference's own Fortran
+    library (oracle/_ref, only present in the build container) plugged into compute_tei exactly as
+    LegendreTable::compute does (legendretable.cpp:60-97).  The converged energies must agree far below the
+    1e-8 Eh parity bar, i.e. the reference library's limited Q accuracy is immaterial."""
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libref_legendre.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref not built (reference sources absent on this machine)")
+    import ctypes
+    import oracle_lib as orc
+    ref = ctypes.CDLL(ref_path)
+    dp = ctypes.POINTER(ctypes.c_double)
+    for f in (ref.calc_Plm_arr, ref.calc_Qlm_arr):
+        f.argtypes = [dp, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, dp)
+    tiny = np.finfo(float).tiny
+    cwd = os.getcwd()
+
+    def provider(Lmax, Mmax, lpad, xi, P, Q):
+        Lp = Lmax + lpad
+        if xi == 1.0:
+            for i in range((Lmax + 1) * (Mmax + 1)):
+                P[i] = 0.0
+                Q[i] = 0.0
+            return
+        a = np.zeros((Lp + 1, Lp + 1))
+        b = np.zeros((Lp + 1, Lp + 1))
+        ref.calc_Plm_arr(a.ctypes.data_as(dp), Lp, Lp, xi)
+        ref.calc_Qlm_arr(b.ctypes.data_as(dp), Lp, Lp, xi)
+        for M in range(Mmax + 1):
+            for L in range(Lmax + 1):
+                pv, qv = a[M, L], b[M, L]
+                P[M * (Lmax + 1) + L] = pv if (np.isfinite(pv) and abs(pv) >= tiny) else 0.0
+                Q[M * (Lmax + 1) + L] = qv if (np.isfinite(qv) and abs(qv) >= tiny) else 0.0
+
+    cb = CB(provider)
+    L = orc.lib()
+    L.orc_set_legendre_provider.argtypes = [CB]
+    L.orc_set_legendre_provider.restype = None
+    kw = dict(Z1=1, Z2=1, Rbond=1.4, lmmax=[3], nelem=2, nnodes=6, method="HF", convthr=1e-9)
+    own = orc.scf_diatomic(**kw)
+    try:
+        os.chdir("/tmp")  # the Fortran library writes fort.9 into the cwd
+        L.orc_set_legendre_provider(cb)
+        viaref = orc.scf_diatomic(**kw)
+    finally:
+        L.orc_set_legendre_provider(ctypes.cast(None, CB))
+        os.chdir(cwd)
+    assert own["converged"] and viaref["converged"]
+    assert abs(own["Etot"] - viaref["Etot"]) < 1e-10, (own["Etot"], viaref["Etot"])
 
 
 def test_legendre_PQ_vs_mpmath(hf):
@@ -122,8 +180,8 @@ def test_quadrature_rules(hf):
     for n in (5, 20, 75):
         x, w = hf.chebyshev(n)
         assert np.all(np.diff(x) > 0) and abs(w.sum() - 2.0) < 1e-12
-        # the modified Gauss-Chebyshev rule is not Gaussian: moderate polynomial exactness only
-        assert abs((w * x ** 2).sum() - 2.0 / 3.0) < 1e-3 / n
+        # the modified Gauss-Chebyshev rule is not Gaussian: it converges geometrically with n instead
+        assert abs((w * x ** 2).sum() - 2.0 / 3.0) < {5: 1e-3, 20: 1e-9, 75: 1e-14}[n]
     # Gauss-Lobatto nodes: a few tabulated 30-digit values of lobatto.cpp (orders 4 and 5)
     x4 = hf.lobatto_nodes(4)
     assert np.allclose(x4, [-1, -0.447213595499957939281834733746, 0.447213595499957939281834733746, 1], atol=1e-16)
@@ -145,7 +203,9 @@ def test_grid_overlap_and_kinetic_identity(hf):
     import common
     gb, ob = common.make_bases(1, 1, 1.4, (3, 2), 2, 6)
     S, T = gb.overlap(), gb.kinetic()
-    ldft, mdft = 4 * 3 + 12, 4 * 2 + 5
+    # the cos(theta) rule converges geometrically (1.7e-9 at 24 points, 1e-11 at 40, 2e-13 at 60 for this basis);
+    # the reference's default 4*lmax+12 is sized for lmax ~ 20, so the identity is checked at 40 points here
+    ldft, mdft = 40, 4 * 2 + 5
     Sg, Tg = ob.grid_overlap(ldft, mdft), ob.grid_kinetic(ldft, mdft)
     nrm = 1.0 / np.sqrt(np.diag(S))
     assert np.linalg.norm((Sg - S) * np.outer(nrm, nrm)) < 1e-10

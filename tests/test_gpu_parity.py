@@ -231,3 +231,57 @@ def test_eig_sym_1400_dense(hf):
     assert np.max(np.abs(E - Eref)) < 1e-10
     assert np.max(np.abs(C.T @ C - np.eye(n))) < 1e-11
     assert np.max(np.abs(A @ C - C * E)) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-GPU sharding rules, exercised on one device: shards (rank r of n) must sum to the unsharded result
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_step_sums_to_unsharded(hf, nranks):
+    import common
+    import ctypes
+    import torch
+    gb, _ = common.make_bases(7, 7, 2.068, (3, 2), 2, 5, oracle=False)
+    gb.compute_tei(False)
+    ldft, mdft = 24, 13
+    N = gb.Nbf()
+    blocks = gb.get_sym_idx(1)
+    P = common.random_density(N, 2, seed=33, blocks=blocks)
+    S = gb.overlap()
+    H0 = gb.kinetic() + gb.nuclear()
+    full = hf.DeviceSCFStep(gb, 101, 130, ldft, mdft, 3, symmetry=1, device=0, rank=0, nranks=1)
+    X = hf.scf.form_Sinvh(S, False, blocks, ctx=full.ctx)
+    full.set_matrices(H0, X)
+    full.set_density(P)
+    full.step(None)
+    torch.cuda.synchronize()
+    Fc_ref = full.Fc.clone()
+    scal_ref = full.scal.clone()
+    E_ref, C_ref, P_ref = full.E.clone(), full.C.clone(), full.P.clone()
+    Fc_sum = torch.zeros_like(Fc_ref)
+    scal_sum = torch.zeros_like(scal_ref)
+    bb_sum = torch.zeros_like(full.blockbuf)
+    for r in range(nranks):
+        full.ctx.set_shard(r, nranks)
+        full.set_density(P)
+        full.fock_partial()
+        torch.cuda.synchronize()
+        Fc_sum += full.Fc
+        scal_sum += full.scal
+    assert float((Fc_sum - Fc_ref).abs().max()) < 1e-11 * float(Fc_ref.abs().max())
+    assert float((scal_sum - scal_ref).abs().max()) < 1e-11 * float(scal_ref.abs().max())
+    # eigensolve: each rank's owned blocks, summed buffer, then assemble
+    full.Fc.copy_(Fc_sum)
+    full.fock_finish()
+    for r in range(nranks):
+        full.ctx.set_shard(r, nranks)
+        full.eig_partial()
+        torch.cuda.synchronize()
+        bb_sum += full.blockbuf
+    full.blockbuf.copy_(bb_sum)
+    full.ctx.set_shard(0, 1)
+    full.eig_finish()
+    full.density()
+    torch.cuda.synchronize()
+    assert float((full.E - E_ref).abs().max()) < 1e-10 * max(1.0, float(E_ref.abs().max()))
+    assert float((full.P - P_ref).abs().max()) < 1e-9 * max(1.0, float(P_ref.abs().max()))
