@@ -44,6 +44,15 @@ def lib():
         if not os.path.exists(_LIB_PATH):
             raise RuntimeError("%s is missing: run `python -m helfem_amd.build` (or __graft_entry__.build()) first; "
                                "there is no Python/CPU fallback for the hot path" % _LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime.  If this library
+        # (linked against /opt/rocm) is loaded first and torch afterwards, torch reports "No HIP GPUs are
+        # available"; loading torch first makes both resolve to the same runtime (same SONAME).  torch is only
+        # plumbing here (HBM buffers, streams, torch.distributed), so import it first when it is installed.
+        if os.environ.get("HELFEM_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = ctypes.CDLL(_LIB_PATH)
         L.hfg_last_error.restype = ctypes.c_char_p
         L.hfg_version.restype = ctypes.c_char_p
@@ -66,6 +75,7 @@ def lib():
         L.hfg_xc_fock_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
         L.hfg_profile_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, c_double_p, c_i64_p]
+        L.hfg_measure_kernel.argtypes = [ctypes.c_void_p, ctypes.c_char_p, c_double_p, c_i64_p]
         _lib = L
     return _lib
 
@@ -118,6 +128,12 @@ class Context(object):
 
     def profile_reset(self):
         _check(lib().hfg_profile_reset(self.h))
+
+    def measure_kernel(self, name):
+        ms = ctypes.c_double()
+        n = ctypes.c_int64()
+        _check(lib().hfg_measure_kernel(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def profile_get(self, name):
         ms = ctypes.c_double()

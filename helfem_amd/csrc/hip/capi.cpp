@@ -24,6 +24,7 @@ void exchange_release(hfg_dev_tables *t);
 void eig_release(hfg_ctx *ctx);
 void dc_release(hfg_ctx *ctx);
 void trd_release(hfg_ctx *ctx);
+void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
@@ -492,6 +493,13 @@ int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launche
     *ms = it->second.ms;
     *launches = it->second.launches;
   }
+  HFG_CATCH
+}
+
+int hfg_measure_kernel(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches) {
+  HFG_TRY
+  if (std::string(name) == "k_trdb_gemv") trd_measure_gemv(ctx, ms, launches);
+  else throw std::logic_error("hfg_measure_kernel: unknown kernel");
   HFG_CATCH
 }
 

@@ -379,6 +379,7 @@ __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
 struct TrdWork {
   DevBuf<double> V[TB_MAXB], W[TB_MAXB], col[TB_MAXB], normp[TB_MAXB], pp[TB_MAXB], dots[TB_MAXB], cpart[TB_MAXB];
   DevBuf<TrdBatch> desc;
+  std::vector<int> last_ns;  // sizes of the last batch (for the measurement replay)
 };
 static std::map<hfg_ctx *, TrdWork *> g_trd;
 void trd_release(hfg_ctx *ctx) {
@@ -447,11 +448,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
       const int nrs = (m + 63) / 64, nrg = (m + 1 + 127) / 128;
       // 64-column slabs (16 columns per wave, all issued before the prologue); at most 64 slabs
       int ncs = std::max(1, std::min(64, (m + 63) / 64));
-      {
-        // per-launch HIP events on the dominant kernel (bench.py's roofline leg); off unless profiling is enabled
-        ProfScope pk(ctx, "k_trdb_gemv");
-        hipLaunchKernelGGL(k_trdb_gemv, dim3(nrg * ncs, nblk), dim3(256), shb, s, db, i, c, ncs);
-      }
+      hipLaunchKernelGGL(k_trdb_gemv, dim3(nrg * ncs, nblk), dim3(256), shb, s, db, i, c, ncs);
       hipLaunchKernelGGL(k_trdb_w, dim3(nrs, nblk), dim3(256), 0, s, db, i, c, (i + 1 < jend) ? 1 : 0, ncs);
     }
     // trailing update per block: columns processed in this panel for block k: j0 .. min(j0+NB, n_k-2)-1
@@ -469,6 +466,45 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
   }
   hipLaunchKernelGGL(k_trdb_finish, dim3(nblk), dim3(64), 0, s, db);
   HFG_HIP_CHECK(hipGetLastError());
+  w.last_ns.assign(ns, ns + nblk);
+}
+
+/// Measurement replay of the dominant kernel: the k_trdb_gemv launch of every Householder column of the last
+/// batch, back to back on the context's stream between two HIP events (the companion k_trdb_w launches are left
+/// out, the sweep's duration does not depend on the matrix values).  Returns total ms and the launch count.
+void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
+  *ms = 0.0;
+  *launches = 0;
+  auto it = g_trd.find(ctx);
+  if (it == g_trd.end() || it->second->last_ns.empty()) throw std::logic_error("no tridiagonalisation has run on this context");
+  TrdWork &w = *it->second;
+  const int nblk = (int)w.last_ns.size();
+  int nmax = 0;
+  for (int n : w.last_ns) nmax = std::max(nmax, n);
+  hipStream_t s = ctx->stream;
+  const TrdBatch *db = w.desc.p;
+  size_t shb = (size_t)(nmax + 4 * 128 + 8) * sizeof(double);
+  hipEvent_t e0, e1;
+  HFG_HIP_CHECK(hipEventCreate(&e0));
+  HFG_HIP_CHECK(hipEventCreate(&e1));
+  HFG_HIP_CHECK(hipEventRecord(e0, s));
+  int count = 0;
+  for (int i = 0; i <= nmax - 3; i++) {
+    const int c = i % TB_NB;
+    const int m = nmax - i - 1;
+    const int nrg = (m + 1 + 127) / 128;
+    int ncs = std::max(1, std::min(64, (m + 63) / 64));
+    hipLaunchKernelGGL(k_trdb_gemv, dim3(nrg * ncs, nblk), dim3(256), shb, s, db, i, c, ncs);
+    count++;
+  }
+  HFG_HIP_CHECK(hipEventRecord(e1, s));
+  HFG_HIP_CHECK(hipEventSynchronize(e1));
+  float t = 0.f;
+  HFG_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms = t;
+  *launches = count;
 }
 
 }  // namespace hfg

@@ -1,0 +1,68 @@
+// Spherical-coordinate two-dimensional basis (B_n(r)/r) Y_l^m and the tables of the atomic Fock build.
+// Host-side (setup) counterpart of helfem::atomic::basis::TwoDBasis (/root/reference/src/atomic/TwoDBasis.cpp:38
+// ctor, :202 get_sym_idx, :304-420 one-electron matrices, :666-739 compute_tei) and of
+// helfem::atomic::basis::RadialBasis (libhelfem/src/RadialBasis.cpp:190 radial_integral, :484 twoe_integral,
+// :649/:676 get_bf/get_df) with libhelfem/src/quadrature.cpp:22-130 (in-element two-electron integrals).
+//
+// Point nucleus at the origin only (finite nuclei, off-centre charges, confinement, range separation are
+// outside this round's scope and rejected by the driver).
+//
+// B(r)/r near the origin: the reference switches to a Taylor series of order nprim-1 below a numerically
+// chosen cutoff (RadialBasis.cpp:59-133, 575-631).  For LIPs whose first function is dropped, B_i(r)/r is a
+// polynomial and that series is exact; here it is evaluated directly as the Lagrange product with the
+// (x - x_0) factor removed, which is the same polynomial without the cancellation the series avoids.
+#pragma once
+#include "fem.h"
+#include "special.h"
+
+namespace helfem {
+namespace atomic {
+
+/// atomic::basis::angular_basis (src/atomic/basis.cpp:174): |m|=0..mmax, l=|m|..lmax, (l,+|m|),(l,-|m|)
+void angular_basis(int lmax, int mmax, IVec &lval, IVec &mval);
+
+struct TwoDBasis {
+  int Z = 0;
+  int nnodes = 0;
+  FEMBasis fem;
+  Vec xq, wq;
+  IVec lval, mval;
+  Gaunt gaunt;
+
+  std::vector<Mat> disjoint_L, disjoint_m1L;  // [L*Nel+iel]
+  std::vector<Mat> prim_tei, prim_ktei;      // [L*Nel+iel]
+  bool have_tei = false, have_ktei = false;
+
+  TwoDBasis() {}
+  TwoDBasis(int Z, int nnodes, int n_quad, const Vec &bval, const IVec &lval, const IVec &mval);
+
+  size_t Nel() const { return fem.nelem(); }
+  size_t Nrad() const { return fem.nbf(); }
+  size_t Nang() const { return lval.size(); }
+  size_t Nbf() const { return Nang() * Nrad(); }
+  size_t Ndummy() const { return Nbf(); }
+  size_t max_Nprim() const { return fem.max_nprim(); }
+  int nquad() const { return (int)xq.size(); }
+  int N_L() const;  // 2*max(l)+1
+  int Mmax() const;  // max(m)-min(m)
+
+  std::vector<size_t> m_indices(int m) const;
+  std::vector<size_t> lm_indices(int l, int m) const;
+  std::vector<std::vector<size_t> > get_sym_idx(int symm) const;
+
+  /// B_n(r)/r and d/dr (B_n(r)/r) at the quadrature points of element iel (nq x Nprim(iel))
+  Mat get_bf(size_t iel) const;
+  Mat get_df(size_t iel) const;
+  Vec get_wrad(size_t iel) const;
+  Vec get_r(size_t iel) const { return fem.eval_coord(xq, iel); }
+  /// \int (B_i/r)(B_j/r) r^{Rexp+2} dr over element iel   (RadialBasis::radial_integral)
+  Mat radial_integral(int Rexp, size_t iel) const;
+
+  Mat overlap() const;
+  Mat kinetic() const;
+  Mat nuclear() const;
+  void compute_tei(bool exchange);
+};
+
+}  // namespace atomic
+}  // namespace helfem

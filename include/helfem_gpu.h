@@ -171,6 +171,10 @@ int hfg_profile_enable(hfg_ctx *ctx, int on);
 int hfg_profile_reset(hfg_ctx *ctx);
 int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches);
 
+/* Replays every launch of the named kernel of the last eigensolve back to back between two HIP events on the
+ * context's stream (the roofline leg of bench.py).  Supported: "k_trdb_gemv". */
+int hfg_measure_kernel(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches);
+
 /* pinned host memory for arma-owned buffers ("Armadillo matrices pinned and mirrored to HBM") */
 int hfg_pin(void *host_ptr, size_t bytes);
 int hfg_unpin(void *host_ptr);

@@ -13,6 +13,7 @@
 // libxc arithmetic (functional values) is restated from the published formulas: PARITY UNPINNED
 // for PBE/VWN beyond those literature energies.
 #pragma once
+#include "../helfem_amd/csrc/host/atomic_basis.h"
 #include "../helfem_amd/csrc/host/diatomic_basis.h"
 #include "../helfem_amd/csrc/host/linalg.h"
 
@@ -51,6 +52,15 @@ void eval_Fxc(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_fu
 /// DFTGrid::eval_overlap / eval_kinetic  src/diatomic/dftgrid.cpp:858-896
 Mat grid_overlap(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
 Mat grid_kinetic(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
+
+// ---- atomic Fock build ----
+/// atomic::basis::TwoDBasis::coulomb   src/atomic/TwoDBasis.cpp:817-955
+Mat atomic_coulomb(const helfem::atomic::TwoDBasis &b, const Mat &P);
+/// atomic::basis::TwoDBasis::exchange  src/atomic/TwoDBasis.cpp:957-1140
+Mat atomic_exchange(const helfem::atomic::TwoDBasis &b, const Mat &P);
+/// atomic::dftgrid::DFTGrid::eval_Fxc (restricted)  src/atomic/dftgrid.cpp:810-870
+void atomic_eval_Fxc(const helfem::atomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P, Mat &H,
+                     double &Exc, double &Nel, double &Ekin, double thr);
 
 // ---- exchange-correlation functionals, spin-unpolarised, libxc conventions ----
 // ids follow libxc: 1 = lda_x, 7 = lda_c_vwn (VWN5), 12 = lda_c_pw, 101 = gga_x_pbe, 130 = gga_c_pbe

@@ -1,0 +1,285 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).
+//
+// Loop-for-loop CPU restatement of the atomic Fock build of the reference:
+//   atomic::basis::TwoDBasis::coulomb   src/atomic/TwoDBasis.cpp:817-955
+//   atomic::basis::TwoDBasis::exchange  src/atomic/TwoDBasis.cpp:957-1140
+//   atomic::dftgrid::DFTGridWorker / DFTGrid::eval_Fxc  src/atomic/dftgrid.cpp:710-790 (compute_bf), :810-870,
+//       with the same update_density / compute_xc / eval_Fxc algebra as the diatomic worker
+//       (w = w_ang w_rad r^2, h_r = 1, h_theta = r, h_phi = r sin(theta);  atomic/dftgrid.cpp:724-743).
+// The reference processes a whole radial element per compute_bf call; the sums are the same, here they are
+// accumulated one radial point at a time (the dense complex formulation is kept).
+#include "oracle.h"
+#include "../helfem_amd/csrc/host/atomic_basis.h"
+#include <cfloat>
+#include <cmath>
+#include <complex>
+
+namespace oracle {
+using helfem::atomic::TwoDBasis;
+typedef std::complex<double> cplx;
+
+static Mat submat(const Mat &M, size_t r0, size_t c0, size_t nr, size_t nc) {
+  Mat S(nr, nc);
+  for (size_t j = 0; j < nc; j++)
+    for (size_t i = 0; i < nr; i++) S(i, j) = M(r0 + i, c0 + j);
+  return S;
+}
+static void add_submat(Mat &M, size_t r0, size_t c0, const Mat &S, double f) {
+  for (size_t j = 0; j < S.n_cols; j++)
+    for (size_t i = 0; i < S.n_rows; i++) M(r0 + i, c0 + j) += f * S(i, j);
+}
+static Vec matvec(const Mat &A, const Vec &x) {
+  Vec y(A.n_rows, 0.0);
+  for (size_t j = 0; j < A.n_cols; j++)
+    for (size_t i = 0; i < A.n_rows; i++) y[i] += A(i, j) * x[j];
+  return y;
+}
+
+Mat atomic_coulomb(const TwoDBasis &b, const Mat &P) {
+  if (!b.have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
+  const size_t Nel = b.Nel(), Nrad = b.Nrad();
+  const helfem::IVec &lval = b.lval, &mval = b.mval;
+  const int NL = b.N_L(), Mmax = b.Mmax();
+  auto idx = [&](int L, int M) { return (size_t)L * (2 * Mmax + 1) + (M + Mmax); };
+  std::vector<Mat> Paux((size_t)NL * (2 * Mmax + 1), Mat(Nrad, Nrad)), Jaux((size_t)NL * (2 * Mmax + 1), Mat(Nrad, Nrad));
+  // contract ket (:852-873)
+  for (size_t kang = 0; kang < lval.size(); kang++)
+    for (size_t lang = 0; lang < lval.size(); lang++) {
+      int lk = lval[kang], mk = mval[kang], ll = lval[lang], ml = mval[lang];
+      int M = mk - ml;
+      int Lmin = std::max(std::abs(lk - ll), std::abs(M)), Lmax = lk + ll;
+      for (int L = Lmin; L <= Lmax; L++) {
+        double cpl = b.gaunt.coeff(lk, mk, L, M, ll, ml);
+        add_submat(Paux[idx(L, M)], 0, 0, submat(P, kang * Nrad, lang * Nrad, Nrad, Nrad), cpl);
+      }
+    }
+  // contract integrals (:884-936)
+  for (int L = 0; L < NL; L++) {
+    const double Lfac = 4.0 * M_PI / (2 * L + 1);
+    for (int M = -std::min(L, Mmax); M <= std::min(L, Mmax); M++)
+      for (size_t jel = 0; jel < Nel; jel++) {
+        size_t jfirst, jlast;
+        b.fem.get_idx(jel, jfirst, jlast);
+        size_t Nj = jlast - jfirst + 1;
+        Mat Psub = submat(Paux[idx(L, M)], jfirst, jfirst, Nj, Nj);
+        double jsmall = Lfac * helfem::trace_prod(b.disjoint_L[L * Nel + jel], Psub);
+        double jbig = Lfac * helfem::trace_prod(b.disjoint_m1L[L * Nel + jel], Psub);
+        for (size_t iel = 0; iel < jel; iel++)
+          add_submat(Jaux[idx(L, M)], b.fem.first[iel], b.fem.first[iel], b.disjoint_L[L * Nel + iel], jbig);
+        for (size_t iel = jel + 1; iel < Nel; iel++)
+          add_submat(Jaux[idx(L, M)], b.fem.first[iel], b.fem.first[iel], b.disjoint_m1L[L * Nel + iel], jsmall);
+        Vec y = matvec(b.prim_tei[L * Nel + jel], Psub.d);
+        Mat Jsub(Nj, Nj);
+        for (size_t k = 0; k < y.size(); k++) Jsub.d[k] = Lfac * y[k];
+        add_submat(Jaux[idx(L, M)], jfirst, jfirst, Jsub, 1.0);
+      }
+  }
+  // full Coulomb matrix (:938-954)
+  Mat J(b.Nbf(), b.Nbf());
+  for (size_t iang = 0; iang < lval.size(); iang++)
+    for (size_t jang = 0; jang < lval.size(); jang++) {
+      int li = lval[iang], mi = mval[iang], lj = lval[jang], mj = mval[jang];
+      int M = mj - mi;
+      int Lmin = std::max(std::abs(lj - li), std::abs(M)), Lmax = lj + li;
+      for (int L = Lmin; L <= Lmax; L++) {
+        double cpl = b.gaunt.coeff(lj, mj, L, M, li, mi);
+        if (cpl != 0.0) add_submat(J, iang * Nrad, jang * Nrad, Jaux[idx(L, M)], cpl);
+      }
+    }
+  return J;
+}
+
+Mat atomic_exchange(const TwoDBasis &b, const Mat &P) {
+  if (!b.have_ktei) throw std::logic_error("Primitive teis have not been computed!\n");
+  const size_t Nel = b.Nel(), Nrad = b.Nrad();
+  const helfem::IVec &lval = b.lval, &mval = b.mval;
+  const size_t NL = b.N_L();
+  Mat K(b.Nbf(), b.Nbf());
+  for (size_t jang = 0; jang < lval.size(); jang++)
+    for (size_t kang = 0; kang < lval.size(); kang++) {
+      int lj = lval[jang], mj = mval[jang], lk = lval[kang], mk = mval[kang];
+      std::vector<Mat> Rmat(NL, Mat(Nrad, Nrad));
+      std::vector<bool> couple(NL, false);
+      for (size_t iang = 0; iang < lval.size(); iang++) {
+        int li = lval[iang], mi = mval[iang];
+        for (size_t lang = 0; lang < lval.size(); lang++) {
+          int ll = lval[lang], ml = mval[lang];
+          int M = mj - mi, Mp = mk - ml;
+          if (M != Mp) continue;
+          Mat Psub = submat(P, iang * Nrad, lang * Nrad, Nrad, Nrad);
+          double bdens = 0.0;
+          for (double v : Psub.d) bdens += v * v;
+          if (sqrt(bdens) < 10 * DBL_EPSILON) continue;
+          int Lmin = std::max(std::max(std::abs(li - lj), std::abs(lk - ll)), std::abs(M));
+          int Lmax = std::min(li + lj, lk + ll);
+          for (int L = Lmin; L <= Lmax; L++) {
+            double cpl = b.gaunt.coeff(lj, mj, L, M, li, mi) * b.gaunt.coeff(lk, mk, L, M, ll, ml);
+            if (cpl == 0.0) continue;
+            double Lfac = 4.0 * M_PI / (2 * L + 1);
+            add_submat(Rmat[L], 0, 0, Psub, Lfac * cpl);
+            couple[L] = true;
+          }
+        }
+      }
+      for (size_t iel = 0; iel < Nel; iel++) {
+        size_t ifirst, ilast;
+        b.fem.get_idx(iel, ifirst, ilast);
+        for (size_t jel = 0; jel < Nel; jel++) {
+          size_t jfirst, jlast;
+          b.fem.get_idx(jel, jfirst, jlast);
+          size_t Ni = ilast - ifirst + 1, Nj = jlast - jfirst + 1;
+          if (iel == jel) {
+            Vec Ksub(Ni * Nj, 0.0);
+            for (size_t L = 0; L < NL; L++) {
+              if (!couple[L]) continue;
+              Vec y = matvec(b.prim_ktei[L * Nel + iel], submat(Rmat[L], ifirst, jfirst, Ni, Nj).d);
+              for (size_t k = 0; k < Ksub.size(); k++) Ksub[k] += y[k];
+            }
+            for (size_t jj = 0; jj < Nj; jj++)
+              for (size_t ii = 0; ii < Ni; ii++)
+                K(jang * Nrad + ifirst + ii, kang * Nrad + jfirst + jj) -= Ksub[jj * Ni + ii];
+          } else {
+            Mat Ksub(Ni, Nj);
+            for (size_t L = 0; L < NL; L++) {
+              if (!couple[L]) continue;
+              const Mat &iint = (iel > jel) ? b.disjoint_m1L[L * Nel + iel] : b.disjoint_L[L * Nel + iel];
+              const Mat &jint = (iel > jel) ? b.disjoint_L[L * Nel + jel] : b.disjoint_m1L[L * Nel + jel];
+              Mat T = helfem::matmul(submat(Rmat[L], ifirst, jfirst, Ni, Nj), false, jint, true);
+              Ksub += helfem::matmul(iint, false, T, false);
+            }
+            add_submat(K, jang * Nrad + ifirst, kang * Nrad + jfirst, Ksub, -1.0);
+          }
+        }
+      }
+    }
+  return K;
+}
+
+// ---- XC quadrature --------------------------------------------------------------------------------------
+void atomic_eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P, Mat &H, double &Exc,
+                     double &Nel, double &Ekin, double thr) {
+  helfem::Vec cth, phi, wang;
+  helfem::angular_chebyshev(lang, mang, cth, phi, wang);
+  const size_t Ng = wang.size(), A = b.Nang();
+  const bool do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  H.zeros(b.Nbf(), b.Nbf());
+  double exc_tot = 0.0, nel = 0.0;
+  for (size_t iel = 0; iel < b.Nel(); iel++) {
+    size_t ifirst, ilast;
+    b.fem.get_idx(iel, ifirst, ilast);
+    const size_t Nr = ilast - ifirst + 1, ne = Nr * A;
+    std::vector<size_t> bf_ind(ne);
+    for (size_t iam = 0; iam < A; iam++)
+      for (size_t j = 0; j < Nr; j++) bf_ind[iam * Nr + j] = b.Nrad() * iam + ifirst + j;
+    Mat frad = b.get_bf(iel), drad = b.get_df(iel);
+    Vec r = b.get_r(iel), wrad = b.get_wrad(iel);
+    Mat Psub(ne, ne);
+    for (size_t j = 0; j < ne; j++)
+      for (size_t i = 0; i < ne; i++) Psub(i, j) = P(bf_ind[i], bf_ind[j]);
+    Mat Hsub(ne, ne);
+    for (size_t irad = 0; irad < r.size(); irad++) {
+      std::vector<cplx> bf(ne * Ng), bf_r, bf_t, bf_p;
+      if (do_grad) {
+        bf_r.assign(ne * Ng, cplx(0));
+        bf_t.assign(ne * Ng, cplx(0));
+        bf_p.assign(ne * Ng, cplx(0));
+      }
+      Vec wtot(Ng), s_t(Ng), s_p(Ng);
+      for (size_t ia = 0; ia < Ng; ia++) {
+        double sth = sqrt(1.0 - cth[ia] * cth[ia]);
+        wtot[ia] = wang[ia] * wrad[irad] * r[irad] * r[irad];
+        s_t[ia] = r[irad];
+        s_p[ia] = r[irad] * sth;
+        double cotth = cth[ia] / sth;
+        for (size_t i = 0; i < A; i++) {
+          int l = b.lval[i], m = b.mval[i];
+          cplx sph = helfem::spherical_harmonics(l, m, cth[ia], phi[ia]);
+          cplx angfac(0);
+          if (do_grad) {
+            angfac = m * cotth * sph;
+            if (m < l)
+              angfac += sqrt((double)((l - m) * (l + m + 1))) * std::exp(cplx(0, -phi[ia])) *
+                        helfem::spherical_harmonics(l, m + 1, cth[ia], phi[ia]);
+          }
+          for (size_t j = 0; j < Nr; j++) {
+            size_t u = i * Nr + j;
+            bf[ia * ne + u] = sph * frad(irad, j);
+            if (do_grad) {
+              bf_r[ia * ne + u] = sph * drad(irad, j);
+              bf_p[ia * ne + u] = cplx(0.0, m) * sph * frad(irad, j);
+              bf_t[ia * ne + u] = angfac * frad(irad, j);
+            }
+          }
+        }
+      }
+      // update_density
+      Vec rho(Ng, 0.0), sigma(Ng, 0.0), g0(Ng, 0.0), g1(Ng, 0.0), g2(Ng, 0.0);
+      std::vector<cplx> Pv(ne);
+      for (size_t ip = 0; ip < Ng; ip++) {
+        for (size_t i = 0; i < ne; i++) Pv[i] = 0;
+        for (size_t j = 0; j < ne; j++) {
+          cplx cb = std::conj(bf[ip * ne + j]);
+          for (size_t i = 0; i < ne; i++) Pv[i] += Psub(i, j) * cb;
+        }
+        cplx d(0), a0(0), a1(0), a2(0);
+        for (size_t i = 0; i < ne; i++) {
+          d += Pv[i] * bf[ip * ne + i];
+          if (do_grad) {
+            a0 += Pv[i] * bf_r[ip * ne + i];
+            a1 += Pv[i] * bf_t[ip * ne + i];
+            a2 += Pv[i] * bf_p[ip * ne + i];
+          }
+        }
+        rho[ip] = d.real();
+        if (do_grad) {
+          g0[ip] = 2.0 * a0.real();
+          g1[ip] = 2.0 * a1.real() / s_t[ip];
+          g2[ip] = 2.0 * a2.real() / s_p[ip];
+          sigma[ip] = g0[ip] * g0[ip] + g1[ip] * g1[ip] + g2[ip] * g2[ip];
+        }
+        nel += wtot[ip] * rho[ip];
+      }
+      Vec exc(Ng, 0.0), vxc(Ng, 0.0), vsig(Ng, 0.0), e(Ng), v(Ng), vs(Ng);
+      bool do_gga = false;
+      for (int id : {x_func, c_func}) {
+        if (id <= 0) continue;
+        do_gga = do_gga || xc_is_gga(id);
+        xc_unpolarized(id, Ng, rho.data(), do_grad ? sigma.data() : nullptr, e.data(), v.data(), vs.data(), thr);
+        for (size_t i = 0; i < Ng; i++) {
+          exc[i] += e[i];
+          vxc[i] += v[i];
+          vsig[i] += vs[i];
+        }
+      }
+      for (size_t ip = 0; ip < Ng; ip++) exc_tot += wtot[ip] * exc[ip] * rho[ip];
+      // eval_Fxc
+      for (size_t ip = 0; ip < Ng; ip++) {
+        double vr = vxc[ip] * wtot[ip];
+        for (size_t j = 0; j < ne; j++) {
+          cplx cj = std::conj(bf[ip * ne + j]) * vr;
+          for (size_t i = 0; i < ne; i++) Hsub(i, j) += (bf[ip * ne + i] * cj).real();
+        }
+      }
+      if (do_gga) {
+        std::vector<cplx> gamma(ne);
+        for (size_t ip = 0; ip < Ng; ip++) {
+          double f = 2.0 * wtot[ip] * vsig[ip];
+          double c0 = g0[ip] * f, c1 = g1[ip] * f / s_t[ip], c2 = g2[ip] * f / s_p[ip];
+          for (size_t i = 0; i < ne; i++)
+            gamma[i] = c0 * bf_r[ip * ne + i] + c1 * bf_t[ip * ne + i] + c2 * bf_p[ip * ne + i];
+          for (size_t j = 0; j < ne; j++) {
+            cplx cfj = std::conj(bf[ip * ne + j]), cgj = std::conj(gamma[j]);
+            for (size_t i = 0; i < ne; i++) Hsub(i, j) += (gamma[i] * cfj + bf[ip * ne + i] * cgj).real();
+          }
+        }
+      }
+    }
+    for (size_t j = 0; j < ne; j++)
+      for (size_t i = 0; i < ne; i++) H(bf_ind[i], bf_ind[j]) += Hsub(i, j);
+  }
+  Exc = exc_tot;
+  Nel = nel;
+  Ekin = 0.0;
+}
+
+}  // namespace oracle

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # one HIP runtime per process: torch's bundled runtime must be loaded before libhelfem_amd.so
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
