@@ -37,6 +37,12 @@ class hfg_diatomic_desc(ctypes.Structure):
                 ("lval", c_int_p), ("mval", c_int_p), ("nang", ctypes.c_int), ("lpad", ctypes.c_int)]
 
 
+class hfg_atomic_desc(ctypes.Structure):
+    _fields_ = [("Z", ctypes.c_int), ("primbas", ctypes.c_int), ("nnodes", ctypes.c_int), ("nquad", ctypes.c_int),
+                ("bval", c_double_p), ("nbval", ctypes.c_int), ("lval", c_int_p), ("mval", c_int_p),
+                ("nang", ctypes.c_int)]
+
+
 def lib():
     """Load the native library (fails loudly if it has not been built)."""
     global _lib
@@ -267,6 +273,36 @@ class TwoDBasis(object):
         return K
 
 
+def angular_basis(lmax, mmax):
+    """atomic::basis::angular_basis (src/atomic/basis.cpp:174)."""
+    cap = (lmax + 1) * (2 * mmax + 1) + 4
+    lv = (ctypes.c_int * cap)()
+    mv = (ctypes.c_int * cap)()
+    n = ctypes.c_int(cap)
+    _check(lib().hfg_angular_basis(int(lmax), int(mmax), lv, mv, ctypes.byref(n)))
+    return list(lv[:n.value]), list(mv[:n.value])
+
+
+class AtomicTwoDBasis(TwoDBasis):
+    """atomic::basis::TwoDBasis (point nucleus) — setup on the host, coulomb/exchange on the GPU."""
+
+    def __init__(self, Z, nnodes, nquad, bval, lval, mval, ctx=None):
+        self._bval = np.ascontiguousarray(bval, dtype=np.float64)
+        self._lval = (ctypes.c_int * len(lval))(*lval)
+        self._mval = (ctypes.c_int * len(mval))(*mval)
+        d = hfg_atomic_desc(int(Z), 4, int(nnodes), int(nquad), _p(self._bval), len(self._bval), self._lval,
+                            self._mval, len(lval))
+        h = ctypes.c_void_p()
+        _check(lib().hfg_atomic_basis_create(ctypes.byref(d), ctypes.byref(h)))
+        self.h = h
+        self.ctx = ctx
+        self.lval, self.mval = list(lval), list(mval)
+        self._uploaded = None
+        dims = [ctypes.c_int64() for _ in range(5)]
+        _check(lib().hfg_basis_dims(self.h, *[ctypes.byref(x) for x in dims]))
+        self._Nbf, self._Ndummy, self._Nrad, self._Nang, self._Nel = [x.value for x in dims]
+
+
 class DFTGrid(object):
     """diatomic::dftgrid::DFTGrid (dftgrid.cpp:760)."""
 
@@ -410,6 +446,26 @@ def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0
     lm = (ctypes.c_int * len(lmmax))(*lmmax)
     _check(L.hfg_scf_diatomic(ctx.h, Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
                               method.encode(), ldft, mdft, symmetry, maxit, convthr, verbose, _p(out)))
+    keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
+    r = dict(zip(keys, out[:7]))
+    r["iterations"] = int(out[7])
+    r["converged"] = (out[7] - int(out[7])) > 0.25
+    r["tJ"], r["tK"], r["tXC"], r["tdiag"] = out[8:12]
+    return r
+
+
+def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None):
+    """Restricted closed-shell atomic SCF with every per-iteration step on the GPU
+    (the loop of src/atomic/main.cpp:760-1005; flags as in main.cpp:66-100)."""
+    ctx = ctx or default_context()
+    L = lib()
+    L.hfg_scf_atomic.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int,
+                                ctypes.c_double, ctypes.c_char_p] + [ctypes.c_int] * 4 + [ctypes.c_double,
+                                ctypes.c_int, c_double_p]
+    out = np.zeros(12)
+    _check(L.hfg_scf_atomic(ctx.h, Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft,
+                            mdft, symmetry, maxit, convthr, verbose, _p(out)))
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])

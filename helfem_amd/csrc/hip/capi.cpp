@@ -205,6 +205,33 @@ int hfg_diatomic_basis_create(const hfg_diatomic_desc *d, hfg_basis **out) {
   HFG_CATCH
 }
 
+int hfg_atomic_basis_create(const hfg_atomic_desc *d, hfg_basis **out) {
+  HFG_TRY
+  if (d->primbas != 4) throw std::logic_error("Unsupported primitive basis.\n");
+  hfg_basis *b = new hfg_basis();
+  b->kind = 1;
+  b->ab = helfem::atomic::TwoDBasis(d->Z, d->nnodes, d->nquad, helfem::Vec(d->bval, d->bval + d->nbval),
+                                    helfem::IVec(d->lval, d->lval + d->nang), helfem::IVec(d->mval, d->mval + d->nang));
+  *out = b;
+  HFG_CATCH
+}
+
+int hfg_angular_basis(int lmax, int mmax, int *lval, int *mval, int *nang) {
+  HFG_TRY
+  helfem::IVec l, m;
+  helfem::atomic::angular_basis(lmax, mmax, l, m);
+  if ((int)l.size() > *nang) {
+    *nang = (int)l.size();
+    throw std::logic_error("hfg_angular_basis: output capacity too small");
+  }
+  *nang = (int)l.size();
+  for (size_t i = 0; i < l.size(); i++) {
+    lval[i] = l[i];
+    mval[i] = m[i];
+  }
+  HFG_CATCH
+}
+
 int hfg_basis_destroy(hfg_basis *b) {
   HFG_TRY
   if (!b) return 0;
@@ -218,11 +245,11 @@ int hfg_basis_destroy(hfg_basis *b) {
 }
 
 int hfg_basis_dims(const hfg_basis *b, int64_t *Nbf, int64_t *Ndummy, int64_t *Nrad, int64_t *Nang, int64_t *Nel) {
-  if (Nbf) *Nbf = b->b.Nbf();
-  if (Ndummy) *Ndummy = b->b.Ndummy();
-  if (Nrad) *Nrad = b->b.Nrad();
-  if (Nang) *Nang = b->b.Nang();
-  if (Nel) *Nel = b->b.Nel();
+  if (Nbf) *Nbf = b->Nbf();
+  if (Ndummy) *Ndummy = b->Ndummy();
+  if (Nrad) *Nrad = b->Nrad();
+  if (Nang) *Nang = b->Nang();
+  if (Nel) *Nel = b->Nel();
   return 0;
 }
 
@@ -231,21 +258,21 @@ static int copy_out(const helfem::Mat &M, double *out) {
   return 0;
 }
 int hfg_basis_overlap(const hfg_basis *b, double *S) {
-  HFG_TRY copy_out(b->b.overlap(), S);
+  HFG_TRY copy_out(b->kind ? b->ab.overlap() : b->b.overlap(), S);
   HFG_CATCH
 }
 int hfg_basis_kinetic(const hfg_basis *b, double *T) {
-  HFG_TRY copy_out(b->b.kinetic(), T);
+  HFG_TRY copy_out(b->kind ? b->ab.kinetic() : b->b.kinetic(), T);
   HFG_CATCH
 }
 int hfg_basis_nuclear(const hfg_basis *b, double *V) {
-  HFG_TRY copy_out(b->b.nuclear(), V);
+  HFG_TRY copy_out(b->kind ? b->ab.nuclear() : b->b.nuclear(), V);
   HFG_CATCH
 }
 
 int hfg_basis_sym_blocks(const hfg_basis *b, int symm, int *nblk, int64_t *blk_ptr, int64_t *blk_idx) {
   HFG_TRY
-  auto idx = b->b.get_sym_idx(symm);
+  auto idx = b->kind ? b->ab.get_sym_idx(symm) : b->b.get_sym_idx(symm);
   *nblk = (int)idx.size();
   if (blk_ptr) {
     int64_t off = 0;
@@ -260,7 +287,9 @@ int hfg_basis_sym_blocks(const hfg_basis *b, int symm, int *nblk, int64_t *blk_p
 }
 
 int hfg_compute_tei(hfg_basis *b, int exchange) {
-  HFG_TRY b->b.compute_tei(exchange != 0);
+  HFG_TRY
+  if (b->kind) b->ab.compute_tei(exchange != 0);
+  else b->b.compute_tei(exchange != 0);
   HFG_CATCH
 }
 
@@ -372,7 +401,7 @@ int hfg_fock_finish_dev(hfg_ctx *ctx, hfg_basis *b, const double *dFc, const dou
 // ---- host-pointer API ------------------------------------------------------------------------------
 int hfg_coulomb(hfg_ctx *ctx, hfg_basis *b, const double *P, double *J) {
   HFG_TRY
-  size_t N = b->b.Nbf();
+  size_t N = b->Nbf();
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dJ = st.alloc(N * N);
   coulomb_dev(ctx, b, dP, dJ);
@@ -382,7 +411,7 @@ int hfg_coulomb(hfg_ctx *ctx, hfg_basis *b, const double *P, double *J) {
 }
 int hfg_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
   HFG_TRY
-  size_t N = b->b.Nbf();
+  size_t N = b->Nbf();
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dK = st.alloc(N * N);
   exchange_dev(ctx, b, dP, dK);
@@ -393,7 +422,7 @@ int hfg_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
 int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *P, double *H, double *Exc,
                 double *Nel, double *Ekin, double thr) {
   HFG_TRY
-  size_t N = b->b.Nbf();
+  size_t N = b->Nbf();
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dH = st.alloc(N * N), *dS = st.alloc(3);
   xc_fock_dev(ctx, b, x_func, c_func, dP, dH, dS, thr);

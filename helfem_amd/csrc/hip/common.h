@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../../include/helfem_gpu.h"
+#include "../host/atomic_basis.h"
 #include "../host/diatomic_basis.h"
 
 namespace hfg {
@@ -80,10 +81,21 @@ struct hfg_ctx {
   void prof_collect();
 };
 
+// Either program's basis behind one handle: kind 0 = diatomic (prolate spheroidal), 1 = atomic (spherical)
 struct hfg_basis {
+  int kind = 0;
   helfem::diatomic::TwoDBasis b;
+  helfem::atomic::TwoDBasis ab;
   hfg_dev_tables *dev = nullptr;
   int dev_device = -1;
+
+  size_t Nbf() const { return kind ? ab.Nbf() : b.Nbf(); }
+  size_t Ndummy() const { return kind ? ab.Nbf() : b.Ndummy(); }
+  size_t Nrad() const { return kind ? ab.Nrad() : b.Nrad(); }
+  size_t Nang() const { return kind ? ab.Nang() : b.Nang(); }
+  size_t Nel() const { return kind ? ab.Nel() : b.Nel(); }
+  size_t max_Nprim() const { return kind ? ab.max_Nprim() : b.max_Nprim(); }
+  bool have_tei() const { return kind ? ab.have_tei : b.have_tei; }
 };
 
 namespace hfg {

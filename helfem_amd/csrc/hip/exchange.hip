@@ -68,8 +68,9 @@ __global__ void k_ex_U(const double *__restrict__ Pd, int Nd, int R, int A, int 
 __global__ void k_ex_R(const double *__restrict__ U, int R, int A, int nchan, const int *__restrict__ chanL,
                        const int *__restrict__ chanM, const int *__restrict__ chan_ilm,
                        const double *__restrict__ chan_fac, const int *__restrict__ shell_m,
-                       const double *__restrict__ c0tab, const double *__restrict__ c2tab, int Lp1, int Nlm,
+                       const double *__restrict__ c0tab, const double *__restrict__ c2tab, int Lp1, int Nlm, int ntt,
                        double *__restrict__ Rm, int *__restrict__ couple /* [A][Nlm] */) {
+  // "ilm" here and below is the primitive-table slot ((L,|M|) for the diatomic tables, L for the atomic ones)
   int k = blockIdx.x, ilm = blockIdx.y;
   size_t RR = (size_t)R * R;
   int any = 0;
@@ -93,11 +94,13 @@ __global__ void k_ex_R(const double *__restrict__ U, int R, int A, int nchan, co
         r22 += fac * b2 * u2;
       }
     }
-    double *o = Rm + (((size_t)k * Nlm + ilm) * 4) * RR + t;
+    double *o = Rm + (((size_t)k * Nlm + ilm) * ntt) * RR + t;
     o[0] = r00;
-    o[RR] = r02;
-    o[2 * RR] = r20;
-    o[3 * RR] = r22;
+    if (ntt == 4) {
+      o[RR] = r02;
+      o[2 * RR] = r20;
+      o[3 * RR] = r22;
+    }
   }
   any = __syncthreads_or(any);
   if (threadIdx.x == 0) couple[k * Nlm + ilm] = any;
@@ -106,7 +109,7 @@ __global__ void k_ex_R(const double *__restrict__ U, int R, int A, int nchan, co
 // EXc/EXd: radial stage for output block (j,k), element pair (iel,jel)
 __global__ void k_ex_radial(const double *__restrict__ Rm, const int *__restrict__ couple,
                             const double *__restrict__ tei, const double *__restrict__ disj, int R, int E, int p,
-                            int Nlm, double *__restrict__ Kc /* [A][E][E][p*p] */) {
+                            int Nlm, int ntt, double *__restrict__ Kc /* [A][E][E][p*p] */) {
   extern __shared__ double sh[];  // T[p*p]
   int k = blockIdx.x;
   int iel = blockIdx.y / E, jel = blockIdx.y % E;
@@ -121,13 +124,13 @@ __global__ void k_ex_radial(const double *__restrict__ Rm, const int *__restrict
   double acc = 0.0;
   for (int ilm = 0; ilm < Nlm; ilm++) {
     if (!couple[k * Nlm + ilm]) continue;
-    const double *R00 = Rm + (((size_t)k * Nlm + ilm) * 4) * RR;
-    const double *R02 = R00 + RR, *R20 = R00 + 2 * RR, *R22 = R00 + 3 * RR;
+    const double *R00 = Rm + (((size_t)k * Nlm + ilm) * ntt) * RR;
+    const double *R02 = R00 + RR, *R20 = R00 + 2 * RR, *R22 = R00 + 3 * RR;  // only read when ntt == 4
     if (iel == jel) {
       // Ksub(a,b) = sum_{i',l'} tei[(i' a),(b l')] R(i',l') :  ktei(b*p+a, l'*p+i') = tei(a*p+i', l'*p+b)
       if (inrange) {
         double s = 0.0;
-        for (int tt = 0; tt < 4; tt++) {
+        for (int tt = 0; tt < ntt; tt++) {
           const double *T = tei + (((size_t)tt * Nlm + ilm) * E + iel) * (size_t)pp * pp;
           const double *Rt = R00 + (size_t)tt * RR;
           for (int lp = 0; lp < p; lp++) {
@@ -145,13 +148,15 @@ __global__ void k_ex_radial(const double *__restrict__ Rm, const int *__restrict
       }
     } else {
       // disjoint integrals: the outer element gets Q, the inner one P  (basis.cpp:1709-1713)
-      int it0 = (iel > jel) ? 2 : 0, it2 = (iel > jel) ? 3 : 1;  // disj types: 0=P0 1=P2 2=Q0 3=Q2
-      int jt0 = (iel > jel) ? 0 : 2, jt2 = (iel > jel) ? 1 : 3;
+      const bool full = (ntt == 4);
+      const int tQ0 = full ? 2 : 1;  // disj types: 0=P0 1=P2 2=Q0 3=Q2 (diatomic); 0=P0 1=Q0 (atomic)
+      int it0 = (iel > jel) ? tQ0 : 0, it2 = (iel > jel) ? 3 : 1;
+      int jt0 = (iel > jel) ? 0 : tQ0, jt2 = (iel > jel) ? 1 : 3;
       const double *ii0 = disj + (((size_t)it0 * Nlm + ilm) * E + iel) * pp;
-      const double *ii2 = disj + (((size_t)it2 * Nlm + ilm) * E + iel) * pp;
+      const double *ii2 = full ? disj + (((size_t)it2 * Nlm + ilm) * E + iel) * pp : ii0;
       const double *jj0 = disj + (((size_t)jt0 * Nlm + ilm) * E + jel) * pp;
-      const double *jj2 = disj + (((size_t)jt2 * Nlm + ilm) * E + jel) * pp;
-      for (int pass = 0; pass < 2; pass++) {
+      const double *jj2 = full ? disj + (((size_t)jt2 * Nlm + ilm) * E + jel) * pp : jj0;
+      for (int pass = 0; pass < (full ? 2 : 1); pass++) {
         const double *Ra = pass ? R20 : R00, *Rb = pass ? R22 : R02;
         const double *ii = pass ? ii2 : ii0;
         // T(a,b) = sum_c Ra(a,c) jj0(b,c) + Rb(a,c) jj2(b,c)
@@ -160,7 +165,8 @@ __global__ void k_ex_radial(const double *__restrict__ Rm, const int *__restrict
           for (int c = 0; c < p; c++) {
             int gc = jfirst + c;
             if (gc >= R) continue;
-            tv += Ra[(size_t)gc * R + ga] * jj0[c * p + b] + Rb[(size_t)gc * R + ga] * jj2[c * p + b];
+            tv += Ra[(size_t)gc * R + ga] * jj0[c * p + b];
+            if (full) tv += Rb[(size_t)gc * R + ga] * jj2[c * p + b];
           }
         }
         __syncthreads();
@@ -224,40 +230,40 @@ static ExAux &exaux_for(hfg_ctx *ctx, hfg_basis *basis) {
   auto it = g_ex.find(t);
   if (it != g_ex.end()) return *it->second;
   ExAux *a = new ExAux();
-  const auto &b = basis->b;
   const int A = t->A;
-  a->Lp1 = b.Lmax + 1;
-  std::vector<double> c0((size_t)A * A * a->Lp1, 0.0), c2((size_t)A * A * a->Lp1, 0.0);
+  a->Lp1 = t->Lp1;
   a->hL.resize(A);
   a->hM.resize(A);
   a->hilm.resize(A);
   a->hfac.resize(A);
+  // coupling channels (L,M) of every shell x: those with a non-zero coefficient against some shell y
+  std::map<std::pair<int, int>, int> LMpos;
+  for (int i = 0; i < t->NLM; i++) LMpos[std::make_pair(t->h_LM_L[i], t->h_LM_M[i])] = i;
   for (int x = 0; x < A; x++) {
     std::vector<std::pair<int, int> > chans;
     for (int y = 0; y < A; y++) {
-      int lx = b.lval[x], mx = b.mval[x], ly = b.lval[y], my = b.mval[y];
-      int M = mx - my;
-      int Lmin = std::max(std::abs(lx - ly) - 2, std::abs(M)), Lmax = lx + ly + 2;
-      for (int L = Lmin; L <= Lmax; L++) {
-        double v0 = b.gaunt.mod_coeff(lx, mx, L, M, ly, my), v2 = b.gaunt.coeff(lx, mx, L, M, ly, my);
-        c0[((size_t)x * A + y) * a->Lp1 + L] = v0;
-        c2[((size_t)x * A + y) * a->Lp1 + L] = v2;
-        if (v0 != 0.0 || v2 != 0.0) chans.push_back(std::make_pair(L, M));
-      }
+      int M = t->h_shell_m[x] - t->h_shell_m[y];
+      for (int L = 0; L < a->Lp1; L++)
+        if (t->h_c0tab[((size_t)x * A + y) * a->Lp1 + L] != 0.0 || t->h_c2tab[((size_t)x * A + y) * a->Lp1 + L] != 0.0)
+          chans.push_back(std::make_pair(L, M));
     }
     std::sort(chans.begin(), chans.end());
     chans.erase(std::unique(chans.begin(), chans.end()), chans.end());
     for (auto &c : chans) {
+      int iLM = LMpos.at(c);
       a->hL[x].push_back(c.first);
       a->hM[x].push_back(c.second);
-      a->hilm[x].push_back((int)b.lmind(c.first, c.second));
-      a->hfac[x].push_back(b.LMfac(c.first, c.second));
+      a->hilm[x].push_back(t->h_lm_tab[t->h_LM_ilm[iLM]]);
+      a->hfac[x].push_back(t->h_LM_fac[iLM]);
     }
   }
-  a->c0tab.upload(c0, ctx->stream);
-  a->c2tab.upload(c2, ctx->stream);
-  std::vector<size_t> pi = b.pure_indices();
-  std::vector<int> pidx(pi.begin(), pi.end());
+  a->c0tab.upload(t->h_c0tab, ctx->stream);
+  a->c2tab.upload(t->h_c2tab, ctx->stream);
+  // positions of the real functions inside the (shell, dummy radial index) numbering
+  std::vector<int> pidx;
+  for (int s = 0; s < A; s++)
+    for (int n = (t->h_shell_skip[s] ? 1 : 0); n < t->R; n++) pidx.push_back(s * t->R + n);
+  if ((int)pidx.size() != t->N) throw std::logic_error("pure index list does not match the basis size");
   a->pure_idx.upload(pidx, ctx->stream);
   HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   g_ex[t] = a;
@@ -271,11 +277,11 @@ void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK) 
   ExAux &a = exaux_for(ctx, basis);
   ProfScope ps(ctx, "exchange");
   hipStream_t s = ctx->stream;
-  const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, Nlm = t->Nlm;
+  const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, Nlm = t->Ntab, ntt = t->ntt;
   const size_t RR = (size_t)R * R;
   a.Pd.resize((size_t)Nd * Nd);
   a.Kd.resize((size_t)Nd * Nd);
-  a.Rm.resize((size_t)A * Nlm * 4 * RR);
+  a.Rm.resize((size_t)A * Nlm * ntt * RR);
   a.couple.resize((size_t)A * Nlm);
   a.Kc.resize((size_t)A * E * E * p * p);
   hipLaunchKernelGGL(k_expand, dim3((Nd + 255) / 256, Nd), dim3(256), 0, s, dP, N, Nd, R, t->shell_off.p,
@@ -293,10 +299,10 @@ void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK) 
     hipLaunchKernelGGL(k_ex_U, dim3(nchan, A), dim3(256), 0, s, a.Pd.p, Nd, R, A, j, a.chanL.p, a.chanM.p,
                        t->shell_m.p, a.c0tab.p, a.c2tab.p, a.Lp1, a.U.p, nchan);
     hipLaunchKernelGGL(k_ex_R, dim3(A, Nlm), dim3(256), 0, s, a.U.p, R, A, nchan, a.chanL.p, a.chanM.p, a.chan_ilm.p,
-                       a.chan_fac.p, t->shell_m.p, a.c0tab.p, a.c2tab.p, a.Lp1, Nlm, a.Rm.p, a.couple.p);
+                       a.chan_fac.p, t->shell_m.p, a.c0tab.p, a.c2tab.p, a.Lp1, Nlm, ntt, a.Rm.p, a.couple.p);
     int bs = std::max(64, ((p * p + 63) / 64) * 64);
     hipLaunchKernelGGL(k_ex_radial, dim3(A, E * E), dim3(bs), p * p * sizeof(double), s, a.Rm.p, a.couple.p, t->tei.p,
-                       t->disj.p, R, E, p, Nlm, a.Kc.p);
+                       t->disj.p, R, E, p, Nlm, ntt, a.Kc.p);
     hipLaunchKernelGGL(k_ex_assemble, dim3(A, R), dim3(128), 0, s, a.Kc.p, R, E, p, Nd, j, a.Kd.p);
   }
   hipLaunchKernelGGL(k_remove, dim3((N + 255) / 256, N), dim3(256), 0, s, a.Kd.p, N, Nd, a.pure_idx.p, dK);

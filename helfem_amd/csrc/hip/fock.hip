@@ -144,9 +144,9 @@ __global__ void k_coulomb_ket(const double *__restrict__ Pc, int A, int E, int p
 // K2b in-element integrals (basis.cpp:1472-1485): Y[tt][iLM][e][:] = tei_tt[ilm][e] * vec(Paux_{tt&1 ? 2:0}[iLM][e])
 //     for iLM=(L,+|M|) and its partner (L,-|M|) in one pass over the p^2 x p^2 table (HBM-bound:
 //     this is where the 4*Nlm*E*p^4*8 bytes of primitive integrals are streamed once per build).
-__global__ void k_coulomb_tei(const double *__restrict__ tei, const double *__restrict__ Paux, int Nlm, int NLM,
+__global__ void k_coulomb_tei(const double *__restrict__ tei, const double *__restrict__ Paux, int Ntab, int NLM,
                               int E, int pp, const int *__restrict__ lmpos /* [Nlm][2] iLM of +M and -M */,
-                              int rank, int nranks, double *__restrict__ Y) {
+                              const int *__restrict__ lm_tab, int rank, int nranks, double *__restrict__ Y) {
   extern __shared__ double sh[];  // x_plus[pp], x_minus[pp]
   int ilm = blockIdx.x / E, e = blockIdx.x % E;
   if (ilm % nranks != rank) return;
@@ -159,7 +159,7 @@ __global__ void k_coulomb_tei(const double *__restrict__ tei, const double *__re
     xm[t] = (iLMm >= 0) ? Paux[((size_t)(which * NLM + iLMm) * E + e) * pp + t] : 0.0;
   }
   __syncthreads();
-  const double *T = tei + (((size_t)tt * Nlm + ilm) * E + e) * (size_t)pp * pp;
+  const double *T = tei + (((size_t)tt * Ntab + lm_tab[ilm]) * E + e) * (size_t)pp * pp;
   for (int r = threadIdx.x; r < pp; r += blockDim.x) {
     double yp = 0.0, ym = 0.0;
 #pragma unroll 5
@@ -173,32 +173,41 @@ __global__ void k_coulomb_tei(const double *__restrict__ tei, const double *__re
   }
 }
 
-// K2c per (L,M): disjoint (cross-element) part via the trace scalars + in-element part (basis.cpp:1424-1494)
+// K2c per (L,M): disjoint (cross-element) part via the trace scalars + in-element part (basis.cpp:1424-1494).
+//     full = 1: prolate kernel with the four P0/P2/Q0/Q2 and 00/02/20/22 tables; full = 0: spherical kernel
+//     r_<^L/r_>^{L+1} with P0/Q0 and 00 only (atomic TwoDBasis.cpp:884-936), disj then holds [P0][Q0].
 __global__ void k_coulomb_radial(const double *__restrict__ Paux, const double *__restrict__ Y,
                                  const double *__restrict__ disj, const int *__restrict__ LM_ilm,
-                                 const double *__restrict__ LM_fac, int Nlm, int NLM, int E, int p, int rank,
-                                 int nranks, double *__restrict__ Jaux) {
+                                 const int *__restrict__ LM_tab, const double *__restrict__ LM_fac, int Ntab, int NLM,
+                                 int E, int p, int full, int rank, int nranks, double *__restrict__ Jaux) {
   extern __shared__ double sh[];  // red[4*E*nwave], sc[4*E], big[E], small[E]
   int iLM = blockIdx.x;
-  int ilm = LM_ilm[iLM];
-  if (ilm % nranks != rank) return;
+  if (LM_ilm[iLM] % nranks != rank) return;
+  int tab = LM_tab[iLM];
   double fac = LM_fac[iLM];
   int pp = p * p;
   int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
   double *red = sh;
   double *sc = red + 4 * E * nwave;
   double *big = sc + 4 * E, *small = big + E;
+  const int tQ0 = full ? 2 : 1;
+  const double *dP0 = disj + ((size_t)0 * Ntab + tab) * E * pp;
+  const double *dQ0 = disj + ((size_t)tQ0 * Ntab + tab) * E * pp;
+  const double *dP2 = full ? disj + ((size_t)1 * Ntab + tab) * E * pp : nullptr;
+  const double *dQ2 = full ? disj + ((size_t)3 * Ntab + tab) * E * pp : nullptr;
   // traces: js[k][e], k: 0 small0=tr(P0*Psub0) 1 big0=tr(Q0*Psub0) 2 small2=tr(P2*Psub2) 3 big2=tr(Q2*Psub2)
   for (int e = 0; e < E; e++) {
     double a[4] = {0, 0, 0, 0};
     for (int t = threadIdx.x; t < pp; t += blockDim.x) {
       int i = t % p, j = t / p;
       double x0 = Paux[((size_t)(0 * NLM + iLM) * E + e) * pp + (i * p + j)];  // Psub(j,i)
-      double x2 = Paux[((size_t)(1 * NLM + iLM) * E + e) * pp + (i * p + j)];
-      a[0] += disj[(((size_t)0 * Nlm + ilm) * E + e) * pp + t] * x0;
-      a[1] += disj[(((size_t)2 * Nlm + ilm) * E + e) * pp + t] * x0;
-      a[2] += disj[(((size_t)1 * Nlm + ilm) * E + e) * pp + t] * x2;
-      a[3] += disj[(((size_t)3 * Nlm + ilm) * E + e) * pp + t] * x2;
+      a[0] += dP0[(size_t)e * pp + t] * x0;
+      a[1] += dQ0[(size_t)e * pp + t] * x0;
+      if (full) {
+        double x2 = Paux[((size_t)(1 * NLM + iLM) * E + e) * pp + (i * p + j)];
+        a[2] += dP2[(size_t)e * pp + t] * x2;
+        a[3] += dQ2[(size_t)e * pp + t] * x2;
+      }
     }
     for (int k = 0; k < 4; k++) {
       double v = a[k];
@@ -225,12 +234,17 @@ __global__ void k_coulomb_radial(const double *__restrict__ Paux, const double *
   __syncthreads();
   for (int e = 0; e < E; e++)
     for (int t = threadIdx.x; t < pp; t += blockDim.x) {
-      double P0 = disj[(((size_t)0 * Nlm + ilm) * E + e) * pp + t], P2 = disj[(((size_t)1 * Nlm + ilm) * E + e) * pp + t];
-      double Q0 = disj[(((size_t)2 * Nlm + ilm) * E + e) * pp + t], Q2 = disj[(((size_t)3 * Nlm + ilm) * E + e) * pp + t];
-      double y00 = Y[((size_t)(0 * NLM + iLM) * E + e) * pp + t], y02 = Y[((size_t)(1 * NLM + iLM) * E + e) * pp + t];
-      double y20 = Y[((size_t)(2 * NLM + iLM) * E + e) * pp + t], y22 = Y[((size_t)(3 * NLM + iLM) * E + e) * pp + t];
-      double j0 = P0 * big[e] + Q0 * small[e] + fac * y00 - fac * y02;
-      double j2 = -P2 * big[e] - Q2 * small[e] - fac * y20 + fac * y22;
+      double P0 = dP0[(size_t)e * pp + t], Q0 = dQ0[(size_t)e * pp + t];
+      double y00 = Y[((size_t)(0 * NLM + iLM) * E + e) * pp + t];
+      double j0 = P0 * big[e] + Q0 * small[e] + fac * y00;
+      double j2 = 0.0;
+      if (full) {
+        double P2 = dP2[(size_t)e * pp + t], Q2 = dQ2[(size_t)e * pp + t];
+        double y02 = Y[((size_t)(1 * NLM + iLM) * E + e) * pp + t];
+        double y20 = Y[((size_t)(2 * NLM + iLM) * E + e) * pp + t], y22 = Y[((size_t)(3 * NLM + iLM) * E + e) * pp + t];
+        j0 -= fac * y02;
+        j2 = -P2 * big[e] - Q2 * small[e] - fac * y20 + fac * y22;
+      }
       Jaux[((size_t)(0 * NLM + iLM) * E + e) * pp + t] = j0;
       Jaux[((size_t)(1 * NLM + iLM) * E + e) * pp + t] = j2;
     }
@@ -350,7 +364,7 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
                           const double *__restrict__ rad_sh, const double *__restrict__ th_s,
                           const double *__restrict__ th_w, const int *__restrict__ grp_m,
                           const double *__restrict__ cosd, const double *__restrict__ sind, int Dmax, int G, int nth,
-                          int nphi, double Rh, int x_func, int c_func, int do_grad, double thr, size_t NQ,
+                          int nphi, double Rh, int geom, int x_func, int c_func, int do_grad, double thr, size_t NQ,
                           int rank, int nranks, double *__restrict__ Fo, double *__restrict__ partial /* [2][NQ] */) {
   extern __shared__ double sh[];  // pot[4][nth*nphi], red[2*nwave]
   size_t Q = blockIdx.x;
@@ -371,10 +385,20 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
   for (int pt = threadIdx.x; pt < ng; pt += blockDim.x) {
     int i = pt / nphi, j = pt % nphi;
     double sth = th_s[i];
-    double h2 = shm * shm + sth * sth;
-    double hmu = Rh * sqrt(h2);
-    double hphi = Rh * shm * sth;
-    double w = th_w[i] * dphi * wr * Rh * Rh * Rh * shm * h2;
+    // scale factors of the radial-like, polar-like and azimuthal coordinates and the volume weight:
+    // prolate spheroidal (diatomic dftgrid.cpp:693-707), spherical (atomic dftgrid.cpp:724-743; shm holds r)
+    double hmu, hnu, hphi, w;
+    if (geom == 0) {
+      double h2 = shm * shm + sth * sth;
+      hmu = hnu = Rh * sqrt(h2);
+      hphi = Rh * shm * sth;
+      w = th_w[i] * dphi * wr * Rh * Rh * Rh * shm * h2;
+    } else {
+      hmu = 1.0;
+      hnu = shm;
+      hphi = shm * sth;
+      w = th_w[i] * dphi * wr * shm * shm;
+    }
     double rho = 0.0, gmu = 0.0, gnu = 0.0, gphi = 0.0;
     for (int ga = 0; ga < G; ga++)
       for (int gb = 0; gb < G; gb++) {
@@ -393,7 +417,7 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
     double sigma = 0.0;
     if (do_grad) {
       gmu *= 2.0 / hmu;
-      gnu *= 2.0 / hmu;
+      gnu *= 2.0 / hnu;
       gphi *= 2.0 / hphi;
       sigma = gmu * gmu + gnu * gnu + gphi * gphi;
     }
@@ -408,7 +432,7 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
     if (do_grad) {
       double f = 2.0 * w * vsig;
       p1[pt] = f * gmu / hmu;
-      p2[pt] = f * gnu / hmu;
+      p2[pt] = f * gnu / hnu;
       p3[pt] = f * gphi / hphi;
     }
   }
@@ -558,12 +582,11 @@ static FockAux &aux_for(hfg_ctx *ctx, hfg_basis *basis) {
   auto it = g_aux.find(t);
   if (it != g_aux.end()) return *it->second;
   FockAux *a = new FockAux();
-  const auto &b = basis->b;
   std::vector<int> ps(t->N), pn(t->N);
   {
     size_t k = 0;
     for (int s = 0; s < t->A; s++)
-      for (int n = (b.mval[s] != 0 ? 1 : 0); n < t->R; n++, k++) {
+      for (int n = (t->h_shell_skip[s] ? 1 : 0); n < t->R; n++, k++) {
         ps[k] = s;
         pn[k] = n;
       }
@@ -572,8 +595,8 @@ static FockAux &aux_for(hfg_ctx *ctx, hfg_basis *basis) {
   a->pure_n.upload(pn, ctx->stream);
   std::vector<int> lmpos(2 * t->Nlm, -1);
   for (int i = 0; i < t->NLM; i++) {
-    int L = b.LM_map[i].first, M = b.LM_map[i].second;
-    int ilm = (int)b.lmind(L, M);
+    int M = t->h_LM_M[i];
+    int ilm = t->h_LM_ilm[i];
     if (M >= 0) lmpos[2 * ilm] = i;
     if (M < 0) lmpos[2 * ilm + 1] = i;
   }
@@ -623,12 +646,14 @@ void coulomb_compact(hfg_ctx *ctx, hfg_basis *basis, const double *dPc, double *
   int bs = std::min(256, round_up64(pp));
   hipLaunchKernelGGL(k_coulomb_ket, dim3(t->NLM, t->E), dim3(bs), 0, ctx->stream, dPc, t->A, t->E, pp, t->lm_off.p,
                      t->lm_x.p, t->lm_y.p, t->lm_c0.p, t->lm_c2.p, t->NLM, t->LM_ilm.p, ctx->shard_rank, ctx->shard_n, a.Paux.p);
-  hipLaunchKernelGGL(k_coulomb_tei, dim3(t->Nlm * t->E, 4), dim3(bs), 2 * pp * sizeof(double), ctx->stream, t->tei.p,
-                     a.Paux.p, t->Nlm, t->NLM, t->E, pp, a.lmpos.p, ctx->shard_rank, ctx->shard_n, a.Y.p);
+  hipLaunchKernelGGL(k_coulomb_tei, dim3(t->Nlm * t->E, t->ntt), dim3(bs), 2 * pp * sizeof(double), ctx->stream,
+                     t->tei.p, a.Paux.p, t->Ntab, t->NLM, t->E, pp, a.lmpos.p, t->lm_tab.p, ctx->shard_rank, ctx->shard_n,
+                     a.Y.p);
   int nwave = bs / 64;
   size_t shb = (size_t)(4 * t->E * nwave + 4 * t->E + 2 * t->E) * sizeof(double);
   hipLaunchKernelGGL(k_coulomb_radial, dim3(t->NLM), dim3(bs), shb, ctx->stream, a.Paux.p, a.Y.p, t->disj.p,
-                     t->LM_ilm.p, t->LM_fac.p, t->Nlm, t->NLM, t->E, t->p, ctx->shard_rank, ctx->shard_n, a.Jaux.p);
+                     t->LM_ilm.p, t->LM_tab.p, t->LM_fac.p, t->Ntab, t->NLM, t->E, t->p, t->ntt == 4 ? 1 : 0,
+                     ctx->shard_rank, ctx->shard_n, a.Jaux.p);
   hipLaunchKernelGGL(k_coulomb_bra, dim3(t->A * t->A, t->E), dim3(bs), 0, ctx->stream, a.Jaux.p, t->A, t->E, pp,
                      t->NLM, t->pair_off.p, t->ent_iLM.p, t->ent_c0.p, t->ent_c2.p, t->LM_ilm.p, ctx->shard_rank, ctx->shard_n, dJc);
   HFG_HIP_CHECK(hipGetLastError());
@@ -677,8 +702,8 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   hipLaunchKernelGGL(k_xc_grid, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
-                     t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, x_func,
-                     c_func, do_grad, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
+                     t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
+                     x_func, c_func, do_grad, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
   hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 3 * nth * sizeof(double), ctx->stream,
                      a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p);
   hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 3 * nq * sizeof(double),
@@ -702,8 +727,7 @@ void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const d
 }
 
 size_t fock_compact_size(hfg_basis *basis) {
-  const auto &b = basis->b;
-  return (size_t)b.Nang() * b.Nang() * b.Nel() * b.max_Nprim() * b.max_Nprim();
+  return (size_t)basis->Nang() * basis->Nang() * basis->Nel() * basis->max_Nprim() * basis->max_Nprim();
 }
 
 // This shard's part of J + XC in the compact layout (to be summed over ranks), dScal = partial (Exc, Nel, 0)

@@ -37,6 +37,13 @@ struct GPUBackend : public helfem::scf::Backend {
     hb->b = basis;  // tables already computed by the driver
     chk(hfg_basis_upload(ctx, hb, ldft, mdft));
   }
+  void prepare_atomic(const helfem::atomic::TwoDBasis &basis, bool, int ldft, int mdft) override {
+    if (hb) hfg_basis_destroy(hb);
+    hb = new hfg_basis();
+    hb->kind = 1;
+    hb->ab = basis;
+    chk(hfg_basis_upload(ctx, hb, ldft, mdft));
+  }
   Mat coulomb(const Mat &P) override {
     Mat J(P.n_rows, P.n_cols);
     chk(hfg_coulomb(ctx, hb, P.memptr(), J.memptr()));
@@ -110,6 +117,52 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
     o.verbose = verbose != 0;
     GPUBackend be(ctx);
     helfem::scf::Result r = helfem::scf::run_diatomic(o, be);
+    out[0] = r.Etot;
+    out[1] = r.Ekin;
+    out[2] = r.Epot;
+    out[3] = r.Ecoul;
+    out[4] = r.Exx;
+    out[5] = r.Exc;
+    out[6] = r.Enucr;
+    out[7] = r.iterations + (r.converged ? 0.5 : 0.0);
+    out[8] = r.tJ;
+    out[9] = r.tK;
+    out[10] = r.tXC;
+    out[11] = r.tdiag;
+  } catch (const std::exception &e) {
+    hfg::set_error(e.what());
+    return 1;
+  }
+  return 0;
+}
+
+int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax,
+                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int maxit,
+                   double convthr, int verbose, double *out) {
+  try {
+    helfem::scf::AtomicOptions a;
+    a.Z = Z;
+    a.Q = Q;
+    a.lmax = lmax;
+    a.mmax = mmax;
+    helfem::scf::Options &o = a.common;
+    o.nelem = nelem;
+    o.nnodes = nnodes;
+    o.nquad = nquad;
+    o.Rmax = Rmax;
+    o.igrid = igrid;
+    o.zexp = zexp;
+    o.method = method;
+    helfem::parse_xc_func(o.x_func, o.c_func, o.method);
+    o.kfrac = helfem::exact_exchange(o.x_func);
+    o.ldft = ldft;
+    o.mdft = mdft;
+    o.symmetry = symmetry;
+    o.maxit = maxit;
+    o.convthr = convthr;
+    o.verbose = verbose != 0;
+    GPUBackend be(ctx);
+    helfem::scf::Result r = helfem::scf::run_atomic(a, be);
     out[0] = r.Etot;
     out[1] = r.Ekin;
     out[2] = r.Epot;

@@ -196,6 +196,49 @@ Mat TwoDBasis::nuclear() const {
   return place_diag(*this, std::vector<Mat>(Nang(), (-(double)Z) * Vrad));
 }
 
+Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly, int L) {
+  const size_t nq = xq.size();
+  const double rmid0 = 0.5 * (rmax + rmin), rlen0 = 0.5 * (rmax - rmin);
+  const size_t Ni = poly.nbf(), Np = Ni * Ni;
+  Vec r0(nq);
+  for (size_t q = 0; q < nq; q++) r0[q] = rmid0 + rlen0 * xq[q];
+  // inner(q,(kl)) = r_q^{-L-1} int_{rmin}^{r_q} r^L B_k B_l dr, built segment by segment (quadrature.cpp:22-83)
+  Mat inner(Np, nq);
+  for (size_t ip = 0; ip < nq; ip++) {
+    double a = (ip == 0) ? rmin : r0[ip - 1], bnd = r0[ip];
+    double rmid = 0.5 * (bnd + a), rlen = 0.5 * (bnd - a);
+    Vec xpoly(nq), wp(nq);
+    for (size_t q = 0; q < nq; q++) {
+      double r = rmid + rlen * xq[q];
+      wp[q] = wq[q] * std::pow(r / bnd, (double)L) / bnd * rlen;
+      xpoly[q] = (r - rmid0) / rlen0;
+    }
+    Mat bf = poly.eval_dnf(xpoly, 0, rlen0);
+    double *col = &inner.d[ip * Np];
+    for (size_t q = 0; q < nq; q++)
+      for (size_t l = 0; l < Ni; l++)
+        for (size_t k = 0; k < Ni; k++) col[l * Ni + k] += wp[q] * bf(q, k) * bf(q, l);
+    if (ip > 0) {
+      double ratio = std::pow(r0[ip], -(double)L - 1.0) / std::pow(r0[ip - 1], -(double)L - 1.0);
+      const double *prev = &inner.d[(ip - 1) * Np];
+      for (size_t k = 0; k < Np; k++) col[k] += prev[k] * ratio;
+    }
+  }
+  Mat bf0 = poly.eval_dnf(xq, 0, rlen0);
+  Mat ints(Np, Np);
+  for (size_t q = 0; q < nq; q++) {
+    double w = wq[q] * rlen0;
+    const double *in = &inner.d[q * Np];
+    for (size_t c = 0; c < Np; c++) {
+      double wi = w * in[c];
+      double *colp = &ints.d[c * Np];
+      for (size_t fj = 0; fj < Ni; fj++)
+        for (size_t fi = 0; fi < Ni; fi++) colp[fi * Ni + fj] += bf0(q, fi) * bf0(q, fj) * wi;
+    }
+  }
+  return ints + ints.t();
+}
+
 void TwoDBasis::compute_tei(bool exchange) {
   const size_t Ne = Nel(), NL = (size_t)N_L(), nq = xq.size();
   disjoint_L.assign(Ne * NL, Mat());
@@ -208,47 +251,8 @@ void TwoDBasis::compute_tei(bool exchange) {
     }
   parallel_for(Ne * NL, [&](size_t idx) {
     const size_t L = idx / Ne, iel = idx % Ne;
-    const double rmin = fem.element_begin(iel), rmax = fem.element_end(iel);
-    const double rmid0 = 0.5 * (rmax + rmin), rlen0 = 0.5 * (rmax - rmin);
-    LIPBasis poly = fem.get_basis(iel);
-    const size_t Ni = poly.nbf(), Np = Ni * Ni;
-    Vec r0(nq);
-    for (size_t q = 0; q < nq; q++) r0[q] = rmid0 + rlen0 * xq[q];
-    // inner(q,(kl)) = r_q^{-L-1} int_{rmin}^{r_q} r^L B_k B_l dr, built segment by segment (quadrature.cpp:22-83)
-    Mat inner(Np, nq);
-    for (size_t ip = 0; ip < nq; ip++) {
-      double a = (ip == 0) ? rmin : r0[ip - 1], bnd = r0[ip];
-      double rmid = 0.5 * (bnd + a), rlen = 0.5 * (bnd - a);
-      Vec xpoly(nq), wp(nq);
-      for (size_t q = 0; q < nq; q++) {
-        double r = rmid + rlen * xq[q];
-        wp[q] = wq[q] * std::pow(r / bnd, (double)L) / bnd * rlen;
-        xpoly[q] = (r - rmid0) / rlen0;
-      }
-      Mat bf = poly.eval_dnf(xpoly, 0, rlen0);
-      double *col = &inner.d[ip * Np];
-      for (size_t q = 0; q < nq; q++)
-        for (size_t l = 0; l < Ni; l++)
-          for (size_t k = 0; k < Ni; k++) col[l * Ni + k] += wp[q] * bf(q, k) * bf(q, l);
-      if (ip > 0) {
-        double ratio = std::pow(r0[ip], -(double)L - 1.0) / std::pow(r0[ip - 1], -(double)L - 1.0);
-        const double *prev = &inner.d[(ip - 1) * Np];
-        for (size_t k = 0; k < Np; k++) col[k] += prev[k] * ratio;
-      }
-    }
-    Mat bf0 = poly.eval_dnf(xq, 0, rlen0);
-    Mat ints(Np, Np);
-    for (size_t q = 0; q < nq; q++) {
-      double w = wq[q] * rlen0;
-      const double *in = &inner.d[q * Np];
-      for (size_t c = 0; c < Np; c++) {
-        double wi = w * in[c];
-        double *colp = &ints.d[c * Np];
-        for (size_t fj = 0; fj < Ni; fj++)
-          for (size_t fi = 0; fi < Ni; fi++) colp[fi * Ni + fj] += bf0(q, fi) * bf0(q, fj) * wi;
-      }
-    }
-    prim_tei[L * Ne + iel] = ints + ints.t();
+    prim_tei[L * Ne + iel] =
+        twoe_integral(fem.element_begin(iel), fem.element_end(iel), xq, wq, fem.get_basis(iel), (int)L);
   });
   have_tei = true;
   if (exchange) {

@@ -21,6 +21,10 @@ namespace atomic {
 /// atomic::basis::angular_basis (src/atomic/basis.cpp:174): |m|=0..mmax, l=|m|..lmax, (l,+|m|),(l,-|m|)
 void angular_basis(int lmax, int mmax, IVec &lval, IVec &mval);
 
+/// In-element two-electron integral table of one radial element, int int B_i(r1)B_j(r1) r_<^L/r_>^{L+1} B_k(r2)B_l(r2),
+/// (ij) x (kl), without the 4 pi/(2L+1) factor (quadrature::twoe_integral, libhelfem/src/quadrature.cpp:22-130)
+Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly, int L);
+
 struct TwoDBasis {
   int Z = 0;
   int nnodes = 0;

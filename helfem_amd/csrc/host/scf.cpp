@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <deque>
+#include <functional>
 
 namespace helfem {
 namespace scf {
@@ -90,47 +91,24 @@ Mat enforce_sym(const Mat &F, const std::vector<std::vector<size_t> > &sym) {
 }
 }  // namespace
 
-Result run_diatomic(const Options &opt, Backend &be) {
-  Result res;
-  const bool verbose = opt.verbose;
-  int nel = opt.Z1 + opt.Z2;
-  if (nel % 2) throw std::logic_error("Open-shell (unrestricted/ROHF) runs are not implemented in this build.\n");
-  const size_t nocc = nel / 2;
-
-  int Nquad = opt.nquad;
-  if (Nquad == 0) Nquad = 5 * opt.nnodes;
-  else if (Nquad < 2 * opt.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
-
-  IVec lval, mval;
-  diatomic::lm_to_l_m(opt.lmmax, lval, mval);
-  double Rhalf = 0.5 * opt.Rbond;
-  double mumax = arcosh(opt.Rmax / Rhalf);
-  Vec bval = get_grid(mumax, opt.nelem, opt.igrid, opt.zexp);
-
-  diatomic::TwoDBasis basis(opt.Z1, opt.Z2, Rhalf, opt.nnodes, Nquad, bval, lval, mval, opt.lpad);
-  res.Nbf = basis.Nbf();
-  if (verbose)
-    printf("Basis set consists of %i angular shells composed of %i radial functions, totaling %i basis functions\n",
-           (int)basis.Nang(), (int)basis.Nrad(), (int)basis.Nbf());
-  res.Enucr = opt.Z1 * opt.Z2 / opt.Rbond;
-
-  const bool dft = (opt.x_func > 0 || opt.c_func > 0);
-  int ldft = opt.ldft, mdft = opt.mdft;
-  if (dft) {
-    int lmaxmax = 0;
-    for (int l : opt.lmmax) lmaxmax = std::max(lmaxmax, l);
-    if (ldft == 0) ldft = 4 * lmaxmax + 12;
-    if (ldft < 2 * lmaxmax + 2) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
-    if (mdft == 0) mdft = 4 * (int)opt.lmmax.size() + 5;
-    if (mdft < 2 * (int)opt.lmmax.size()) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
-  }
-
+namespace {
+// the part of the drivers shared by the diatomic and atomic programs: everything from the one-electron matrices on
+struct Problem {
+  Mat S, T, Vnuc;
   std::vector<std::vector<size_t> > dsym;
-  int symm = opt.symmetry;
-  if (symm == 2 && opt.Z1 != opt.Z2) symm = 1;
-  dsym = basis.get_sym_idx(symm);
+  int symm = 1;
+  int nel = 0;
+  std::function<void()> compute_tei_and_prepare;
+};
 
-  Mat S(basis.overlap()), T(basis.kinetic()), Vnuc(basis.nuclear());
+Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
+  const bool verbose = opt.verbose;
+  const bool dft = (opt.x_func > 0 || opt.c_func > 0);
+  const int nel = pb.nel;
+  const size_t nocc = nel / 2;
+  const int symm = pb.symm;
+  const Mat &S = pb.S, &T = pb.T, &Vnuc = pb.Vnuc;
+  const std::vector<std::vector<size_t> > &dsym = pb.dsym;
   Mat H0(T + Vnuc);
   double t0 = wall();
   Mat Sinvh(be.Sinvh(S, !opt.diag, dsym));
@@ -144,8 +122,7 @@ Result run_diatomic(const Options &opt, Backend &be) {
 
   if (verbose) printf("Computing two-electron integrals\n");
   t0 = wall();
-  basis.compute_tei(opt.kfrac != 0.0);
-  be.prepare(basis, opt.kfrac != 0.0, ldft, mdft);
+  pb.compute_tei_and_prepare();
   if (verbose) printf("Done in %.6f\n", wall() - t0);
 
   DIIS diis(opt.diisorder);
@@ -243,6 +220,103 @@ Result run_diatomic(const Options &opt, Backend &be) {
     printf("%-21s energy: % .16f\n", "Virial ratio", -res.Etot / res.Ekin);
   }
   return res;
+}
+}  // namespace
+
+Result run_diatomic(const Options &opt, Backend &be) {
+  Result res;
+  const bool verbose = opt.verbose;
+  Problem pb;
+  int nel = opt.Z1 + opt.Z2;
+  if (nel % 2) throw std::logic_error("Open-shell (unrestricted/ROHF) runs are not implemented in this build.\n");
+
+  int Nquad = opt.nquad;
+  if (Nquad == 0) Nquad = 5 * opt.nnodes;
+  else if (Nquad < 2 * opt.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
+
+  IVec lval, mval;
+  diatomic::lm_to_l_m(opt.lmmax, lval, mval);
+  double Rhalf = 0.5 * opt.Rbond;
+  double mumax = arcosh(opt.Rmax / Rhalf);
+  Vec bval = get_grid(mumax, opt.nelem, opt.igrid, opt.zexp);
+
+  diatomic::TwoDBasis basis(opt.Z1, opt.Z2, Rhalf, opt.nnodes, Nquad, bval, lval, mval, opt.lpad);
+  res.Nbf = basis.Nbf();
+  if (verbose)
+    printf("Basis set consists of %i angular shells composed of %i radial functions, totaling %i basis functions\n",
+           (int)basis.Nang(), (int)basis.Nrad(), (int)basis.Nbf());
+  res.Enucr = opt.Z1 * opt.Z2 / opt.Rbond;
+
+  const bool dft = (opt.x_func > 0 || opt.c_func > 0);
+  int ldft = opt.ldft, mdft = opt.mdft;
+  if (dft) {
+    int lmaxmax = 0;
+    for (int l : opt.lmmax) lmaxmax = std::max(lmaxmax, l);
+    if (ldft == 0) ldft = 4 * lmaxmax + 12;
+    if (ldft < 2 * lmaxmax + 2) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
+    if (mdft == 0) mdft = 4 * (int)opt.lmmax.size() + 5;
+    if (mdft < 2 * (int)opt.lmmax.size()) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
+  }
+
+  int symm = opt.symmetry;
+  if (symm == 2 && opt.Z1 != opt.Z2) symm = 1;
+  pb.symm = symm;
+  pb.dsym = basis.get_sym_idx(symm);
+
+  pb.nel = nel;
+  pb.S = basis.overlap();
+  pb.T = basis.kinetic();
+  pb.Vnuc = basis.nuclear();
+  pb.compute_tei_and_prepare = [&]() {
+    basis.compute_tei(opt.kfrac != 0.0);
+    be.prepare(basis, opt.kfrac != 0.0, ldft, mdft);
+  };
+  return scf_loop(opt, be, pb, res);
+}
+
+Result run_atomic(const AtomicOptions &aopt, Backend &be) {
+  const Options &opt = aopt.common;
+  Result res;
+  const bool verbose = opt.verbose;
+  Problem pb;
+  int nel = aopt.Z - aopt.Q;
+  if (nel % 2) throw std::logic_error("Open-shell (unrestricted/ROHF) runs are not implemented in this build.\n");
+  if (nel <= 0) throw std::logic_error("No electrons.\n");
+
+  // atomic/main.cpp:245-251
+  int Nquad = opt.nquad;
+  if (Nquad == 0) Nquad = 5 * opt.nnodes;
+  else if (Nquad < 2 * opt.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
+
+  IVec lval, mval;
+  atomic::angular_basis(aopt.lmax, aopt.mmax, lval, mval);
+  Vec bval = get_grid(opt.Rmax, opt.nelem, opt.igrid, opt.zexp);
+  atomic::TwoDBasis basis(aopt.Z, opt.nnodes, Nquad, bval, lval, mval);
+  res.Nbf = basis.Nbf();
+  if (verbose)
+    printf("Basis set consists of %i angular shells composed of %i radial functions, totaling %i basis functions\n",
+           (int)basis.Nang(), (int)basis.Nrad(), (int)basis.Nbf());
+  res.Enucr = 0.0;
+
+  const bool dft = (opt.x_func > 0 || opt.c_func > 0);
+  int ldft = opt.ldft, mdft = opt.mdft;
+  if (dft) {  // atomic/main.cpp:389-403
+    if (ldft == 0) ldft = 4 * aopt.lmax + 10;
+    if (ldft < 2 * aopt.lmax) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
+    if (mdft == 0) mdft = 4 * aopt.mmax + 5;
+    if (mdft < 2 * aopt.mmax) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
+  }
+  pb.symm = opt.symmetry;
+  pb.dsym = basis.get_sym_idx(pb.symm);
+  pb.nel = nel;
+  pb.S = basis.overlap();
+  pb.T = basis.kinetic();
+  pb.Vnuc = basis.nuclear();
+  pb.compute_tei_and_prepare = [&]() {
+    basis.compute_tei(opt.kfrac != 0.0);
+    be.prepare_atomic(basis, opt.kfrac != 0.0, ldft, mdft);
+  };
+  return scf_loop(opt, be, pb, res);
 }
 
 }  // namespace scf

@@ -7,6 +7,7 @@
 // Open-shell / unrestricted runs, external fields, finite nuclei, checkpoints and the SAP/GSZ/TF
 // guesses are outside the hot-path scope and are rejected loudly.
 #pragma once
+#include "atomic_basis.h"
 #include "diatomic_basis.h"
 #include <string>
 
@@ -18,6 +19,8 @@ struct Backend {
   virtual const char *name() const = 0;
   /// upload / prepare tables after compute_tei
   virtual void prepare(const diatomic::TwoDBasis &basis, bool exchange, int ldft, int mdft) = 0;
+  /// same for the atomic program's basis (src/atomic/main.cpp)
+  virtual void prepare_atomic(const atomic::TwoDBasis &basis, bool exchange, int ldft, int mdft) = 0;
   virtual Mat coulomb(const Mat &P) = 0;
   virtual Mat exchange(const Mat &P) = 0;
   virtual void eval_Fxc(int x_func, int c_func, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin,
@@ -61,7 +64,16 @@ struct Result {
   size_t Nbf = 0;
 };
 
+/// options of the atomic program on top of the common ones (Z1/Z2/Rbond/lmmax/lpad of `common` are unused)
+struct AtomicOptions {
+  Options common;
+  int Z = 2, Q = 0;
+  int lmax = 0, mmax = 0;
+};
+
 Result run_diatomic(const Options &opt, Backend &be);
+/// src/atomic/main.cpp:100-1010, restricted closed shell, point nucleus, core guess
+Result run_atomic(const AtomicOptions &opt, Backend &be);
 
 }  // namespace scf
 }  // namespace helfem

@@ -69,6 +69,26 @@ typedef struct {
 } hfg_diatomic_desc;
 
 int hfg_diatomic_basis_create(const hfg_diatomic_desc *desc, hfg_basis **basis);
+
+/* Constructor arguments of helfem::atomic::basis::TwoDBasis (src/atomic/TwoDBasis.cpp:38-76) for the
+ * point-nucleus case the atomic driver builds at src/atomic/main.cpp:268-273 (finitenuc = 0, no off-centre
+ * charges, zeroder = 0).  The handle is used with every hfg_basis_* / hfg_coulomb / hfg_exchange / hfg_xc_fock
+ * entry below exactly like a diatomic one (replacing TwoDBasis::coulomb / exchange, TwoDBasis.cpp:817/957,
+ * and atomic::dftgrid::DFTGrid::eval_Fxc, src/atomic/dftgrid.cpp:810). */
+typedef struct {
+  int Z;
+  int primbas;   /* 4 = LIP on Gauss-Lobatto nodes (the default); others are rejected */
+  int nnodes;
+  int nquad;
+  const double *bval; /* element boundaries in r, bval[0] = 0 */
+  int nbval;
+  const int *lval;
+  const int *mval;
+  int nang;
+} hfg_atomic_desc;
+int hfg_atomic_basis_create(const hfg_atomic_desc *desc, hfg_basis **basis);
+/* atomic::basis::angular_basis (src/atomic/basis.cpp:174): shell list for --lmax/--mmax */
+int hfg_angular_basis(int lmax, int mmax, int *lval, int *mval, int *nang /* in: capacity, out: count */);
 int hfg_basis_destroy(hfg_basis *basis);
 /* Nbf, Ndummy, Nrad, Nang, Nel (TwoDBasis::Nbf/Ndummy/Nrad/Nang, basis.cpp:457-480) */
 int hfg_basis_dims(const hfg_basis *basis, int64_t *Nbf, int64_t *Ndummy, int64_t *Nrad, int64_t *Nang,
@@ -170,6 +190,11 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
 int hfg_profile_enable(hfg_ctx *ctx, int on);
 int hfg_profile_reset(hfg_ctx *ctx);
 int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches);
+
+/* Restricted closed-shell atomic SCF (driver loop of src/atomic/main.cpp:760-1005); out as for hfg_scf_diatomic */
+int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax,
+                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int maxit,
+                   double convthr, int verbose, double *out /* 12 */);
 
 /* Replays every launch of the named kernel of the last eigensolve back to back between two HIP events on the
  * context's stream (the roofline leg of bench.py).  Supported: "k_trdb_gemv". */

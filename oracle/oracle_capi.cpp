@@ -34,6 +34,7 @@ static std::vector<std::vector<size_t> > to_blocks(int nblk, const int64_t *ptr,
 namespace {
 struct OracleBackend : public helfem::scf::Backend {
   const TwoDBasis *b = nullptr;
+  const helfem::atomic::TwoDBasis *ab = nullptr;
   int ldft = 0, mdft = 0;
   const char *name() const override { return "oracle"; }
   void prepare(const TwoDBasis &basis, bool, int l, int m) override {
@@ -41,10 +42,16 @@ struct OracleBackend : public helfem::scf::Backend {
     ldft = l;
     mdft = m;
   }
-  Mat coulomb(const Mat &P) override { return oracle::coulomb(*b, P); }
-  Mat exchange(const Mat &P) override { return oracle::exchange(*b, P); }
+  void prepare_atomic(const helfem::atomic::TwoDBasis &basis, bool, int l, int m) override {
+    ab = &basis;
+    ldft = l;
+    mdft = m;
+  }
+  Mat coulomb(const Mat &P) override { return ab ? oracle::atomic_coulomb(*ab, P) : oracle::coulomb(*b, P); }
+  Mat exchange(const Mat &P) override { return ab ? oracle::atomic_exchange(*ab, P) : oracle::exchange(*b, P); }
   void eval_Fxc(int x, int c, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin, double thr) override {
-    oracle::eval_Fxc(*b, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
+    if (ab) oracle::atomic_eval_Fxc(*ab, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
+    else oracle::eval_Fxc(*b, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
   }
   void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh, const std::vector<std::vector<size_t> > &sym) override {
     oracle::eig_gsym_sub(E, C, F, Sinvh, sym);
@@ -222,6 +229,147 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
   o.verbose = verbose != 0;
   OracleBackend be;
   helfem::scf::Result r = helfem::scf::run_diatomic(o, be);
+  out[0] = r.Etot;
+  out[1] = r.Ekin;
+  out[2] = r.Epot;
+  out[3] = r.Ecoul;
+  out[4] = r.Exx;
+  out[5] = r.Exc;
+  out[6] = r.Enucr;
+  out[7] = r.iterations + (r.converged ? 0.5 : 0.0);
+  ORC_CATCH
+}
+
+
+// ---- atomic program ----
+typedef helfem::atomic::TwoDBasis ABasis;
+
+int orc_atomic_basis_create(int Z, int nnodes, int nquad, const double *bval, int nbval, const int *lval,
+                            const int *mval, int nang, void **out) {
+  ORC_TRY
+  *out = new ABasis(Z, nnodes, nquad, Vec(bval, bval + nbval), helfem::IVec(lval, lval + nang),
+                    helfem::IVec(mval, mval + nang));
+  ORC_CATCH
+}
+int orc_atomic_basis_destroy(void *h) {
+  delete (ABasis *)h;
+  return 0;
+}
+int orc_atomic_basis_dims(void *h, int64_t *Nbf, int64_t *Nrad, int64_t *Nang, int64_t *Nel) {
+  ABasis *b = (ABasis *)h;
+  *Nbf = b->Nbf();
+  *Nrad = b->Nrad();
+  *Nang = b->Nang();
+  *Nel = b->Nel();
+  return 0;
+}
+/// which: 0 overlap, 1 kinetic, 2 nuclear
+int orc_atomic_onebody(void *h, int which, double *out) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  Mat M = which == 0 ? b->overlap() : which == 1 ? b->kinetic() : b->nuclear();
+  memcpy(out, M.memptr(), sizeof(double) * M.n_elem());
+  ORC_CATCH
+}
+int orc_atomic_compute_tei(void *h, int exchange) {
+  ORC_TRY((ABasis *)h)->compute_tei(exchange != 0);
+  ORC_CATCH
+}
+int orc_atomic_coulomb(void *h, const double *P, double *J) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  size_t N = b->Nbf();
+  Mat Jm = atomic_coulomb(*b, to_mat(P, N, N));
+  memcpy(J, Jm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_atomic_exchange(void *h, const double *P, double *K) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  size_t N = b->Nbf();
+  Mat Km = atomic_exchange(*b, to_mat(P, N, N));
+  memcpy(K, Km.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_atomic_eval_fxc(void *h, int lang, int mang, int x_func, int c_func, const double *P, double *H, double *Exc,
+                        double *Nel, double *Ekin, double thr) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  size_t N = b->Nbf();
+  Mat Hm;
+  atomic_eval_Fxc(*b, lang, mang, x_func, c_func, to_mat(P, N, N), Hm, *Exc, *Nel, *Ekin, thr);
+  memcpy(H, Hm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+/// \int B_i B_j r^n dr over the whole radial basis (Nrad x Nrad) -- checked against the Maple rationals of
+/// the reference's src/atomic/inttest.cpp
+int orc_atomic_radial_integral(void *h, int n, double *out) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  size_t Nrad = b->Nrad();
+  Mat M(Nrad, Nrad);
+  for (size_t iel = 0; iel < b->Nel(); iel++) {
+    size_t f, l;
+    b->fem.get_idx(iel, f, l);
+    Mat s = b->radial_integral(n, iel);
+    for (size_t j = 0; j < s.n_cols; j++)
+      for (size_t i = 0; i < s.n_rows; i++) M(f + i, f + j) += s(i, j);
+  }
+  memcpy(out, M.memptr(), sizeof(double) * M.n_elem());
+  ORC_CATCH
+}
+
+/// twoe_integral on [0,R] for the full nnodes-node LIP set (nothing dropped) -- the set-up of the reference's
+/// src/atomic/inttest.cpp; out is n^2 x n^2 with n = nnodes, without the 4 pi/(2L+1) factor
+int orc_atomic_twoe_integral(double rmin, double rmax, int nnodes, int nquad, int L, double *out) {
+  ORC_TRY
+  Vec xq, wq;
+  helfem::chebyshev_rule(nquad, xq, wq);
+  helfem::LIPBasis poly(helfem::lobatto_nodes(nnodes));
+  Mat m = helfem::atomic::twoe_integral(rmin, rmax, xq, wq, poly, L);
+  memcpy(out, m.memptr(), sizeof(double) * m.n_elem());
+  ORC_CATCH
+}
+
+/// in-element two-electron integral table of (L, iel), n^2 x n^2 without the 4 pi/(2L+1) factor
+int orc_atomic_prim_tei(void *h, int L, int iel, double *out, int64_t *n) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  if (!b->have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
+  const Mat &m = b->prim_tei.at((size_t)L * b->Nel() + iel);
+  *n = (int64_t)m.n_rows;
+  memcpy(out, m.memptr(), sizeof(double) * m.n_elem());
+  ORC_CATCH
+}
+
+/// Restricted closed-shell atomic SCF on the CPU oracle; out as for orc_scf_diatomic
+int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax, int igrid,
+                   double zexp, const char *method, int ldft, int mdft, int symmetry, int maxit, double convthr,
+                   int verbose, double *out) {
+  ORC_TRY
+  helfem::scf::AtomicOptions a;
+  a.Z = Z;
+  a.Q = Q;
+  a.lmax = lmax;
+  a.mmax = mmax;
+  helfem::scf::Options &o = a.common;
+  o.nelem = nelem;
+  o.nnodes = nnodes;
+  o.nquad = nquad;
+  o.Rmax = Rmax;
+  o.igrid = igrid;
+  o.zexp = zexp;
+  o.method = method;
+  parse_xc_func(o.x_func, o.c_func, o.method);
+  o.kfrac = (o.x_func == -1) ? 1.0 : 0.0;
+  o.ldft = ldft;
+  o.mdft = mdft;
+  o.symmetry = symmetry;
+  o.maxit = maxit;
+  o.convthr = convthr;
+  o.verbose = verbose != 0;
+  OracleBackend be;
+  helfem::scf::Result r = helfem::scf::run_atomic(a, be);
   out[0] = r.Etot;
   out[1] = r.Ekin;
   out[2] = r.Epot;

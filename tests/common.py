@@ -19,6 +19,18 @@ def make_bases(Z1=1, Z2=1, Rbond=1.4, lmmax=(4,), nelem=2, nnodes=6, nquad=0, Rm
     return gb, ob
 
 
+def make_atomic_bases(Z=2, lmax=1, mmax=1, nelem=3, nnodes=6, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, product=True,
+                      oracle=True):
+    """the basis of the atomic program (src/atomic/main.cpp:245-273): r grid on [0,Rmax], shells from lmax/mmax"""
+    lval, mval = hf.angular_basis(lmax, mmax)
+    bval = hf.get_grid(Rmax, nelem, igrid, zexp)
+    if nquad == 0:
+        nquad = 5 * nnodes
+    gb = hf.AtomicTwoDBasis(Z, nnodes, nquad, bval, lval, mval) if product else None
+    ob = orc.OracleAtomicBasis(Z, nnodes, nquad, bval, lval, mval) if oracle else None
+    return gb, ob
+
+
 def random_density(N, nocc=3, seed=1, blocks=None):
     """P = C C^T with seeded random orthonormal-ish C; block-diagonal over `blocks` if given"""
     rng = np.random.RandomState(seed)

@@ -36,6 +36,17 @@ def lib():
                                        ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                        c_double_p]
+        L.orc_atomic_basis_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_void_p)]
+        L.orc_atomic_eval_fxc.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double]
+        L.orc_atomic_onebody.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p]
+        L.orc_atomic_radial_integral.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p]
+        L.orc_atomic_prim_tei.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_i64_p]
+        L.orc_scf_atomic.argtypes = [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                                          ctypes.c_char_p] + [ctypes.c_int] * 4 + [
+                                                              ctypes.c_double, ctypes.c_int, c_double_p]
         for name in ("orc_basis_destroy", "orc_basis_dims", "orc_compute_tei", "orc_coulomb", "orc_exchange",
                      "orc_grid_overlap", "orc_grid_kinetic"):
             getattr(L, name).argtypes = None
@@ -129,6 +140,77 @@ class OracleBasis(object):
         T = np.zeros((self.Nbf, self.Nbf), order="F")
         _check(lib().orc_grid_kinetic(self.h, lang, mang, _p(T)))
         return T
+
+
+class OracleAtomicBasis(object):
+    def __init__(self, Z, nnodes, nquad, bval, lval, mval):
+        bval = np.ascontiguousarray(bval, dtype=np.float64)
+        lv = (ctypes.c_int * len(lval))(*lval)
+        mv = (ctypes.c_int * len(mval))(*mval)
+        h = ctypes.c_void_p()
+        _check(lib().orc_atomic_basis_create(Z, nnodes, nquad, _p(bval), len(bval), lv, mv, len(lval), ctypes.byref(h)))
+        self.h = h
+        dims = [ctypes.c_int64() for _ in range(4)]
+        lib().orc_atomic_basis_dims(self.h, *[ctypes.byref(x) for x in dims])
+        self.Nbf, self.Nrad, self.Nang, self.Nel = [x.value for x in dims]
+
+    def __del__(self):
+        try:
+            lib().orc_atomic_basis_destroy(self.h)
+        except Exception:
+            pass
+
+    def onebody(self, which):
+        M = np.zeros((self.Nbf, self.Nbf), order="F")
+        _check(lib().orc_atomic_onebody(self.h, {"overlap": 0, "kinetic": 1, "nuclear": 2}[which], _p(M)))
+        return M
+
+    def radial_integral(self, n):
+        M = np.zeros((self.Nrad, self.Nrad), order="F")
+        _check(lib().orc_atomic_radial_integral(self.h, int(n), _p(M)))
+        return M
+
+    def prim_tei(self, L, iel, nmax=64):
+        out = np.zeros(nmax ** 4)
+        n = ctypes.c_int64()
+        _check(lib().orc_atomic_prim_tei(self.h, int(L), int(iel), _p(out), ctypes.byref(n)))
+        k = n.value
+        return out[:k * k].reshape((k, k), order="F")
+
+    def compute_tei(self, exchange=True):
+        _check(lib().orc_atomic_compute_tei(self.h, 1 if exchange else 0))
+
+    def coulomb(self, P):
+        P = _f(P)
+        J = np.zeros_like(P, order="F")
+        _check(lib().orc_atomic_coulomb(self.h, _p(P), _p(J)))
+        return J
+
+    def exchange(self, P):
+        P = _f(P)
+        K = np.zeros_like(P, order="F")
+        _check(lib().orc_atomic_exchange(self.h, _p(P), _p(K)))
+        return K
+
+    def eval_Fxc(self, lang, mang, x_func, c_func, P, thr=1e-12):
+        P = _f(P)
+        H = np.zeros_like(P, order="F")
+        exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(lib().orc_atomic_eval_fxc(self.h, lang, mang, x_func, c_func, _p(P), _p(H), ctypes.byref(exc),
+                                         ctypes.byref(nel), ctypes.byref(ekin), thr))
+        return H, exc.value, nel.value, ekin.value
+
+
+def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0):
+    out = np.zeros(8)
+    _check(lib().orc_scf_atomic(Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft, mdft,
+                                symmetry, maxit, convthr, verbose, _p(out)))
+    keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
+    r = dict(zip(keys, out[:7]))
+    r["iterations"] = int(out[7])
+    r["converged"] = (out[7] - int(out[7])) > 0.25
+    return r
 
 
 def eig_sym(A):

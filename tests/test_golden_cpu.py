@@ -300,3 +300,116 @@ def test_compute_paths_fail_loudly_without_gpu(hf):
         hf.Context(0)
     with pytest.raises(RuntimeError):
         hf.scf.eig_sym(np.eye(3))
+
+
+# ---------------------------------------------------------------------------------------------------
+# atomic program: the reference's own known answers and literature energies
+# ---------------------------------------------------------------------------------------------------
+import oracle_lib as orc  # noqa: E402
+
+
+def test_atomic_twoe_integral_maple_rationals():
+    """src/atomic/inttest.cpp:57-96: the 16 in-element integrals of the linear LIP pair on [0,R] for L=0, as Maple
+    rationals in units of R (the reference multiplies by 4 pi, the tables here carry that factor separately)."""
+    import ctypes
+    L = orc.lib()
+    L.orc_atomic_twoe_integral.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           orc.c_double_p]
+    m = np.array([[47 / 180, 11 / 360, 11 / 360, 1 / 90], [1 / 10, 1 / 40, 1 / 40, 1 / 60],
+                  [1 / 10, 1 / 40, 1 / 40, 1 / 60], [3 / 20, 7 / 120, 7 / 120, 1 / 15]])
+    for R in (0.5, 2.3, 40.0):
+        ref = (m + m.T) * R
+        for nq, tol in ((10, 1e-6), (50, 1e-13), (200, 1e-13)):
+            out = np.zeros(16)
+            assert L.orc_atomic_twoe_integral(0.0, R, 2, nq, 0, orc._p(out)) == 0
+            err = np.abs(out.reshape(4, 4, order="F") - ref).max() / R
+            assert err < tol, (R, nq, err)
+
+
+def test_atomic_twoe_integral_higher_L_against_mpmath():
+    """same routine for L = 1, 2 on an element away from the origin, against adaptive quadrature"""
+    import ctypes
+    import mpmath as mp
+    L = orc.lib()
+    L.orc_atomic_twoe_integral.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           orc.c_double_p]
+    a, b = 0.7, 1.9
+    nodes = [-1.0, 0.0, 1.0]
+
+    def lip(i, r):
+        x = (2 * r - (a + b)) / (b - a)
+        v = mp.mpf(1)
+        for k, xk in enumerate(nodes):
+            if k != i:
+                v *= (x - xk) / (nodes[i] - xk)
+        return v
+
+    for Lq in (1, 2):
+        out = np.zeros(81)
+        assert L.orc_atomic_twoe_integral(a, b, 3, 60, Lq, orc._p(out)) == 0
+        t = out.reshape(9, 9, order="F")
+        for (i, j, k, l) in [(0, 0, 0, 0), (0, 1, 2, 2), (1, 2, 0, 1), (2, 2, 1, 1)]:
+            def inner(r1):
+                lo = mp.quad(lambda r2: lip(k, r2) * lip(l, r2) * r2 ** Lq, [a, r1]) / r1 ** (Lq + 1)
+                hi = mp.quad(lambda r2: lip(k, r2) * lip(l, r2) / r2 ** (Lq + 1), [r1, b]) * r1 ** Lq
+                return lip(i, r1) * lip(j, r1) * (lo + hi)
+            ref = float(mp.quad(inner, [a, b]))
+            assert abs(t[j * 3 + i, l * 3 + k] - ref) < 1e-12, (Lq, i, j, k, l, t[j * 3 + i, l * 3 + k], ref)
+
+
+def test_atomic_hydrogenic_one_electron_spectrum():
+    """T + V of the atomic basis reproduces the hydrogen-like levels -Z^2/(2 n^2) (1s, 2s, 2p, 3d)"""
+    import common
+    import scipy.linalg
+    Z = 3
+    _, ob = common.make_atomic_bases(Z, 2, 0, 5, 15, product=False)
+    S, T, V = ob.onebody("overlap"), ob.onebody("kinetic"), ob.onebody("nuclear")
+    nr = ob.Nrad
+    for l, levels in ((0, [1, 2, 3]), (1, [2, 3]), (2, [3])):
+        sl = slice(l * nr, (l + 1) * nr)
+        E = scipy.linalg.eigh(T[sl, sl] + V[sl, sl], S[sl, sl], eigvals_only=True)
+        for k, n in enumerate(levels):
+            assert abs(E[k] + Z * Z / (2.0 * n * n)) < 1e-9, (l, n, E[k])
+
+
+ATOMIC_LITERATURE = [
+    # closed-shell total energies: HF limits (numerical HF) and the NIST atomic reference data LDA (VWN) values
+    ("He_HF", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF"), -2.8616799956, 1e-8),
+    ("Be_HF", dict(Z=4, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF"), -14.573023168, 1e-7),
+    ("Ne_HF", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="HF"), -128.54709811, 1e-7),
+    ("He_LDA", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -2.834836, 1e-6),
+    ("Ne_LDA", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -128.233481, 1e-6),
+]
+
+
+@pytest.mark.parametrize("name,kw,lit,tol", ATOMIC_LITERATURE, ids=[c[0] for c in ATOMIC_LITERATURE])
+def test_atomic_oracle_literature_energies(name, kw, lit, tol):
+    r = orc.scf_atomic(convthr=1e-9, maxit=60, **kw)
+    assert r["converged"]
+    assert abs(r["Etot"] - lit) < tol, (name, r["Etot"], lit)
+    if kw["method"] == "HF":
+        # virial theorem at the HF limit
+        assert abs(-(r["Etot"] - r["Ekin"]) / r["Ekin"] - 2.0) < 1e-5
+    if name == "He_LDA":
+        # NIST atomic reference data, He LDA: Ekin = 2.767922, Ecoul = 1.996120, Eenuc = -6.625564, Exc = -0.973314
+        for k, v in (("Ekin", 2.767922), ("Ecoul", 1.996120), ("Epot", -6.625564), ("Exc", -0.973314)):
+            assert abs(r[k] - v) < 2e-6, (k, r[k], v)
+
+
+def test_atomic_grid_electron_count_and_exchange_energy():
+    """He 1s^2 with the exact hydrogenic orbital shape: Tr PS = 2 and E_x^{HF} = -E_J/2 for a two-electron singlet"""
+    import common
+    _, ob = common.make_atomic_bases(2, 0, 0, 5, 15, product=False)
+    ob.compute_tei(True)
+    import scipy.linalg
+    S, T, V = ob.onebody("overlap"), ob.onebody("kinetic"), ob.onebody("nuclear")
+    E, C = scipy.linalg.eigh(T + V, S)
+    Pa = np.outer(C[:, 0], C[:, 0])
+    J = ob.coulomb(2 * Pa)
+    K = ob.exchange(Pa)
+    EJ = 0.5 * np.sum(2 * Pa * J)
+    EK = np.sum(Pa * K)
+    assert abs(EJ - 2 * 5.0 / 8.0 * 2) < 1e-8          # J_1s1s = 5Z/8, E_J = 2 J  (Z=2)
+    assert abs(EK + 0.5 * EJ) < 1e-10
+    H, Exc, Nel, _ = ob.eval_Fxc(10, 5, 1, 0, 2 * Pa)
+    assert abs(Nel - 2.0) < 1e-9

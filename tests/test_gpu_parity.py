@@ -159,6 +159,95 @@ def test_form_density_parity(case, hf):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Fock build parity: atomic J, K, XC against the oracle (BASELINE configs 1 and 2 run on this path)
+# ---------------------------------------------------------------------------------------------------
+ATOMIC_CASES = {
+    # name: (Z, lmax, mmax, nelem, nnodes)
+    "s_only": (2, 0, 0, 3, 6),
+    "sp": (10, 1, 1, 3, 5),
+    "spd_m1": (18, 2, 1, 2, 6),
+    "spdf_full": (4, 3, 3, 1, 5),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(ATOMIC_CASES))
+def acase(request, hf):
+    import common
+    Z, lmax, mmax, nelem, nnodes = ATOMIC_CASES[request.param]
+    gb, ob = common.make_atomic_bases(Z, lmax, mmax, nelem, nnodes)
+    gb.compute_tei(True)
+    ob.compute_tei(True)
+    ldft, mdft = 4 * lmax + 10, 4 * mmax + 5
+    gb.upload(ldft, mdft)
+    return request.param, gb, ob, ldft, mdft
+
+
+def test_atomic_one_electron_matrices(acase):
+    import common
+    name, gb, ob, _, _ = acase
+    assert gb.Nbf() == ob.Nbf
+    for which, M in (("overlap", gb.overlap()), ("kinetic", gb.kinetic()), ("nuclear", gb.nuclear())):
+        assert common.relerr(M, ob.onebody(which)) < 1e-14, (name, which)
+
+
+def test_atomic_coulomb_parity(acase):
+    import common
+    name, gb, ob, _, _ = acase
+    for tag, P in _densities(gb):
+        J = gb.coulomb(P)
+        Jo = ob.coulomb(P)
+        assert common.relerr(J, Jo) < 1e-12, (name, tag, common.relerr(J, Jo))
+
+
+def test_atomic_exchange_parity(acase):
+    import common
+    name, gb, ob, _, _ = acase
+    for tag, P in _densities(gb):
+        K = gb.exchange(P)
+        Ko = ob.exchange(P)
+        assert common.relerr(K, Ko) < 1e-12, (name, tag, common.relerr(K, Ko))
+
+
+@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (101, 0), (0, 130), (1, 12)])
+def test_atomic_xc_parity(acase, hf, funcs):
+    import common
+    name, gb, ob, ldft, mdft = acase
+    grid = hf.DFTGrid(gb, ldft, mdft)
+    x, c = funcs
+    for tag, P in _densities(gb):
+        if tag == "general":
+            P = 0.05 * P + list(_densities(gb))[1][1]
+        H, Exc, Nel, _ = grid.eval_Fxc(x, c, P)
+        Ho, Exco, Nelo, _ = ob.eval_Fxc(ldft, mdft, x, c, P)
+        assert abs(Nel - Nelo) < 1e-11 * max(1.0, abs(Nelo)), (name, tag, Nel, Nelo)
+        assert abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco)), (name, tag, Exc, Exco)
+        assert common.relerr(H, Ho) < 1e-10, (name, tag, funcs, common.relerr(H, Ho))
+
+
+ATOMIC_SCF_CASES = [
+    # BASELINE config 1: He, LDA (NIST reference-data total energy) ; config 2-like: Ne / Be with l up to 1
+    ("He_LDA", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -2.834836, 2e-6),
+    ("He_PBE", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="gga_x_pbe-gga_c_pbe"), -2.892935, 2e-6),
+    ("He_HF", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF"), -2.8616799956, 1e-8),
+    ("Be_HF", dict(Z=4, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF"), -14.573023168, 1e-7),
+    ("Ne_HF", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="HF"), -128.54709811, 1e-7),
+    ("Ne_LDA", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -128.233481, 2e-6),
+]
+
+
+@pytest.mark.parametrize("name,kw,lit,littol", ATOMIC_SCF_CASES, ids=[c[0] for c in ATOMIC_SCF_CASES])
+def test_atomic_scf_energy_parity(hf, name, kw, lit, littol):
+    import oracle_lib as orc
+    g = hf.scf_atomic(convthr=1e-9, maxit=60, **kw)
+    o = orc.scf_atomic(convthr=1e-9, maxit=60, **kw)
+    assert g["converged"] and o["converged"]
+    assert abs(g["Etot"] - o["Etot"]) < 1e-8 * max(1.0, abs(o["Etot"]) / 10), (name, g["Etot"], o["Etot"])
+    for k in ("Ekin", "Epot", "Ecoul", "Exx", "Exc"):
+        assert abs(g[k] - o[k]) < 1e-6 * max(1.0, abs(o[k]) / 10), (name, k, g[k], o[k])
+    assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
+
+
+# ---------------------------------------------------------------------------------------------------
 # end-to-end SCF: converged total energies, GPU vs oracle on identical grids (north-star bar: 1e-8 Eh)
 # ---------------------------------------------------------------------------------------------------
 SCF_CASES = [
