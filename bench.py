@@ -156,6 +156,16 @@ def main():
         avg_ms = gemv_ms / gemv_launches if gemv_launches else 0.0
         trd_ms = fams["eig_tridiag"]["ms_per_step"]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM-side bytes per launch of the same kernel from the committed PMC passes of this command
+        # (tools/gpu_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 guide
+        # prescribes; tools/pmc_traffic.py).  The counters cannot be collected from inside this process.
+        traffic = None
+        try:
+            if args.workload == "n2_pbe_nbf4230" and world == 1:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                    traffic = json.load(fh)["hfg::k_trdb_gemv"]["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "scf_iteration_wall_time_fock_plus_geneig_nbf4230" if args.workload == "n2_pbe_nbf4230"
             else "scf_iteration_wall_time_" + args.workload,
@@ -167,7 +177,7 @@ def main():
                                    "eig_gsym_sub + density per step" % (N, basis.Nang(), basis.Nrad(), ldft, mdft, sizes),
                        "name": args.workload, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "hfg::k_trdb_gemv", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_ms * 1e3, "launches_per_step": launches_per_step,
                          "note": "latency-bound: 2 dependent launches per Householder column (see DESIGN.md 3.4)"},
