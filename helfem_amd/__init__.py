@@ -78,6 +78,8 @@ def lib():
         L.hfg_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]
         L.hfg_xc_fock.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                   c_double_p, c_double_p, c_double_p, ctypes.c_double]
+        L.hfg_xc_fock_pol.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double]
         L.hfg_xc_fock_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
         L.hfg_profile_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, c_double_p, c_i64_p]
@@ -321,6 +323,18 @@ class DFTGrid(object):
                                  ctypes.byref(nel), ctypes.byref(ekin), float(thr)))
         return H, exc.value, nel.value, ekin.value
 
+    def eval_Fxc_pol(self, x_func, c_func, Pa, Pb, thr=1e-12):
+        """returns (Ha, Hb, Exc, Nel, Ekin) — DFTGrid::eval_Fxc, unrestricted (dftgrid.cpp:812)."""
+        b = self.basis
+        if b._uploaded != (self.ldft, self.mdft):
+            b.upload(self.ldft, self.mdft)
+        Pa, Pb = _f(Pa), _f(Pb)
+        Ha, Hb = np.zeros_like(Pa, order="F"), np.zeros_like(Pb, order="F")
+        exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(lib().hfg_xc_fock_pol(b.ctx.h, b.h, int(x_func), int(c_func), _p(Pa), _p(Pb), _p(Ha), _p(Hb),
+                                     ctypes.byref(exc), ctypes.byref(nel), ctypes.byref(ekin), float(thr)))
+        return Ha, Hb, exc.value, nel.value, ekin.value
+
 
 class scf(object):
     """namespace helfem::scf (src/general/scf_helpers.h)."""
@@ -433,19 +447,19 @@ def lobatto_nodes(n):
 
 
 def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0, igrid=4, zexp=1.0, lpad=10, ldft=0,
-                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None):
-    """Restricted closed-shell diatomic SCF with every per-iteration step on the GPU
+                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1):
+    """Restricted closed-shell (M=1) or unrestricted (M=2S+1>1) diatomic SCF with every per-iteration step on the GPU
     (the loop of src/diatomic/main.cpp:780-995; flags as in main.cpp:89-133)."""
     ctx = ctx or default_context()
     L = lib()
     L.hfg_scf_diatomic.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_int_p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                    ctypes.c_double, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
-                                   ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p]
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p]
     out = np.zeros(12)
     lm = (ctypes.c_int * len(lmmax))(*lmmax)
     _check(L.hfg_scf_diatomic(ctx.h, Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
-                              method.encode(), ldft, mdft, symmetry, maxit, convthr, verbose, _p(out)))
+                              method.encode(), ldft, mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])
@@ -455,17 +469,17 @@ def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0
 
 
 def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
-               symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None):
-    """Restricted closed-shell atomic SCF with every per-iteration step on the GPU
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1):
+    """Restricted closed-shell (M=1) or unrestricted (M=2S+1>1) atomic SCF with every per-iteration step on the GPU
     (the loop of src/atomic/main.cpp:760-1005; flags as in main.cpp:66-100)."""
     ctx = ctx or default_context()
     L = lib()
     L.hfg_scf_atomic.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int,
-                                ctypes.c_double, ctypes.c_char_p] + [ctypes.c_int] * 4 + [ctypes.c_double,
+                                ctypes.c_double, ctypes.c_char_p] + [ctypes.c_int] * 5 + [ctypes.c_double,
                                 ctypes.c_int, c_double_p]
     out = np.zeros(12)
     _check(L.hfg_scf_atomic(ctx.h, Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft,
-                            mdft, symmetry, maxit, convthr, verbose, _p(out)))
+                            mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])

@@ -14,6 +14,8 @@ void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr);
 void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
+                     double *dHa, double *dHb, double *dScal, double thr);
 void fock_release(hfg_dev_tables *t);
 size_t fock_compact_size(hfg_basis *basis);
 void fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dFc,
@@ -360,6 +362,11 @@ int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const do
   HFG_TRY xc_fock_dev(ctx, b, x_func, c_func, dP, dH, dScal, thr);
   HFG_CATCH
 }
+int hfg_xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *dPa, const double *dPb,
+                        double *dHa, double *dHb, double *dScal, double thr) {
+  HFG_TRY xc_fock_pol_dev(ctx, b, x_func, c_func, dPa, dPb, dHa, dHb, dScal, thr);
+  HFG_CATCH
+}
 int hfg_eig_gsym_sub_dev(hfg_ctx *ctx, int64_t N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                          const int64_t *blk_idx, double *dE, double *dC) {
   HFG_TRY eig_gsym_sub_dev(ctx, (int)N, dF, dS, nblk, blk_ptr, blk_idx, dE, dC);
@@ -428,6 +435,24 @@ int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double
   xc_fock_dev(ctx, b, x_func, c_func, dP, dH, dS, thr);
   double sc[3];
   st.down(H, dH, N * N);
+  st.down(sc, dS, 3);
+  st.sync();
+  *Exc = sc[0];
+  *Nel = sc[1];
+  *Ekin = sc[2];
+  HFG_CATCH
+}
+int hfg_xc_fock_pol(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *Pa, const double *Pb, double *Ha,
+                    double *Hb, double *Exc, double *Nel, double *Ekin, double thr) {
+  HFG_TRY
+  size_t N = b->Nbf();
+  Stage st(ctx);
+  double *dPa = st.up(Pa, N * N), *dPb = st.up(Pb, N * N);
+  double *dHa = st.alloc(N * N), *dHb = st.alloc(N * N), *dS = st.alloc(3);
+  xc_fock_pol_dev(ctx, b, x_func, c_func, dPa, dPb, dHa, dHb, dS, thr);
+  double sc[3];
+  st.down(Ha, dHa, N * N);
+  st.down(Hb, dHb, N * N);
   st.down(sc, dS, 3);
   st.sync();
   *Exc = sc[0];

@@ -485,6 +485,144 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
   }
 }
 
+// X3 for a spin-polarised density (DFTGridWorker::update_density(Pa,Pb), compute_xc, eval_Fxc(Ha,Hb,beta);
+//    dftgrid.cpp:119-170, 343-458, 547-613): V and Fo hold the alpha planes (0..2) followed by the beta planes (3..5).
+__global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__restrict__ rad_w,
+                              const double *__restrict__ rad_sh, const double *__restrict__ th_s,
+                              const double *__restrict__ th_w, const int *__restrict__ grp_m,
+                              const double *__restrict__ cosd, const double *__restrict__ sind, int Dmax, int G, int nth,
+                              int nphi, double Rh, int geom, int x_func, int c_func, int do_grad, double thr, size_t NQ,
+                              int rank, int nranks, double *__restrict__ Fo, double *__restrict__ partial /* [2][NQ] */) {
+  extern __shared__ double sh[];  // pot[8][nth*nphi], red[2*nwave]
+  size_t Q = blockIdx.x;
+  if ((int)(Q % nranks) != rank) {
+    if (threadIdx.x == 0) {
+      partial[Q] = 0.0;
+      partial[NQ + Q] = 0.0;
+    }
+    return;
+  }
+  int ng = nth * nphi;
+  double *red = sh + 8 * ng;
+  double shm = rad_sh[Q], wr = rad_w[Q];
+  double dphi = 2.0 * HFG_PI / nphi;
+  size_t stride = NQ * G * G * nth;
+  double nel = 0.0, exc_sum = 0.0;
+  for (int pt = threadIdx.x; pt < ng; pt += blockDim.x) {
+    int i = pt / nphi, j = pt % nphi;
+    double sth = th_s[i];
+    double hmu, hnu, hphi, w;
+    if (geom == 0) {
+      double h2 = shm * shm + sth * sth;
+      hmu = hnu = Rh * sqrt(h2);
+      hphi = Rh * shm * sth;
+      w = th_w[i] * dphi * wr * Rh * Rh * Rh * shm * h2;
+    } else {
+      hmu = 1.0;
+      hnu = shm;
+      hphi = shm * sth;
+      w = th_w[i] * dphi * wr * shm * shm;
+    }
+    double rho[2] = {0.0, 0.0}, gmu[2] = {0.0, 0.0}, gnu[2] = {0.0, 0.0}, gphi[2] = {0.0, 0.0};
+    for (int ga = 0; ga < G; ga++)
+      for (int gb = 0; gb < G; gb++) {
+        int D = grp_m[ga] - grp_m[gb];
+        double cd = cosd[(size_t)(D + Dmax) * nphi + j];
+        double sd = sind[(size_t)(D + Dmax) * nphi + j];
+        size_t o = ((Q * G + ga) * G + gb) * nth + i;
+        for (int sp = 0; sp < 2; sp++) {
+          const double *Vs = V + (size_t)sp * 3 * stride;
+          double vr = Vs[o];
+          rho[sp] += cd * vr;
+          if (do_grad) {
+            gnu[sp] += cd * Vs[stride + o];
+            gmu[sp] += cd * Vs[2 * stride + o];
+            gphi[sp] -= grp_m[ga] * sd * vr;
+          }
+        }
+      }
+    double saa = 0.0, sab = 0.0, sbb = 0.0;
+    if (do_grad) {
+      for (int sp = 0; sp < 2; sp++) {
+        gmu[sp] *= 2.0 / hmu;
+        gnu[sp] *= 2.0 / hnu;
+        gphi[sp] *= 2.0 / hphi;
+      }
+      saa = gmu[0] * gmu[0] + gnu[0] * gnu[0] + gphi[0] * gphi[0];
+      sab = gmu[0] * gmu[1] + gnu[0] * gnu[1] + gphi[0] * gphi[1];
+      sbb = gmu[1] * gmu[1] + gnu[1] * gnu[1] + gphi[1] * gphi[1];
+    }
+    double exc = 0.0, va = 0.0, vb = 0.0, vsaa = 0.0, vsab = 0.0, vsbb = 0.0;
+    const double rt = rho[0] + rho[1];
+    if (rt >= thr && rt > 0.0) {
+      double ra = fmax(rho[0], thr), rb = fmax(rho[1], thr);
+      if (x_func > 0) xc::eval_add_pol(x_func, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+      if (c_func > 0) xc::eval_add_pol(c_func, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+    }
+    nel += w * rt;
+    exc_sum += w * exc * rt;
+    sh[0 * ng + pt] = w * va;
+    sh[4 * ng + pt] = w * vb;
+    if (do_grad) {
+      // gr_a = w (2 vs_aa grad rho_a + vs_ab grad rho_b) / h ; gr_b likewise   (dftgrid.cpp:583-601)
+      sh[1 * ng + pt] = w * (2.0 * vsaa * gmu[0] + vsab * gmu[1]) / hmu;
+      sh[2 * ng + pt] = w * (2.0 * vsaa * gnu[0] + vsab * gnu[1]) / hnu;
+      sh[3 * ng + pt] = w * (2.0 * vsaa * gphi[0] + vsab * gphi[1]) / hphi;
+      sh[5 * ng + pt] = w * (2.0 * vsbb * gmu[1] + vsab * gmu[0]) / hmu;
+      sh[6 * ng + pt] = w * (2.0 * vsbb * gnu[1] + vsab * gnu[0]) / hnu;
+      sh[7 * ng + pt] = w * (2.0 * vsbb * gphi[1] + vsab * gphi[0]) / hphi;
+    }
+  }
+  int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+  for (int o = 32; o > 0; o >>= 1) {
+    nel += __shfl_down(nel, o, 64);
+    exc_sum += __shfl_down(exc_sum, o, 64);
+  }
+  if (lane == 0) {
+    red[wave] = nel;
+    red[nwave + wave] = exc_sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < nwave; w++) {
+      a += red[w];
+      b += red[nwave + w];
+    }
+    partial[Q] = a;
+    partial[NQ + Q] = b;
+  }
+  int nout = G * G * nth;
+  for (int t = threadIdx.x; t < 2 * nout; t += blockDim.x) {
+    int sp = t / nout, tt = t % nout;
+    int i = tt % nth;
+    int gab = tt / nth;
+    int ga = gab / G, gb = gab % G;
+    int D = grp_m[ga] - grp_m[gb];
+    const double *cd = cosd + (size_t)(D + Dmax) * nphi;
+    const double *sd = sind + (size_t)(D + Dmax) * nphi;
+    const double *p0 = sh + (size_t)(4 * sp) * ng, *p1 = p0 + ng, *p2 = p0 + 2 * ng, *p3 = p0 + 3 * ng;
+    double fa = 0.0, fs = 0.0, fb = 0.0;
+    double mga = grp_m[ga];
+    for (int j = 0; j < nphi; j++) {
+      int pt = i * nphi + j;
+      fa += 0.5 * p0[pt] * cd[j];
+      if (do_grad) {
+        fa -= mga * p3[pt] * sd[j];
+        fs += p2[pt] * cd[j];
+        fb += p1[pt] * cd[j];
+      }
+    }
+    size_t o = ((Q * G + ga) * G + gb) * nth + i;
+    double *Fs = Fo + (size_t)sp * 3 * stride;
+    Fs[o] = fa;
+    if (do_grad) {
+      Fs[stride + o] = fs;
+      Fs[2 * stride + o] = fb;
+    }
+  }
+}
+
 // X4 theta expansion: GA[Q][a][b] = sum_i Theta_a Theta_b Fo0 + dTheta_a Theta_b Fo1 ; GB[Q][a][b] = sum_i Theta_a Theta_b Fo2
 __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__restrict__ Th,
                                 const double *__restrict__ dTh, int A, int nth, int G,
@@ -572,7 +710,7 @@ static int round_up64(int n) { return ((n + 63) / 64) * 64; }
 
 struct FockAux {
   DevBuf<int> pure_shell, pure_n, lmpos;
-  DevBuf<double> Pc, Jc, Paux, Y, Jaux, D0, D1, V, Fo, GA, GB, partial, scal;
+  DevBuf<double> Pc, Jc, Pc2, Jc2, Paux, Y, Jaux, D0, D1, V, Fo, GA, GB, partial, scal;
 };
 
 static std::map<hfg_dev_tables *, FockAux *> g_aux;
@@ -723,6 +861,72 @@ void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const d
   gather_compact(ctx, basis, dP, a.Pc.p);
   xc_compact(ctx, basis, x_func, c_func, a.Pc.p, a.Jc.p, dScal, thr);
   scatter_dense(ctx, basis, a.Jc.p, dH);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+// spin-polarised XC: Hc_a, Hc_b (compact) from Pc_a, Pc_b (compact); dScal = (Exc, Nel, 0)
+void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPca, const double *dPcb,
+                    double *dHca, double *dHcb, double *dScal, double thr) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  if (!t->have_xc) throw std::runtime_error("XC grid tables were not uploaded (hfg_basis_upload with ldft,mdft > 0)\n");
+  if ((x_func > 0 && !xc::is_supported(x_func)) || (c_func > 0 && !xc::is_supported(c_func)))
+    throw std::runtime_error("Functional not found!");
+  FockAux &a = aux_for(ctx, basis);
+  const int A = t->A, E = t->E, p = t->p, nq = t->nq, G = t->G, nth = t->ntheta, nphi = t->nphi;
+  const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
+  int do_grad = ((x_func > 0 && xc::is_gga(x_func)) || (c_func > 0 && xc::is_gga(c_func))) ? 1 : 0;
+  a.D0.resize(NQ * AA);
+  a.D1.resize(NQ * AA);
+  a.GA.resize(NQ * AA);
+  a.GB.resize(NQ * AA);
+  const size_t nv = NQ * G * G * nth;
+  a.V.resize(6 * nv);
+  a.Fo.resize(6 * nv);
+  a.partial.resize(2 * NQ);
+  int maxgrp = 0;
+  for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
+  for (int sp = 0; sp < 2; sp++) {
+    hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(std::min(256, round_up64(nq))), p * p * sizeof(double),
+                       ctx->stream, sp ? dPcb : dPca, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank,
+                       ctx->shard_n, a.D0.p, a.D1.p);
+    hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
+                       2 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, t->Th.p, t->dTh.p, A, nth, G,
+                       t->grp_off.p, t->grp_shell.p, do_grad, NQ, ctx->shard_rank, ctx->shard_n, a.V.p + (size_t)sp * 3 * nv);
+  }
+  size_t shb = (size_t)(8 * nth * nphi + 2 * 4) * sizeof(double);
+  if (shb > 160 * 1024) throw std::runtime_error("XC angular grid too large for the polarised grid kernel's LDS tile");
+  if (shb > 64 * 1024)
+    HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_grid_pol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+  hipLaunchKernelGGL(k_xc_grid_pol, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
+                     t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
+                     x_func, c_func, do_grad, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
+  for (int sp = 0; sp < 2; sp++) {
+    hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 3 * nth * sizeof(double), ctx->stream,
+                       a.Fo.p + (size_t)sp * 3 * nv, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad,
+                       NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p);
+    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 3 * nq * sizeof(double),
+                       ctx->stream, a.GA.p, a.GB.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank,
+                       ctx->shard_n, sp ? dHcb : dHca);
+  }
+  hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
+                     double *dHa, double *dHb, double *dScal, double thr) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  FockAux &a = aux_for(ctx, basis);
+  const size_t nc = (size_t)t->A * t->A * t->E * t->p * t->p;
+  a.Pc.resize(nc);
+  a.Jc.resize(nc);
+  a.Pc2.resize(nc);
+  a.Jc2.resize(nc);
+  ProfScope ps(ctx, "xc");
+  gather_compact(ctx, basis, dPa, a.Pc.p);
+  gather_compact(ctx, basis, dPb, a.Pc2.p);
+  xc_compact_pol(ctx, basis, x_func, c_func, a.Pc.p, a.Pc2.p, a.Jc.p, a.Jc2.p, dScal, thr);
+  scatter_dense(ctx, basis, a.Jc.p, dHa);
+  scatter_dense(ctx, basis, a.Jc2.p, dHb);
   HFG_HIP_CHECK(hipGetLastError());
 }
 

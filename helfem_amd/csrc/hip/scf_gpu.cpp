@@ -58,6 +58,12 @@ struct GPUBackend : public helfem::scf::Backend {
     H.zeros(P.n_rows, P.n_cols);
     chk(hfg_xc_fock(ctx, hb, x, c, P.memptr(), H.memptr(), &Exc, &Nel, &Ekin, thr));
   }
+  void eval_Fxc_pol(int x, int c, const Mat &Pa, const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin,
+                    double thr) override {
+    Ha.zeros(Pa.n_rows, Pa.n_cols);
+    Hb.zeros(Pa.n_rows, Pa.n_cols);
+    chk(hfg_xc_fock_pol(ctx, hb, x, c, Pa.memptr(), Pb.memptr(), Ha.memptr(), Hb.memptr(), &Exc, &Nel, &Ekin, thr));
+  }
   void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh, const std::vector<std::vector<size_t> > &sym) override {
     std::vector<int64_t> ptr, idx;
     blocks(sym, ptr, idx);
@@ -92,9 +98,10 @@ extern "C" {
 /// out[8..11] = seconds of the last iteration's J, K, XC, diagonalisation
 int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmmax, int nlm, int nelem, int nnodes,
                      int nquad, double Rmax, int igrid, double zexp, int lpad, const char *method, int ldft, int mdft,
-                     int symmetry, int maxit, double convthr, int verbose, double *out) {
+                     int symmetry, int multiplicity, int maxit, double convthr, int verbose, double *out) {
   try {
     helfem::scf::Options o;
+    o.multiplicity = multiplicity;
     o.Z1 = Z1;
     o.Z2 = Z2;
     o.Rbond = Rbond;
@@ -137,10 +144,11 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
 }
 
 int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax,
-                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int maxit,
+                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity, int maxit,
                    double convthr, int verbose, double *out) {
   try {
     helfem::scf::AtomicOptions a;
+    a.common.multiplicity = multiplicity;
     a.Z = Z;
     a.Q = Q;
     a.lmax = lmax;

@@ -1,4 +1,4 @@
-// Spin-unpolarised exchange-correlation functionals evaluated on the GPU grid (reference: the
+// Exchange-correlation functionals (spin-unpolarised and spin-polarised) evaluated on the GPU grid (reference: the
 // libxc calls of DFTGridWorker::compute_xc, src/diatomic/dftgrid.cpp:343-458).  libxc is a
 // third-party dependency of the reference that is not vendored and not present here; the energy
 // densities below are the published closed forms and the derivatives vrho = d(rho exc)/d rho,
@@ -79,7 +79,7 @@ __host__ __device__ inline Dual eps_lda_c_vwn(Dual rho) {
 }
 
 __host__ __device__ inline Dual eps_pw92(Dual rs, bool mod) {
-  const double a = mod ? 0.0310906908696549 : 0.031091;
+  const double a = mod ? 0.0310907 : 0.031091;  // libxc lda_c_pw.c: par_pw / par_pw_mod
   const double a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
   Dual srs = dsqrt(rs);
   Dual den = (2.0 * a) * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
@@ -136,6 +136,151 @@ __host__ __device__ inline void eval_add(int id, double rho, double sigma, doubl
   exc += e.v;
   vrho += en.dr;
   vsigma += en.ds;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Spin-polarised evaluation (xc_*_exc_vxc with XC_POLARIZED; dftgrid.cpp:343-458 with rho 2 x N, sigma 3 x N).
+// Exchange: spin scaling E_x[ra,rb] = (E_x[2ra] + E_x[2rb])/2 through the two-component duals above.
+// Correlation: three-component duals in (rho_a, rho_b, sigma_total).
+// ---------------------------------------------------------------------------------------------------------
+struct T3 {
+  double v, a, b, s;
+};
+__host__ __device__ inline T3 t3(double v, double a = 0.0, double b = 0.0, double s = 0.0) {
+  T3 r;
+  r.v = v;
+  r.a = a;
+  r.b = b;
+  r.s = s;
+  return r;
+}
+__host__ __device__ inline T3 t3f(T3 x, double f, double df) { return t3(f, df * x.a, df * x.b, df * x.s); }
+__host__ __device__ inline T3 operator+(T3 x, T3 y) { return t3(x.v + y.v, x.a + y.a, x.b + y.b, x.s + y.s); }
+__host__ __device__ inline T3 operator-(T3 x, T3 y) { return t3(x.v - y.v, x.a - y.a, x.b - y.b, x.s - y.s); }
+__host__ __device__ inline T3 operator-(T3 x) { return t3(-x.v, -x.a, -x.b, -x.s); }
+__host__ __device__ inline T3 operator*(T3 x, T3 y) {
+  return t3(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b, x.s * y.v + x.v * y.s);
+}
+__host__ __device__ inline T3 operator/(T3 x, T3 y) {
+  double inv = 1.0 / y.v, q = x.v * inv;
+  return t3(q, (x.a - q * y.a) * inv, (x.b - q * y.b) * inv, (x.s - q * y.s) * inv);
+}
+__host__ __device__ inline T3 operator+(T3 x, double c) { return t3(x.v + c, x.a, x.b, x.s); }
+__host__ __device__ inline T3 operator+(double c, T3 x) { return t3(x.v + c, x.a, x.b, x.s); }
+__host__ __device__ inline T3 operator-(T3 x, double c) { return t3(x.v - c, x.a, x.b, x.s); }
+__host__ __device__ inline T3 operator-(double c, T3 x) { return t3(c - x.v, -x.a, -x.b, -x.s); }
+__host__ __device__ inline T3 operator*(T3 x, double c) { return t3(x.v * c, x.a * c, x.b * c, x.s * c); }
+__host__ __device__ inline T3 operator*(double c, T3 x) { return t3(x.v * c, x.a * c, x.b * c, x.s * c); }
+__host__ __device__ inline T3 operator/(T3 x, double c) { return x * (1.0 / c); }
+__host__ __device__ inline T3 operator/(double c, T3 x) { return t3(c) / x; }
+__host__ __device__ inline T3 tsqrt(T3 x) {
+  double r = sqrt(x.v);
+  return t3f(x, r, 0.5 / r);
+}
+__host__ __device__ inline T3 tcbrt(T3 x) {
+  double c = cbrt(x.v);
+  return t3f(x, c, c / (3.0 * x.v));
+}
+__host__ __device__ inline T3 tlog(T3 x) { return t3f(x, log(x.v), 1.0 / x.v); }
+__host__ __device__ inline T3 texp(T3 x) {
+  double e = exp(x.v);
+  return t3f(x, e, e);
+}
+__host__ __device__ inline T3 tatan(T3 x) { return t3f(x, atan(x.v), 1.0 / (1.0 + x.v * x.v)); }
+__host__ __device__ inline T3 tpow43(T3 x) {
+  double c = cbrt(x.v);
+  return t3f(x, x.v * c, (4.0 / 3.0) * c);
+}
+__host__ __device__ inline T3 tpow23(T3 x) {
+  double c = cbrt(x.v);
+  return t3f(x, c * c, 2.0 / (3.0 * c));
+}
+
+__host__ __device__ inline T3 pol_fzeta(T3 z) {
+  return (tpow43(1.0 + z) + tpow43(1.0 - z) - 2.0) / (2.0 * 1.2599210498948732 - 2.0);
+}
+__host__ __device__ inline T3 pol_vwn_fit(T3 x, double A, double b, double c, double x0) {
+  T3 X = x * x + b * x + c;
+  const double X0 = x0 * x0 + b * x0 + c, Q = sqrt(4.0 * c - b * b);
+  T3 at = tatan(Q / (2.0 * x + b));
+  T3 xm = x - x0;
+  return A * (tlog(x * x / X) + (2.0 * b / Q) * at - (b * x0 / X0) * (tlog(xm * xm / X) + (2.0 * (b + 2.0 * x0) / Q) * at));
+}
+__host__ __device__ inline T3 pol_eps_vwn(T3 rs, T3 z) {
+  T3 x = tsqrt(rs);
+  T3 eP = pol_vwn_fit(x, 0.0310907, 3.72744, 12.9352, -0.10498);
+  T3 eF = pol_vwn_fit(x, 0.01554535, 7.06042, 18.0578, -0.32500);
+  T3 al = pol_vwn_fit(x, -1.0 / (6.0 * HFG_PI * HFG_PI), 1.13107, 13.0045, -0.0047584);
+  const double fpp = 4.0 / (9.0 * (1.2599210498948732 - 1.0));
+  T3 f = pol_fzeta(z), z2 = z * z;
+  T3 z4 = z2 * z2;
+  return eP + al * f * (1.0 - z4) / fpp + (eF - eP) * f * z4;
+}
+__host__ __device__ inline T3 pol_pw_G(T3 rs, double A, double a1, double b1, double b2, double b3, double b4) {
+  T3 s = tsqrt(rs);
+  T3 den = (2.0 * A) * (b1 * s + b2 * rs + b3 * rs * s + b4 * rs * rs);
+  return (-2.0 * A) * (1.0 + a1 * rs) * tlog(1.0 + 1.0 / den);
+}
+__host__ __device__ inline T3 pol_eps_pw(T3 rs, T3 z, bool mod) {
+  T3 e0 = pol_pw_G(rs, mod ? 0.0310907 : 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+  T3 e1 = pol_pw_G(rs, mod ? 0.01554535 : 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+  T3 mac = pol_pw_G(rs, mod ? 0.0168869 : 0.016887, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);
+  const double fz20 = mod ? 1.709920934161365617563962776245 : 1.709921;
+  T3 f = pol_fzeta(z), z2 = z * z;
+  T3 z4 = z2 * z2;
+  return e0 - mac * f * (1.0 - z4) / fz20 + (e1 - e0) * f * z4;
+}
+__host__ __device__ inline T3 pol_eps_pbe_c(T3 n, T3 rs, T3 z, T3 sig) {
+  const double beta = 0.06672455060314922;
+  const double gamma = (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI);
+  const double B = beta / gamma;
+  T3 ec = pol_eps_pw(rs, z, true);
+  T3 phi = 0.5 * (tpow23(1.0 + z) + tpow23(1.0 - z));
+  T3 phi3 = phi * phi * phi;
+  T3 kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
+  T3 ks2 = (4.0 / HFG_PI) * kf;
+  T3 t2 = sig / (4.0 * phi * phi * ks2 * n * n);
+  T3 Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
+  T3 At2 = Aa * t2;
+  return ec + gamma * phi3 * tlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+}
+
+/// adds functional id's exc (per particle of ra+rb), vrho[2], vsigma[3] (aa, ab, bb); ra + rb >= threshold assumed,
+/// ra, rb already raised to the threshold
+__host__ __device__ inline void eval_add_pol(int id, double ra, double rb, double saa, double sab, double sbb, double &exc,
+                                             double &va, double &vb, double &vsaa, double &vsab, double &vsbb) {
+  const double rt = ra + rb;
+  if (id == 1 || id == 101) {
+    Dual a = mk(2.0 * ra, 1.0, 0.0), b = mk(2.0 * rb, 1.0, 0.0);
+    Dual sa = mk(4.0 * saa, 0.0, 1.0), sb = mk(4.0 * sbb, 0.0, 1.0);
+    Dual ea = (id == 1) ? eps_lda_x(a) : eps_gga_x_pbe(a, sa);
+    Dual eb = (id == 1) ? eps_lda_x(b) : eps_gga_x_pbe(b, sb);
+    Dual na = a * ea, nb = b * eb;  // energy per volume of the doubled densities
+    exc += 0.5 * (na.v + nb.v) / rt;
+    va += na.dr;          // d/d ra [ (1/2) n(2 ra) ] = n'(2 ra)
+    vb += nb.dr;
+    vsaa += 2.0 * na.ds;  // d/d saa [ (1/2) n(.., 4 saa) ]
+    vsbb += 2.0 * nb.ds;
+    return;
+  }
+  T3 a = t3(ra, 1.0, 0.0, 0.0), b = t3(rb, 0.0, 1.0, 0.0), st = t3(saa + 2.0 * sab + sbb, 0.0, 0.0, 1.0);
+  T3 n = a + b;
+  T3 rs = tcbrt((3.0 / (4.0 * HFG_PI)) / n);
+  T3 z = (a - b) / n;
+  T3 e;
+  switch (id) {
+    case 7: e = pol_eps_vwn(rs, z); break;
+    case 12: e = pol_eps_pw(rs, z, false); break;
+    case 130: e = pol_eps_pbe_c(n, rs, z, st); break;
+    default: return;
+  }
+  T3 en = n * e;
+  exc += e.v;
+  va += en.a;
+  vb += en.b;
+  vsaa += en.s;
+  vsab += 2.0 * en.s;
+  vsbb += en.s;
 }
 
 }  // namespace xc

@@ -105,7 +105,15 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   const bool verbose = opt.verbose;
   const bool dft = (opt.x_func > 0 || opt.c_func > 0);
   const int nel = pb.nel;
-  const size_t nocc = nel / 2;
+  // occupations (main.cpp:300-340): nela - nelb = M - 1
+  const int M = opt.multiplicity;
+  if (M < 1 || (nel + M - 1) % 2 != 0 || M - 1 > nel) throw std::logic_error("Requested multiplicity not achievable.\n");
+  const size_t nela = (nel + M - 1) / 2, nelb = nel - nela;
+  bool restr = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
+  if (restr && nela != nelb)
+    throw std::logic_error("Restricted open-shell (ROHF) runs are not implemented in this build.\n");
+  res.nela = (int)nela;
+  res.nelb = (int)nelb;
   const int symm = pb.symm;
   const Mat &S = pb.S, &T = pb.T, &Vnuc = pb.Vnuc;
   const std::vector<std::vector<size_t> > &dsym = pb.dsym;
@@ -115,10 +123,14 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   if (verbose) printf("Half-inverse formed in %.6f\n", wall() - t0);
 
   // core guess (main.cpp:655-660 with point nuclei == T+Vnuc)
-  Vec E;
-  Mat C;
+  Vec Ea, Eb;
+  Mat Ca, Cb;
   if (verbose) printf("Guess orbitals from core Hamiltonian\n");
-  be.eig_gsym_sub(E, C, H0, Sinvh, dsym);
+  be.eig_gsym_sub(Ea, Ca, H0, Sinvh, dsym);
+  if (!restr) {
+    Eb = Ea;
+    Cb = Ca;
+  }
 
   if (verbose) printf("Computing two-electron integrals\n");
   t0 = wall();
@@ -127,12 +139,17 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
 
   DIIS diis(opt.diisorder);
   double Eold = 0.0;
-  Mat P, F;
+  Mat P, Fa, Fb;
+  const size_t Nb = S.n_rows;
   for (int it = 1; it <= opt.maxit; it++) {
     if (verbose) printf("\n**** Iteration %i ****\n\n", it);
-    Mat Pa = form_density(C, nocc);
-    P = 2.0 * Pa;
-    if (verbose) printf("Tr Pa = %f\n", trace_prod(Pa, S));
+    Mat Pa = form_density(Ca, nela);
+    Mat Pb = restr ? Pa : form_density(Cb, nelb);
+    P = Pa + Pb;
+    if (verbose) {
+      printf("Tr Pa = %f\n", trace_prod(Pa, S));
+      if (!restr) printf("Tr Pb = %f\n", trace_prod(Pb, S));
+    }
     res.Ekin = trace_prod(P, T);
     res.Epot = trace_prod(P, Vnuc);
 
@@ -142,22 +159,28 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
     res.Ecoul = 0.5 * trace_prod(P, J);
     if (verbose) printf("Coulomb energy %.10e % .6f\n", res.Ecoul, res.tJ);
 
-    Mat Ka;
+    Mat Ka, Kb;
     res.Exx = 0.0;
     if (opt.kfrac != 0.0) {
       t0 = wall();
       Ka = opt.kfrac * be.exchange(Pa);
+      if (!restr) {
+        if (nelb) Kb = opt.kfrac * be.exchange(Pb);
+        else Kb.zeros(Nb, Nb);
+      }
       res.tK = wall() - t0;
-      res.Exx = trace_prod(Pa, Ka);  // 0.5 Tr PaKa + 0.5 Tr PbKb with Kb=Ka
+      // 0.5 Tr PaKa + 0.5 Tr PbKb (main.cpp:838-850)
+      res.Exx = restr ? trace_prod(Pa, Ka) : 0.5 * trace_prod(Pa, Ka) + 0.5 * trace_prod(Pb, Kb);
       if (verbose) printf("Exchange energy %.10e % .6f\n", res.Exx, res.tK);
     }
 
-    Mat XC;
+    Mat XCa, XCb;
     res.Exc = 0.0;
     if (dft) {
       t0 = wall();
       double nelnum = 0, ekin = 0;
-      be.eval_Fxc(opt.x_func, opt.c_func, P, XC, res.Exc, nelnum, ekin, opt.dftthr);
+      if (restr) be.eval_Fxc(opt.x_func, opt.c_func, P, XCa, res.Exc, nelnum, ekin, opt.dftthr);
+      else be.eval_Fxc_pol(opt.x_func, opt.c_func, Pa, Pb, XCa, XCb, res.Exc, nelnum, ekin, opt.dftthr);
       res.tXC = wall() - t0;
       if (verbose) {
         printf("DFT energy %.10e % .6f\n", res.Exc, res.tXC);
@@ -165,10 +188,16 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
       }
     }
 
-    F = H0 + J;
-    if (Ka.n_rows == F.n_rows) F += Ka;
-    if (dft) F += XC;
-    if (symm) F = enforce_sym(F, dsym);
+    Fa = H0 + J;
+    if (Ka.n_rows == Fa.n_rows) Fa += Ka;
+    if (dft) Fa += XCa;
+    if (symm) Fa = enforce_sym(Fa, dsym);
+    if (!restr) {
+      Fb = H0 + J;
+      if (Kb.n_rows == Fb.n_rows) Fb += Kb;
+      if (dft) Fb += XCb;
+      if (symm) Fb = enforce_sym(Fb, dsym);
+    }
 
     res.Etot = res.Ekin + res.Epot + res.Ecoul + res.Exx + res.Exc + res.Enucr;
     double dE = res.Etot - Eold;
@@ -178,25 +207,51 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
     }
     Eold = res.Etot;
 
-    // DIIS error Sinvh^T (F Pa S - S Pa F) Sinvh
+    // DIIS error Sinvh^T (F P S - S P F) Sinvh per spin; unrestricted: the two spin blocks side by side
+    // (uDIIS, diis.cpp:129-168)
     t0 = wall();
-    Mat FPS = be.gemm(be.gemm(F, false, Pa, false), false, S, false);
-    Mat err = FPS - FPS.t();
-    err = be.gemm(be.gemm(Sinvh, true, err, false), false, Sinvh, false);
+    auto diis_err = [&](const Mat &F, const Mat &Ps) {
+      Mat FPS = be.gemm(be.gemm(F, false, Ps, false), false, S, false);
+      Mat err = FPS - FPS.t();
+      return be.gemm(be.gemm(Sinvh, true, err, false), false, Sinvh, false);
+    };
+    Mat err, Fcat;
+    if (restr) {
+      err = diis_err(Fa, Pa);
+      Fcat = Fa;
+    } else {
+      Mat ea = diis_err(Fa, Pa), eb = diis_err(Fb, Pb);
+      err.zeros(ea.n_rows, 2 * ea.n_cols);
+      Fcat.zeros(Nb, 2 * Nb);
+      std::copy(ea.d.begin(), ea.d.end(), err.d.begin());
+      std::copy(eb.d.begin(), eb.d.end(), err.d.begin() + ea.d.size());
+      std::copy(Fa.d.begin(), Fa.d.end(), Fcat.d.begin());
+      std::copy(Fb.d.begin(), Fb.d.end(), Fcat.d.begin() + Fa.d.size());
+    }
     double diiserr = 0.0;
     for (double v : err.d) diiserr = std::max(diiserr, fabs(v));
     if (verbose) printf("DIIS error is %e, update done in %.6f\n", diiserr, wall() - t0);
-    diis.push(F, err);
+    diis.push(Fcat, err);
     Mat Fd = diis.solve();
 
     bool convd = (diiserr < opt.convthr) && (fabs(dE) < opt.convthr);
 
     t0 = wall();
-    be.eig_gsym_sub(E, C, Fd, Sinvh, dsym);
+    if (restr) {
+      be.eig_gsym_sub(Ea, Ca, Fd, Sinvh, dsym);
+    } else {
+      Mat Fda(Nb, Nb), Fdb(Nb, Nb);
+      std::copy(Fd.d.begin(), Fd.d.begin() + Nb * Nb, Fda.d.begin());
+      std::copy(Fd.d.begin() + Nb * Nb, Fd.d.end(), Fdb.d.begin());
+      be.eig_gsym_sub(Ea, Ca, Fda, Sinvh, dsym);
+      be.eig_gsym_sub(Eb, Cb, Fdb, Sinvh, dsym);
+    }
     res.tdiag = wall() - t0;
     if (verbose) {
       printf("%s diagonalization done in %.6f\n", symm ? "Subspace" : "Full", res.tdiag);
-      if (E.size() > nocc) printf("Alpha HOMO-LUMO gap is % .3f eV\n", (E[nocc] - E[nocc - 1]) * 27.211386);
+      if (Ea.size() > nela && nela) printf("Alpha HOMO-LUMO gap is % .3f eV\n", (Ea[nela] - Ea[nela - 1]) * 27.211386);
+      if (!restr && Eb.size() > nelb && nelb)
+        printf("Beta  HOMO-LUMO gap is % .3f eV\n", (Eb[nelb] - Eb[nelb - 1]) * 27.211386);
       fflush(stdout);
     }
     res.iterations = it;
@@ -205,10 +260,13 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
       break;
     }
   }
-  res.E = E;
-  res.C = C;
+  res.E = Ea;
+  res.C = Ca;
   res.P = P;
-  res.F = F;
+  res.F = Fa;
+  res.Eb = Eb;
+  res.Cb = Cb;
+  res.Fb = Fb;
   if (verbose) {
     printf("%-21s energy: % .16f\n", "Kinetic", res.Ekin);
     printf("%-21s energy: % .16f\n", "Nuclear attraction", res.Epot);
@@ -228,7 +286,6 @@ Result run_diatomic(const Options &opt, Backend &be) {
   const bool verbose = opt.verbose;
   Problem pb;
   int nel = opt.Z1 + opt.Z2;
-  if (nel % 2) throw std::logic_error("Open-shell (unrestricted/ROHF) runs are not implemented in this build.\n");
 
   int Nquad = opt.nquad;
   if (Nquad == 0) Nquad = 5 * opt.nnodes;
@@ -280,7 +337,6 @@ Result run_atomic(const AtomicOptions &aopt, Backend &be) {
   const bool verbose = opt.verbose;
   Problem pb;
   int nel = aopt.Z - aopt.Q;
-  if (nel % 2) throw std::logic_error("Open-shell (unrestricted/ROHF) runs are not implemented in this build.\n");
   if (nel <= 0) throw std::logic_error("No electrons.\n");
 
   // atomic/main.cpp:245-251

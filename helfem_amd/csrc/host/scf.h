@@ -4,7 +4,7 @@
 // of the reference driver (/root/reference/src/diatomic/main.cpp:402-1009):
 //   S,T,Vnuc -> Sinvh -> guess (core Hamiltonian, --iguess 0) -> compute_tei ->
 //   loop { P = C_occ C_occ^T; J; K; XC; F; E; DIIS; eig_gsym_sub } -> energy table.
-// Open-shell / unrestricted runs, external fields, finite nuclei, checkpoints and the SAP/GSZ/TF
+// Restricted open-shell (ROHF) runs, external fields, finite nuclei, checkpoints and the SAP/GSZ/TF
 // guesses are outside the hot-path scope and are rejected loudly.
 #pragma once
 #include "atomic_basis.h"
@@ -25,6 +25,9 @@ struct Backend {
   virtual Mat exchange(const Mat &P) = 0;
   virtual void eval_Fxc(int x_func, int c_func, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin,
                         double thr) = 0;
+  /// unrestricted: both spin matrices
+  virtual void eval_Fxc_pol(int x_func, int c_func, const Mat &Pa, const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc,
+                            double &Nel, double &Ekin, double thr) = 0;
   virtual void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh,
                             const std::vector<std::vector<size_t> > &sym) = 0;
   virtual Mat Sinvh(const Mat &S, bool chol, const std::vector<std::vector<size_t> > &sym) = 0;
@@ -50,6 +53,8 @@ struct Options {
   int ldft = 0, mdft = 0;
   double dftthr = 1e-12;
   int symmetry = 1;
+  int multiplicity = 1;   // --M: spin multiplicity 2S+1; nela - nelb = M - 1
+  int restricted = -1;    // --restricted: -1 auto (restricted iff M == 1), 0 unrestricted, 1 restricted (M == 1 only)
   int diisorder = 5;
   bool verbose = true;
 };
@@ -59,8 +64,11 @@ struct Result {
   int iterations = 0;
   bool converged = false;
   double tJ = 0, tK = 0, tXC = 0, tdiag = 0;  // seconds of the last iteration
-  Vec E;       // orbital energies
-  Mat C, P, F;  // final orbitals, density, Fock
+  Vec E;       // orbital energies (alpha)
+  Mat C, P, F;  // final orbitals (alpha), total density, Fock (alpha)
+  Vec Eb;      // unrestricted: beta orbital energies / orbitals / Fock
+  Mat Cb, Fb;
+  int nela = 0, nelb = 0;
   size_t Nbf = 0;
 };
 

@@ -129,6 +129,10 @@ int hfg_exchange(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *K);
  * Functional ids are libxc's: 1 lda_x, 7 lda_c_vwn, 12 lda_c_pw, 101 gga_x_pbe, 130 gga_c_pbe; <=0 none. */
 int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *P, double *H, double *Exc,
                 double *Nel, double *Ekin, double dens_thr);
+/* void DFTGrid::eval_Fxc(x_func,x_pars,c_func,c_pars,Pa,Pb,Ha,Hb,Exc,Nel,Ekin,beta,thr)   dftgrid.h:181,
+ * dftgrid.cpp:812 (unrestricted; both spin matrices are always formed, i.e. beta = true) */
+int hfg_xc_fock_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *Pa, const double *Pb,
+                    double *Ha, double *Hb, double *Exc, double *Nel, double *Ekin, double dens_thr);
 /* void scf::eig_gsym(E,C,F,Sinvh): Sinvh is N x n                     scf_helpers.h:34, .cpp:131 */
 int hfg_eig_gsym(hfg_ctx *ctx, int64_t N, int64_t n, const double *F, const double *Sinvh, double *E, double *C);
 /* void scf::eig_gsym_sub(E,C,F,Sinvh,m_idx)                           scf_helpers.h:36, .cpp:142 */
@@ -151,6 +155,8 @@ int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *d
 /* dScal: 3 doubles in HBM receiving Exc, Nel, Ekin */
 int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH,
                     double *dScal, double dens_thr);
+int hfg_xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
+                        double *dHa, double *dHb, double *dScal /* 3: Exc, Nel, Ekin */, double dens_thr);
 /* Fused, shardable Fock build for the SCF loop (main.cpp:808-900): J and the XC matrix are block-banded in
  * the radial index, so each rank produces its shard's contribution in a compact layout of
  * hfg_fock_compact_size() doubles; the caller all-reduces that buffer (and dScal) over ranks and
@@ -175,12 +181,13 @@ int hfg_form_density_dev(hfg_ctx *ctx, int64_t N, int64_t ncols, const double *d
 int hfg_gemm_dev(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int64_t k, const double *dA,
                  int64_t lda, const double *dB, int64_t ldb, double *dC, int64_t ldc);
 
-/* ---- SCF driver (restricted closed shell), the loop of src/diatomic/main.cpp:780-995 --------- */
+/* ---- SCF driver, the loop of src/diatomic/main.cpp:780-995: restricted closed shell (multiplicity 1) or
+ * unrestricted (multiplicity = 2S+1 > 1: nela - nelb = multiplicity - 1, --M of main.cpp:100) --------- */
 /* out[0..7] = Etot, Ekin, Epot, Ecoul, Exx, Exc, Enucr, iterations(+0.5 if converged); out[8..11] =
  * seconds of the last iteration's J, K, XC and diagonalisation steps (the reference's Timer prints). */
 int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmmax, int nlm, int nelem, int nnodes,
                      int nquad, double Rmax, int igrid, double zexp, int lpad, const char *method, int ldft, int mdft,
-                     int symmetry, int maxit, double convthr, int verbose, double *out /* 12 */);
+                     int symmetry, int multiplicity, int maxit, double convthr, int verbose, double *out /* 12 */);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every kernel family is bracketed by hipEvents on the context's stream; the
@@ -191,10 +198,10 @@ int hfg_profile_enable(hfg_ctx *ctx, int on);
 int hfg_profile_reset(hfg_ctx *ctx);
 int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches);
 
-/* Restricted closed-shell atomic SCF (driver loop of src/atomic/main.cpp:760-1005); out as for hfg_scf_diatomic */
+/* Atomic SCF, restricted closed shell or unrestricted (driver loop of src/atomic/main.cpp:760-1005); out as for hfg_scf_diatomic */
 int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax,
-                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int maxit,
-                   double convthr, int verbose, double *out /* 12 */);
+                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity,
+                   int maxit, double convthr, int verbose, double *out /* 12 */);
 
 /* Replays every launch of the named kernel of the last eigensolve back to back between two HIP events on the
  * context's stream (the roofline leg of bench.py).  Supported: "k_trdb_gemv". */

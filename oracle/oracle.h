@@ -49,6 +49,9 @@ Mat exchange(const helfem::diatomic::TwoDBasis &b, const Mat &P0);
 void eval_Fxc(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P,
               Mat &H, double &Exc, double &Nel, double &Ekin, double thr, long q_begin = 0, long q_end = -1,
               int shard_rank = 0, int shard_n = 1);
+/// DFTGrid::eval_Fxc (unrestricted)  src/diatomic/dftgrid.cpp:812-856
+void eval_Fxc_pol(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa,
+                  const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin, double thr);
 /// DFTGrid::eval_overlap / eval_kinetic  src/diatomic/dftgrid.cpp:858-896
 Mat grid_overlap(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
 Mat grid_kinetic(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
@@ -62,12 +65,20 @@ Mat atomic_exchange(const helfem::atomic::TwoDBasis &b, const Mat &P);
 void atomic_eval_Fxc(const helfem::atomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P, Mat &H,
                      double &Exc, double &Nel, double &Ekin, double thr);
 
-// ---- exchange-correlation functionals, spin-unpolarised, libxc conventions ----
+/// atomic::dftgrid::DFTGrid::eval_Fxc (unrestricted)  src/atomic/dftgrid.cpp:872-930
+void atomic_eval_Fxc_pol(const helfem::atomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa,
+                         const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin, double thr);
+
+// ---- exchange-correlation functionals, libxc conventions ----
 // ids follow libxc: 1 = lda_x, 7 = lda_c_vwn (VWN5), 12 = lda_c_pw, 101 = gga_x_pbe, 130 = gga_c_pbe
 // exc: energy per particle; vrho = d(rho exc)/d rho; vsigma = d(rho exc)/d sigma
 bool xc_is_gga(int func_id);
 void xc_unpolarized(int func_id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
                     double *vsigma, double dens_threshold);
+/// spin-polarised: rho[2N] = (a,b) per point, sigma[3N] = (aa,ab,bb) per point; exc[N] per particle of the total
+/// density, vrho[2N], vsigma[3N]  (xc_lda_exc_vxc / xc_gga_exc_vxc with XC_POLARIZED, dftgrid.cpp:343-458)
+void xc_polarized(int func_id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
+                  double *vsigma, double dens_threshold);
 /// "lda_x-lda_c_vwn", "gga_x_pbe-gga_c_pbe", "HF", "none", or numeric ids  (dftfuncs.cpp:64-118)
 void parse_xc_func(int &x_func, int &c_func, const std::string &method);
 

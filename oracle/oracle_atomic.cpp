@@ -9,6 +9,7 @@
 // The reference processes a whole radial element per compute_bf call; the sums are the same, here they are
 // accumulated one radial point at a time (the dense complex formulation is kept).
 #include "oracle.h"
+#include "oracle_grid.h"
 #include "../helfem_amd/csrc/host/atomic_basis.h"
 #include <cfloat>
 #include <cmath>
@@ -16,7 +17,6 @@
 
 namespace oracle {
 using helfem::atomic::TwoDBasis;
-typedef std::complex<double> cplx;
 
 static Mat submat(const Mat &M, size_t r0, size_t c0, size_t nr, size_t nc) {
   Mat S(nr, nc);
@@ -156,128 +156,101 @@ Mat atomic_exchange(const TwoDBasis &b, const Mat &P) {
 }
 
 // ---- XC quadrature --------------------------------------------------------------------------------------
-void atomic_eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P, Mat &H, double &Exc,
-                     double &Nel, double &Ekin, double thr) {
-  helfem::Vec cth, phi, wang;
-  helfem::angular_chebyshev(lang, mang, cth, phi, wang);
-  const size_t Ng = wang.size(), A = b.Nang();
-  const bool do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
-  H.zeros(b.Nbf(), b.Nbf());
-  double exc_tot = 0.0, nel = 0.0;
-  for (size_t iel = 0; iel < b.Nel(); iel++) {
+namespace {
+struct AtomicGridWorker : public DenseGrid {
+  const TwoDBasis &b;
+  Vec cth, phi, wang;
+  AtomicGridWorker(const TwoDBasis &b_, int lang, int mang) : b(b_) { helfem::angular_chebyshev(lang, mang, cth, phi, wang); }
+
+  // atomic/dftgrid.cpp:710-790, one radial point of element iel
+  void compute_bf(size_t iel, size_t irad) {
     size_t ifirst, ilast;
     b.fem.get_idx(iel, ifirst, ilast);
-    const size_t Nr = ilast - ifirst + 1, ne = Nr * A;
-    std::vector<size_t> bf_ind(ne);
+    const size_t Nr = ilast - ifirst + 1, A = b.Nang();
+    ne = Nr * A;
+    Ng = wang.size();
+    bf_ind.resize(ne);
     for (size_t iam = 0; iam < A; iam++)
       for (size_t j = 0; j < Nr; j++) bf_ind[iam * Nr + j] = b.Nrad() * iam + ifirst + j;
     Mat frad = b.get_bf(iel), drad = b.get_df(iel);
-    Vec r = b.get_r(iel), wrad = b.get_wrad(iel);
-    Mat Psub(ne, ne);
-    for (size_t j = 0; j < ne; j++)
-      for (size_t i = 0; i < ne; i++) Psub(i, j) = P(bf_ind[i], bf_ind[j]);
-    Mat Hsub(ne, ne);
-    for (size_t irad = 0; irad < r.size(); irad++) {
-      std::vector<cplx> bf(ne * Ng), bf_r, bf_t, bf_p;
-      if (do_grad) {
-        bf_r.assign(ne * Ng, cplx(0));
-        bf_t.assign(ne * Ng, cplx(0));
-        bf_p.assign(ne * Ng, cplx(0));
-      }
-      Vec wtot(Ng), s_t(Ng), s_p(Ng);
-      for (size_t ia = 0; ia < Ng; ia++) {
-        double sth = sqrt(1.0 - cth[ia] * cth[ia]);
-        wtot[ia] = wang[ia] * wrad[irad] * r[irad] * r[irad];
-        s_t[ia] = r[irad];
-        s_p[ia] = r[irad] * sth;
-        double cotth = cth[ia] / sth;
-        for (size_t i = 0; i < A; i++) {
-          int l = b.lval[i], m = b.mval[i];
-          cplx sph = helfem::spherical_harmonics(l, m, cth[ia], phi[ia]);
-          cplx angfac(0);
-          if (do_grad) {
-            angfac = m * cotth * sph;
-            if (m < l)
-              angfac += sqrt((double)((l - m) * (l + m + 1))) * std::exp(cplx(0, -phi[ia])) *
-                        helfem::spherical_harmonics(l, m + 1, cth[ia], phi[ia]);
-          }
-          for (size_t j = 0; j < Nr; j++) {
-            size_t u = i * Nr + j;
-            bf[ia * ne + u] = sph * frad(irad, j);
-            if (do_grad) {
-              bf_r[ia * ne + u] = sph * drad(irad, j);
-              bf_p[ia * ne + u] = cplx(0.0, m) * sph * frad(irad, j);
-              bf_t[ia * ne + u] = angfac * frad(irad, j);
-            }
-          }
-        }
-      }
-      // update_density
-      Vec rho(Ng, 0.0), sigma(Ng, 0.0), g0(Ng, 0.0), g1(Ng, 0.0), g2(Ng, 0.0);
-      std::vector<cplx> Pv(ne);
-      for (size_t ip = 0; ip < Ng; ip++) {
-        for (size_t i = 0; i < ne; i++) Pv[i] = 0;
-        for (size_t j = 0; j < ne; j++) {
-          cplx cb = std::conj(bf[ip * ne + j]);
-          for (size_t i = 0; i < ne; i++) Pv[i] += Psub(i, j) * cb;
-        }
-        cplx d(0), a0(0), a1(0), a2(0);
-        for (size_t i = 0; i < ne; i++) {
-          d += Pv[i] * bf[ip * ne + i];
-          if (do_grad) {
-            a0 += Pv[i] * bf_r[ip * ne + i];
-            a1 += Pv[i] * bf_t[ip * ne + i];
-            a2 += Pv[i] * bf_p[ip * ne + i];
-          }
-        }
-        rho[ip] = d.real();
+    const double r = b.get_r(iel)[irad], wrad = b.get_wrad(iel)[irad];
+    bf.assign(ne * Ng, cplx(0));
+    if (do_grad) {
+      bf_rho.assign(ne * Ng, cplx(0));
+      bf_theta.assign(ne * Ng, cplx(0));
+      bf_phi.assign(ne * Ng, cplx(0));
+    }
+    wtot.resize(Ng);
+    scale_r.assign(Ng, 1.0);
+    scale_theta.assign(Ng, r);
+    scale_phi.resize(Ng);
+    for (size_t ia = 0; ia < Ng; ia++) {
+      double sth = sqrt(1.0 - cth[ia] * cth[ia]);
+      wtot[ia] = wang[ia] * wrad * r * r;
+      scale_phi[ia] = r * sth;
+      double cotth = cth[ia] / sth;
+      for (size_t i = 0; i < A; i++) {
+        int l = b.lval[i], m = b.mval[i];
+        cplx sph = helfem::spherical_harmonics(l, m, cth[ia], phi[ia]);
+        cplx angfac(0);
         if (do_grad) {
-          g0[ip] = 2.0 * a0.real();
-          g1[ip] = 2.0 * a1.real() / s_t[ip];
-          g2[ip] = 2.0 * a2.real() / s_p[ip];
-          sigma[ip] = g0[ip] * g0[ip] + g1[ip] * g1[ip] + g2[ip] * g2[ip];
+          angfac = m * cotth * sph;
+          if (m < l)
+            angfac += sqrt((double)((l - m) * (l + m + 1))) * std::exp(cplx(0, -phi[ia])) *
+                      helfem::spherical_harmonics(l, m + 1, cth[ia], phi[ia]);
         }
-        nel += wtot[ip] * rho[ip];
-      }
-      Vec exc(Ng, 0.0), vxc(Ng, 0.0), vsig(Ng, 0.0), e(Ng), v(Ng), vs(Ng);
-      bool do_gga = false;
-      for (int id : {x_func, c_func}) {
-        if (id <= 0) continue;
-        do_gga = do_gga || xc_is_gga(id);
-        xc_unpolarized(id, Ng, rho.data(), do_grad ? sigma.data() : nullptr, e.data(), v.data(), vs.data(), thr);
-        for (size_t i = 0; i < Ng; i++) {
-          exc[i] += e[i];
-          vxc[i] += v[i];
-          vsig[i] += vs[i];
-        }
-      }
-      for (size_t ip = 0; ip < Ng; ip++) exc_tot += wtot[ip] * exc[ip] * rho[ip];
-      // eval_Fxc
-      for (size_t ip = 0; ip < Ng; ip++) {
-        double vr = vxc[ip] * wtot[ip];
-        for (size_t j = 0; j < ne; j++) {
-          cplx cj = std::conj(bf[ip * ne + j]) * vr;
-          for (size_t i = 0; i < ne; i++) Hsub(i, j) += (bf[ip * ne + i] * cj).real();
-        }
-      }
-      if (do_gga) {
-        std::vector<cplx> gamma(ne);
-        for (size_t ip = 0; ip < Ng; ip++) {
-          double f = 2.0 * wtot[ip] * vsig[ip];
-          double c0 = g0[ip] * f, c1 = g1[ip] * f / s_t[ip], c2 = g2[ip] * f / s_p[ip];
-          for (size_t i = 0; i < ne; i++)
-            gamma[i] = c0 * bf_r[ip * ne + i] + c1 * bf_t[ip * ne + i] + c2 * bf_p[ip * ne + i];
-          for (size_t j = 0; j < ne; j++) {
-            cplx cfj = std::conj(bf[ip * ne + j]), cgj = std::conj(gamma[j]);
-            for (size_t i = 0; i < ne; i++) Hsub(i, j) += (gamma[i] * cfj + bf[ip * ne + i] * cgj).real();
+        for (size_t j = 0; j < Nr; j++) {
+          size_t u = i * Nr + j;
+          bf[ia * ne + u] = sph * frad(irad, j);
+          if (do_grad) {
+            bf_rho[ia * ne + u] = sph * drad(irad, j);
+            bf_phi[ia * ne + u] = cplx(0.0, m) * sph * frad(irad, j);
+            bf_theta[ia * ne + u] = angfac * frad(irad, j);
           }
         }
       }
     }
-    for (size_t j = 0; j < ne; j++)
-      for (size_t i = 0; i < ne; i++) H(bf_ind[i], bf_ind[j]) += Hsub(i, j);
   }
-  Exc = exc_tot;
+};
+}  // namespace
+
+void atomic_eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P, Mat &H, double &Exc,
+                     double &Nel, double &Ekin, double thr) {
+  AtomicGridWorker grid(b, lang, mang);
+  grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  H.zeros(b.Nbf(), b.Nbf());
+  double exc = 0.0, nel = 0.0;
+  for (size_t iel = 0; iel < b.Nel(); iel++)
+    for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
+      grid.compute_bf(iel, irad);
+      grid.update_density(P);
+      nel += grid.compute_Nel();
+      grid.compute_xc(x_func, c_func, thr);
+      exc += grid.eval_Exc();
+      grid.eval_Fxc(H);
+    }
+  Exc = exc;
+  Nel = nel;
+  Ekin = 0.0;
+}
+
+void atomic_eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa, const Mat &Pb,
+                         Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin, double thr) {
+  AtomicGridWorker grid(b, lang, mang);
+  grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  Ha.zeros(b.Nbf(), b.Nbf());
+  Hb.zeros(b.Nbf(), b.Nbf());
+  double exc = 0.0, nel = 0.0;
+  for (size_t iel = 0; iel < b.Nel(); iel++)
+    for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
+      grid.compute_bf(iel, irad);
+      grid.update_density(Pa, Pb);
+      nel += grid.compute_Nel();
+      grid.compute_xc(x_func, c_func, thr);
+      exc += grid.eval_Exc();
+      grid.eval_Fxc(Ha, Hb);
+    }
+  Exc = exc;
   Nel = nel;
   Ekin = 0.0;
 }

@@ -53,6 +53,11 @@ struct OracleBackend : public helfem::scf::Backend {
     if (ab) oracle::atomic_eval_Fxc(*ab, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
     else oracle::eval_Fxc(*b, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
   }
+  void eval_Fxc_pol(int x, int c, const Mat &Pa, const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin,
+                    double thr) override {
+    if (ab) oracle::atomic_eval_Fxc_pol(*ab, ldft, mdft, x, c, Pa, Pb, Ha, Hb, Exc, Nel, Ekin, thr);
+    else oracle::eval_Fxc_pol(*b, ldft, mdft, x, c, Pa, Pb, Ha, Hb, Exc, Nel, Ekin, thr);
+  }
   void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh, const std::vector<std::vector<size_t> > &sym) override {
     oracle::eig_gsym_sub(E, C, F, Sinvh, sym);
   }
@@ -200,13 +205,32 @@ int orc_xc_unpolarized(int func_id, int64_t N, const double *rho, const double *
   ORC_CATCH
 }
 
+int orc_xc_polarized(int func_id, int64_t N, const double *rho, const double *sigma, double *exc, double *vrho,
+                     double *vsigma, double thr) {
+  ORC_TRY
+  xc_polarized(func_id, N, rho, sigma, exc, vrho, vsigma, thr);
+  ORC_CATCH
+}
+int orc_eval_fxc_pol(void *h, int lang, int mang, int x_func, int c_func, const double *Pa, const double *Pb, double *Ha,
+                     double *Hb, double *Exc, double *Nel, double *Ekin, double thr) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  Mat Ham, Hbm;
+  eval_Fxc_pol(*b, lang, mang, x_func, c_func, to_mat(Pa, N, N), to_mat(Pb, N, N), Ham, Hbm, *Exc, *Nel, *Ekin, thr);
+  memcpy(Ha, Ham.memptr(), sizeof(double) * N * N);
+  memcpy(Hb, Hbm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+
 /// Restricted closed-shell diatomic SCF on the CPU oracle.  out[0..7] = Etot, Ekin, Epot, Ecoul, Exx, Exc,
 /// Enucr, iterations(+0.5 if converged)
 int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, int nelem, int nnodes, int nquad,
                      double Rmax, int igrid, double zexp, int lpad, const char *method, int ldft, int mdft,
-                     int symmetry, int maxit, double convthr, int verbose, double *out) {
+                     int symmetry, int multiplicity, int maxit, double convthr, int verbose, double *out) {
   ORC_TRY
   helfem::scf::Options o;
+  o.multiplicity = multiplicity;
   o.Z1 = Z1;
   o.Z2 = Z2;
   o.Rbond = Rbond;
@@ -301,6 +325,18 @@ int orc_atomic_eval_fxc(void *h, int lang, int mang, int x_func, int c_func, con
   memcpy(H, Hm.memptr(), sizeof(double) * N * N);
   ORC_CATCH
 }
+int orc_atomic_eval_fxc_pol(void *h, int lang, int mang, int x_func, int c_func, const double *Pa, const double *Pb,
+                            double *Ha, double *Hb, double *Exc, double *Nel, double *Ekin, double thr) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  size_t N = b->Nbf();
+  Mat Ham, Hbm;
+  atomic_eval_Fxc_pol(*b, lang, mang, x_func, c_func, to_mat(Pa, N, N), to_mat(Pb, N, N), Ham, Hbm, *Exc, *Nel, *Ekin,
+                      thr);
+  memcpy(Ha, Ham.memptr(), sizeof(double) * N * N);
+  memcpy(Hb, Hbm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
 /// \int B_i B_j r^n dr over the whole radial basis (Nrad x Nrad) -- checked against the Maple rationals of
 /// the reference's src/atomic/inttest.cpp
 int orc_atomic_radial_integral(void *h, int n, double *out) {
@@ -344,10 +380,11 @@ int orc_atomic_prim_tei(void *h, int L, int iel, double *out, int64_t *n) {
 
 /// Restricted closed-shell atomic SCF on the CPU oracle; out as for orc_scf_diatomic
 int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax, int igrid,
-                   double zexp, const char *method, int ldft, int mdft, int symmetry, int maxit, double convthr,
-                   int verbose, double *out) {
+                   double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity, int maxit,
+                   double convthr, int verbose, double *out) {
   ORC_TRY
   helfem::scf::AtomicOptions a;
+  a.common.multiplicity = multiplicity;
   a.Z = Z;
   a.Q = Q;
   a.lmax = lmax;

@@ -8,13 +8,13 @@
 // The dense (complex basis-function matrix) formulation of the reference is kept on purpose:
 // this is the checker for the sum-factorised GPU kernels.
 #include "oracle.h"
+#include "oracle_grid.h"
 #include <cfloat>
 #include <cmath>
 #include <complex>
 
 namespace oracle {
 using helfem::diatomic::TwoDBasis;
-typedef std::complex<double> cplx;
 
 static Mat submat(const Mat &M, size_t r0, size_t c0, size_t nr, size_t nc) {
   Mat S(nr, nc);
@@ -221,18 +221,9 @@ Mat exchange(const TwoDBasis &b, const Mat &P0) {
 // XC quadrature, dense formulation of the reference
 // -------------------------------------------------------------------------------------------------
 namespace {
-struct GridWorker {
+struct GridWorker : public DenseGrid {
   const TwoDBasis &b;
   Vec cth, phi, wang;
-  bool do_grad = false;
-  // per radial point
-  std::vector<size_t> bf_ind;
-  size_t ne = 0, Ng = 0;
-  std::vector<cplx> bf, bf_rho, bf_theta, bf_phi;  // ne x Ng column-major
-  Vec wtot, scale_r, scale_theta, scale_phi;
-  Vec rho, sigma, exc, vxc, vsigma;
-  std::vector<double> grho;  // 3 x Ng
-  bool do_gga = false;
 
   GridWorker(const TwoDBasis &b_, int lang, int mang) : b(b_) { helfem::angular_chebyshev(lang, mang, cth, phi, wang); }
 
@@ -293,95 +284,6 @@ struct GridWorker {
       }
     }
   }
-
-  void update_density(const Mat &Pdummy) {
-    // dftgrid.cpp:51-117 (restricted)
-    Mat P(ne, ne);
-    for (size_t j = 0; j < ne; j++)
-      for (size_t i = 0; i < ne; i++) P(i, j) = Pdummy(bf_ind[i], bf_ind[j]);
-    rho.assign(Ng, 0.0);
-    if (do_grad) {
-      grho.assign(3 * Ng, 0.0);
-      sigma.assign(Ng, 0.0);
-    }
-    std::vector<cplx> Pv(ne);
-    for (size_t ip = 0; ip < Ng; ip++) {
-      // Pv = P * conj(bf)
-      for (size_t i = 0; i < ne; i++) Pv[i] = 0;
-      for (size_t j = 0; j < ne; j++) {
-        cplx cb = std::conj(bf[ip * ne + j]);
-        for (size_t i = 0; i < ne; i++) Pv[i] += P(i, j) * cb;
-      }
-      cplx d(0);
-      for (size_t i = 0; i < ne; i++) d += Pv[i] * bf[ip * ne + i];
-      rho[ip] = d.real();
-      if (do_grad) {
-        cplx g0(0), g1(0), g2(0);
-        for (size_t i = 0; i < ne; i++) {
-          g0 += Pv[i] * bf_rho[ip * ne + i];
-          g1 += Pv[i] * bf_theta[ip * ne + i];
-          g2 += Pv[i] * bf_phi[ip * ne + i];
-        }
-        double gr = grho[0 * Ng + ip] = 2.0 * g0.real() / scale_r[ip];
-        double gt = grho[1 * Ng + ip] = 2.0 * g1.real() / scale_theta[ip];
-        double gp = grho[2 * Ng + ip] = 2.0 * g2.real() / scale_phi[ip];
-        sigma[ip] = gr * gr + gt * gt + gp * gp;
-      }
-    }
-  }
-
-  void compute_xc(int x_func, int c_func, double thr) {
-    exc.assign(Ng, 0.0);
-    vxc.assign(Ng, 0.0);
-    vsigma.assign(Ng, 0.0);
-    do_gga = false;
-    Vec e(Ng), v(Ng), vs(Ng);
-    for (int id : {x_func, c_func}) {
-      if (id <= 0) continue;
-      do_gga = do_gga || xc_is_gga(id);
-      xc_unpolarized(id, Ng, rho.data(), do_grad ? sigma.data() : nullptr, e.data(), v.data(), vs.data(), thr);
-      for (size_t i = 0; i < Ng; i++) {
-        exc[i] += e[i];
-        vxc[i] += v[i];
-        vsigma[i] += vs[i];
-      }
-    }
-  }
-
-  // H += Re[(f o v) f^H]   (dftgrid.h:190-208)
-  void increment_lda(Mat &H, const Vec &v, const std::vector<cplx> &f) const {
-    for (size_t ip = 0; ip < Ng; ip++)
-      for (size_t j = 0; j < ne; j++) {
-        cplx cj = std::conj(f[ip * ne + j]) * v[ip];
-        for (size_t i = 0; i < ne; i++) H(i, j) += (f[ip * ne + i] * cj).real();
-      }
-  }
-
-  void eval_Fxc(Mat &Hdummy) const {
-    // dftgrid.cpp:499-545
-    Mat H(ne, ne);
-    Vec vr(Ng);
-    for (size_t i = 0; i < Ng; i++) vr[i] = vxc[i] * wtot[i];
-    increment_lda(H, vr, bf);
-    if (do_gga) {
-      // gamma = sum_c gr_c d_c bf ;  H += Re[gamma f^H + f gamma^H]   (dftgrid.h:211-253)
-      std::vector<cplx> gamma(ne * Ng);
-      for (size_t ip = 0; ip < Ng; ip++) {
-        double g0 = grho[0 * Ng + ip] * 2.0 * wtot[ip] * vsigma[ip] / scale_r[ip];
-        double g1 = grho[1 * Ng + ip] * 2.0 * wtot[ip] * vsigma[ip] / scale_theta[ip];
-        double g2 = grho[2 * Ng + ip] * 2.0 * wtot[ip] * vsigma[ip] / scale_phi[ip];
-        for (size_t i = 0; i < ne; i++)
-          gamma[ip * ne + i] = g0 * bf_rho[ip * ne + i] + g1 * bf_theta[ip * ne + i] + g2 * bf_phi[ip * ne + i];
-      }
-      for (size_t ip = 0; ip < Ng; ip++)
-        for (size_t j = 0; j < ne; j++) {
-          cplx cfj = std::conj(bf[ip * ne + j]), cgj = std::conj(gamma[ip * ne + j]);
-          for (size_t i = 0; i < ne; i++) H(i, j) += (gamma[ip * ne + i] * cfj + bf[ip * ne + i] * cgj).real();
-        }
-    }
-    for (size_t j = 0; j < ne; j++)
-      for (size_t i = 0; i < ne; i++) Hdummy(bf_ind[i], bf_ind[j]) += H(i, j);
-  }
 };
 }  // namespace
 
@@ -408,6 +310,29 @@ void eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, co
   Nel = nel;
   Ekin = 0.0;  // only meta-GGAs integrate tau (dftgrid.cpp:227-240)
   Hout = b.remove_boundaries(H);
+}
+
+void eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa0, const Mat &Pb0, Mat &Haout,
+                  Mat &Hbout, double &Exc, double &Nel, double &Ekin, double thr) {
+  Mat Ha(b.Ndummy(), b.Ndummy()), Hb(b.Ndummy(), b.Ndummy());
+  Mat Pa(b.expand_boundaries(Pa0)), Pb(b.expand_boundaries(Pb0));
+  double exc = 0.0, nel = 0.0;
+  GridWorker grid(b, lang, mang);
+  grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  for (size_t iel = 0; iel < b.Nel(); iel++)
+    for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
+      grid.compute_bf(iel, irad);
+      grid.update_density(Pa, Pb);
+      nel += grid.compute_Nel();
+      grid.compute_xc(x_func, c_func, thr);
+      exc += grid.eval_Exc();
+      grid.eval_Fxc(Ha, Hb);
+    }
+  Exc = exc;
+  Nel = nel;
+  Ekin = 0.0;
+  Haout = b.remove_boundaries(Ha);
+  Hbout = b.remove_boundaries(Hb);
 }
 
 Mat grid_overlap(const TwoDBasis &b, int lang, int mang) {

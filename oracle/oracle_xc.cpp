@@ -46,7 +46,7 @@ void lda_c_vwn(double rho, double &exc, double &vrho) {
 
 // ---- PW92 paramagnetic correlation; mod=true uses the higher-precision constants of pw_mod ----
 void pw92(double rs, bool mod, double &ec, double &decdrs) {
-  const double a = mod ? 0.0310906908696549 : 0.031091;
+  const double a = mod ? 0.0310907 : 0.031091;  // libxc lda_c_pw.c: par_pw / par_pw_mod
   const double a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
   double srs = sqrt(rs);
   double q0 = -2.0 * a * (1.0 + a1 * rs);
@@ -135,6 +135,168 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
     exc[i] = e;
     vrho[i] = v;
     if (vsigma) vsigma[i] = vs;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Spin-polarised functionals.  Exchange follows from the spin-scaling relation
+//   E_x[rho_a, rho_b] = (E_x[2 rho_a] + E_x[2 rho_b]) / 2
+// applied to the hand-derived unpolarised formulas above.  Correlation depends on (rs, zeta, sigma_total);
+// its derivatives are taken with a small forward-mode differentiation type over (rho_a, rho_b, sigma_tot).
+// Densities of one spin channel below the threshold are raised to it (libxc >= 5 does the same before
+// evaluating a polarised functional), which keeps (1 -+ zeta) away from the non-analytic end points.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct D3 {
+  double v, d[3];
+};
+inline D3 C(double v) { return D3{v, {0, 0, 0}}; }
+inline D3 var(double v, int k) {
+  D3 r = C(v);
+  r.d[k] = 1.0;
+  return r;
+}
+inline D3 operator+(D3 a, D3 b) { return D3{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+inline D3 operator-(D3 a, D3 b) { return D3{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
+inline D3 operator-(D3 a) { return D3{-a.v, {-a.d[0], -a.d[1], -a.d[2]}}; }
+inline D3 operator*(D3 a, D3 b) {
+  return D3{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
+}
+inline D3 chain(D3 a, double f, double df) { return D3{f, {df * a.d[0], df * a.d[1], df * a.d[2]}}; }
+inline D3 operator/(D3 a, D3 b) { return a * chain(b, 1.0 / b.v, -1.0 / (b.v * b.v)); }
+inline D3 operator+(D3 a, double c) { return a + C(c); }
+inline D3 operator+(double c, D3 a) { return a + C(c); }
+inline D3 operator-(D3 a, double c) { return a - C(c); }
+inline D3 operator-(double c, D3 a) { return C(c) - a; }
+inline D3 operator*(double c, D3 a) { return C(c) * a; }
+inline D3 operator*(D3 a, double c) { return C(c) * a; }
+inline D3 operator/(D3 a, double c) { return a * (1.0 / c); }
+inline D3 operator/(double c, D3 a) { return C(c) / a; }
+inline D3 Dsqrt(D3 a) { double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
+inline D3 Dcbrt(D3 a) { double c = cbrt(a.v); return chain(a, c, c / (3.0 * a.v)); }
+inline D3 Dlog(D3 a) { return chain(a, log(a.v), 1.0 / a.v); }
+inline D3 Dexp(D3 a) { double e = exp(a.v); return chain(a, e, e); }
+inline D3 Datan(D3 a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+inline D3 Dpow43(D3 a) { double c = cbrt(a.v); return chain(a, a.v * c, 4.0 / 3.0 * c); }
+inline D3 Dpow23(D3 a) { double c = cbrt(a.v); return chain(a, c * c, 2.0 / (3.0 * c)); }
+
+// f(zeta) = ((1+z)^{4/3} + (1-z)^{4/3} - 2) / (2^{4/3} - 2)
+D3 fzeta(D3 z) { return (Dpow43(1.0 + z) + Dpow43(1.0 - z) - 2.0) / (2.0 * cbrt(2.0) - 2.0); }
+
+// one VWN fit: A [ ln(x^2/X) + 2b/Q atan(Q/(2x+b)) - b x0/X0 ( ln((x-x0)^2/X) + 2(b+2x0)/Q atan(Q/(2x+b)) ) ]
+D3 vwn_fit(D3 x, double A, double b, double c, double x0) {
+  D3 X = x * x + b * x + c;
+  double X0 = x0 * x0 + b * x0 + c, Q = sqrt(4.0 * c - b * b);
+  D3 at = Datan(Q / (2.0 * x + b));
+  D3 xm = x - x0;
+  return A * (Dlog(x * x / X) + (2.0 * b / Q) * at - (b * x0 / X0) * (Dlog(xm * xm / X) + (2.0 * (b + 2.0 * x0) / Q) * at));
+}
+
+// VWN5 (libxc lda_c_vwn): e_P + alpha f(z)(1-z^4)/f''(0) + (e_F - e_P) f(z) z^4
+D3 eps_vwn(D3 rs, D3 z) {
+  D3 x = Dsqrt(rs);
+  D3 eP = vwn_fit(x, 0.0310907, 3.72744, 12.9352, -0.10498);
+  D3 eF = vwn_fit(x, 0.01554535, 7.06042, 18.0578, -0.32500);
+  D3 al = vwn_fit(x, -1.0 / (6.0 * PI * PI), 1.13107, 13.0045, -0.0047584);
+  const double fpp = 4.0 / (9.0 * (cbrt(2.0) - 1.0));
+  D3 f = fzeta(z), z4 = z * z * z * z;
+  return eP + al * f * (1.0 - z4) / fpp + (eF - eP) * f * z4;
+}
+
+D3 pw_G(D3 rs, double A, double a1, double b1, double b2, double b3, double b4) {
+  D3 s = Dsqrt(rs);
+  D3 den = (2.0 * A) * (b1 * s + b2 * rs + b3 * rs * s + b4 * rs * rs);
+  return (-2.0 * A) * (1.0 + a1 * rs) * Dlog(1.0 + 1.0 / den);
+}
+
+// PW92 (libxc lda_c_pw / lda_c_pw_mod): e0 + alpha_c f(z)(1-z^4)/f''(0) + (e1-e0) f(z) z^4, alpha_c = -G(third set)
+D3 eps_pw(D3 rs, D3 z, bool mod) {
+  D3 e0 = pw_G(rs, mod ? 0.0310907 : 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+  D3 e1 = pw_G(rs, mod ? 0.01554535 : 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+  D3 mac = pw_G(rs, mod ? 0.0168869 : 0.016887, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);
+  const double fz20 = mod ? 1.709920934161365617563962776245 : 1.709921;
+  D3 f = fzeta(z), z4 = z * z * z * z;
+  return e0 - mac * f * (1.0 - z4) / fz20 + (e1 - e0) * f * z4;
+}
+
+// PBE correlation (libxc gga_c_pbe): e_pw_mod(rs,z) + gamma phi^3 ln(1 + beta/gamma t^2 (1+A t^2)/(1+A t^2+A^2 t^4))
+D3 eps_pbe_c(D3 rho, D3 rs, D3 z, D3 sig) {
+  const double beta = 0.06672455060314922, gamma = (1.0 - log(2.0)) / (PI * PI), B = beta / gamma;
+  D3 ec = eps_pw(rs, z, true);
+  D3 phi = 0.5 * (Dpow23(1.0 + z) + Dpow23(1.0 - z));
+  D3 phi3 = phi * phi * phi;
+  D3 kf = Dcbrt((3.0 * PI * PI) * rho);
+  D3 ks2 = (4.0 / PI) * kf;
+  D3 t2 = sig / (4.0 * phi * phi * ks2 * rho * rho);
+  D3 A = B / (Dexp(-ec / (gamma * phi3)) - 1.0);
+  D3 At2 = A * t2;
+  return ec + gamma * phi3 * Dlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+}
+}  // namespace
+
+void xc_polarized(int id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho, double *vsigma,
+                  double thr) {
+  for (size_t i = 0; i < N; i++) {
+    exc[i] = 0.0;
+    vrho[2 * i] = vrho[2 * i + 1] = 0.0;
+    if (vsigma) vsigma[3 * i] = vsigma[3 * i + 1] = vsigma[3 * i + 2] = 0.0;
+    double ra = rho[2 * i], rb = rho[2 * i + 1];
+    if (!(ra + rb >= thr) || ra + rb <= 0.0) continue;
+    ra = std::max(ra, thr);
+    rb = std::max(rb, thr);
+    const double rt = ra + rb;
+    const bool gga = xc_is_gga(id);
+    double saa = 0, sab = 0, sbb = 0;
+    if (gga) {
+      saa = sigma[3 * i];
+      sab = sigma[3 * i + 1];
+      sbb = sigma[3 * i + 2];
+    }
+    switch (id) {
+      case 1:
+      case 101: {  // spin-scaled exchange
+        double ea, va, vsa = 0, eb, vb, vsb = 0;
+        if (id == 1) {
+          lda_x(2.0 * ra, ea, va);
+          lda_x(2.0 * rb, eb, vb);
+        } else {
+          gga_x_pbe(2.0 * ra, 4.0 * saa, ea, va, vsa);
+          gga_x_pbe(2.0 * rb, 4.0 * sbb, eb, vb, vsb);
+        }
+        exc[i] = (ra * ea + rb * eb) / rt;  // (1/2)(2 ra ea + 2 rb eb) per particle of the total density
+        vrho[2 * i] = va;
+        vrho[2 * i + 1] = vb;
+        if (gga) {
+          vsigma[3 * i] = 2.0 * vsa;
+          vsigma[3 * i + 2] = 2.0 * vsb;
+        }
+        break;
+      }
+      case 7:
+      case 12:
+      case 130: {
+        D3 a = var(ra, 0), b = var(rb, 1), st = var(saa + 2.0 * sab + sbb, 2);
+        D3 n = a + b;
+        D3 rs = Dcbrt((3.0 / (4.0 * PI)) / n);
+        D3 z = (a - b) / n;
+        D3 e = (id == 7) ? eps_vwn(rs, z) : (id == 12) ? eps_pw(rs, z, false) : eps_pbe_c(n, rs, z, st);
+        D3 en = n * e;
+        exc[i] = e.v;
+        vrho[2 * i] = en.d[0];
+        vrho[2 * i + 1] = en.d[1];
+        if (gga) {
+          vsigma[3 * i] = en.d[2];
+          vsigma[3 * i + 1] = 2.0 * en.d[2];
+          vsigma[3 * i + 2] = en.d[2];
+        }
+        break;
+      }
+      default: {
+        std::ostringstream oss;
+        oss << "Functional " << id << " not found!";
+        throw std::runtime_error(oss.str());
+      }
+    }
   }
 }
 

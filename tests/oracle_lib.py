@@ -29,13 +29,19 @@ def lib():
         L.orc_eval_fxc_shard.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double,
                                          ctypes.c_int, ctypes.c_int]
+        L.orc_xc_polarized.argtypes = [ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
+                                       c_double_p, ctypes.c_double]
+        for nm in ("orc_eval_fxc_pol", "orc_atomic_eval_fxc_pol"):
+            getattr(L, nm).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                       c_double_p, ctypes.c_double]
         L.orc_xc_unpolarized.argtypes = [ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
                                          c_double_p, ctypes.c_double]
         L.orc_scf_diatomic.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int),
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
-                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
-                                       c_double_p]
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_int, c_double_p]
         L.orc_atomic_basis_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_void_p)]
@@ -45,7 +51,7 @@ def lib():
         L.orc_atomic_radial_integral.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p]
         L.orc_atomic_prim_tei.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_i64_p]
         L.orc_scf_atomic.argtypes = [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
-                                                          ctypes.c_char_p] + [ctypes.c_int] * 4 + [
+                                                          ctypes.c_char_p] + [ctypes.c_int] * 5 + [
                                                               ctypes.c_double, ctypes.c_int, c_double_p]
         for name in ("orc_basis_destroy", "orc_basis_dims", "orc_compute_tei", "orc_coulomb", "orc_exchange",
                      "orc_grid_overlap", "orc_grid_kinetic"):
@@ -76,6 +82,8 @@ def _blocks(m_idx):
 
 
 class OracleBasis(object):
+    _fxc_pol = "orc_eval_fxc_pol"
+
     def __init__(self, Z1, Z2, Rhalf, nnodes, nquad, bval, lval, mval, lpad=10):
         bval = np.ascontiguousarray(bval, dtype=np.float64)
         lv = (ctypes.c_int * len(lval))(*lval)
@@ -131,6 +139,14 @@ class OracleBasis(object):
                                   ctypes.byref(nel), ctypes.byref(ekin), thr, q_begin, q_end))
         return H, exc.value, nel.value, ekin.value
 
+    def eval_Fxc_pol(self, lang, mang, x_func, c_func, Pa, Pb, thr=1e-12):
+        Pa, Pb = _f(Pa), _f(Pb)
+        Ha, Hb = np.zeros_like(Pa, order="F"), np.zeros_like(Pb, order="F")
+        exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(getattr(lib(), self._fxc_pol)(self.h, lang, mang, x_func, c_func, _p(Pa), _p(Pb), _p(Ha), _p(Hb),
+                                             ctypes.byref(exc), ctypes.byref(nel), ctypes.byref(ekin), thr))
+        return Ha, Hb, exc.value, nel.value, ekin.value
+
     def grid_overlap(self, lang, mang):
         S = np.zeros((self.Nbf, self.Nbf), order="F")
         _check(lib().orc_grid_overlap(self.h, lang, mang, _p(S)))
@@ -143,6 +159,8 @@ class OracleBasis(object):
 
 
 class OracleAtomicBasis(object):
+    _fxc_pol = "orc_atomic_eval_fxc_pol"
+
     def __init__(self, Z, nnodes, nquad, bval, lval, mval):
         bval = np.ascontiguousarray(bval, dtype=np.float64)
         lv = (ctypes.c_int * len(lval))(*lval)
@@ -200,12 +218,30 @@ class OracleAtomicBasis(object):
                                          ctypes.byref(nel), ctypes.byref(ekin), thr))
         return H, exc.value, nel.value, ekin.value
 
+    def eval_Fxc_pol(self, lang, mang, x_func, c_func, Pa, Pb, thr=1e-12):
+        Pa, Pb = _f(Pa), _f(Pb)
+        Ha, Hb = np.zeros_like(Pa, order="F"), np.zeros_like(Pb, order="F")
+        exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check(getattr(lib(), self._fxc_pol)(self.h, lang, mang, x_func, c_func, _p(Pa), _p(Pb), _p(Ha), _p(Hb),
+                                             ctypes.byref(exc), ctypes.byref(nel), ctypes.byref(ekin), thr))
+        return Ha, Hb, exc.value, nel.value, ekin.value
+
+
+def xc_polarized(func_id, rho, sigma, thr=1e-12):
+    """rho (n,2), sigma (n,3) -> exc (n), vrho (n,2), vsigma (n,3)"""
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    n = rho.shape[0]
+    exc, vrho, vsigma = np.zeros(n), np.zeros((n, 2)), np.zeros((n, 3))
+    _check(lib().orc_xc_polarized(func_id, n, _p(rho), _p(sigma), _p(exc), _p(vrho), _p(vsigma), thr))
+    return exc, vrho, vsigma
+
 
 def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
-               symmetry=1, maxit=50, convthr=1e-7, verbose=0):
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1):
     out = np.zeros(8)
     _check(lib().orc_scf_atomic(Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft, mdft,
-                                symmetry, maxit, convthr, verbose, _p(out)))
+                                symmetry, M, maxit, convthr, verbose, _p(out)))
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])
@@ -270,11 +306,11 @@ def xc_unpolarized(func_id, rho, sigma, thr=1e-12):
 
 
 def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0, igrid=4, zexp=1.0, lpad=10, ldft=0,
-                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0):
+                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1):
     out = np.zeros(8)
     lm = (ctypes.c_int * len(lmmax))(*lmmax)
     _check(lib().orc_scf_diatomic(Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
-                                  method.encode(), ldft, mdft, symmetry, maxit, convthr, verbose, _p(out)))
+                                  method.encode(), ldft, mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])

@@ -413,3 +413,74 @@ def test_atomic_grid_electron_count_and_exchange_energy():
     assert abs(EK + 0.5 * EJ) < 1e-10
     H, Exc, Nel, _ = ob.eval_Fxc(10, 5, 1, 0, 2 * Pa)
     assert abs(Nel - 2.0) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# spin-polarised functionals and unrestricted runs
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fid", [1, 7, 12, 101, 130])
+def test_polarized_functionals_reduce_to_unpolarized_and_match_finite_differences(fid):
+    rng = np.random.RandomState(fid)
+    n = 40
+    rt = 10 ** rng.uniform(-4, 2, n)
+    g = rng.uniform(0, 3, n) * rt ** (4.0 / 3.0)
+    eu, vu, vsu = orc.xc_unpolarized(fid, rt, g * g)
+    e, v, vs = orc.xc_polarized(fid, np.stack([rt / 2, rt / 2], 1), np.stack([g * g / 4] * 3, 1))
+    assert np.max(np.abs(e - eu) / np.abs(eu)) < 1e-13
+    assert np.max(np.abs(v[:, 0] - vu) / np.abs(vu)) < 1e-12 and np.max(np.abs(v[:, 1] - vu) / np.abs(vu)) < 1e-12
+    if fid > 100:  # d/d sigma_total = (vs_aa + vs_ab + vs_bb)/4 at equal spin densities
+        assert np.max(np.abs((vs.sum(axis=1)) / 4 - vsu) / (np.abs(vsu) + 1e-300)) < 1e-10
+    # general polarisation: central differences of the energy density
+    z = rng.uniform(-0.95, 0.95, n)
+    ra, rb = rt * (1 + z) / 2, rt * (1 - z) / 2
+    ga = rng.normal(size=(n, 3)) * ra[:, None] ** (4.0 / 3.0)
+    gb = rng.normal(size=(n, 3)) * rb[:, None] ** (4.0 / 3.0)
+    sig = np.stack([(ga * ga).sum(1), (ga * gb).sum(1), (gb * gb).sum(1)], 1)
+
+    def energy(ra, rb, sig):
+        ee, _, _ = orc.xc_polarized(fid, np.stack([ra, rb], 1), sig)
+        return ee * (ra + rb)
+
+    _, v, vs = orc.xc_polarized(fid, np.stack([ra, rb], 1), sig)
+    h = 1e-6
+    fa = (energy(ra * (1 + h), rb, sig) - energy(ra * (1 - h), rb, sig)) / (2 * h * ra)
+    fb = (energy(ra, rb * (1 + h), sig) - energy(ra, rb * (1 - h), sig)) / (2 * h * rb)
+    assert np.max(np.abs(fa - v[:, 0]) / np.abs(v[:, 0])) < 1e-6
+    assert np.max(np.abs(fb - v[:, 1]) / np.abs(v[:, 1])) < 1e-6
+    if fid > 100:
+        for k in range(3):
+            sp, sm = sig.copy(), sig.copy()
+            d = h * np.maximum(np.abs(sig[:, k]), 1e-30)
+            sp[:, k] += d
+            sm[:, k] -= d
+            fd = (energy(ra, rb, sp) - energy(ra, rb, sm)) / (2 * d)
+            assert np.max(np.abs(fd - vs[:, k]) / (np.abs(vs[:, k]) + 1e-8 * np.abs(vs).max())) < 1e-4, (fid, k)
+
+
+def test_polarized_correlation_textbook_values():
+    """uniform-gas correlation energies per particle at rs = 2 (Perdew-Wang 1992, Table; VWN fit of the same data)"""
+    rs = 2.0
+    n0 = 3.0 / (4.0 * np.pi * rs ** 3)
+    z = np.zeros((1, 3))
+    for fid, para, ferro in ((12, -0.04476, -0.02391), (7, -0.04478, -0.02386)):
+        e0, _, _ = orc.xc_polarized(fid, np.array([[n0 / 2, n0 / 2]]), z)
+        e1, _, _ = orc.xc_polarized(fid, np.array([[n0, 0.0]]), z)
+        assert abs(e0[0] - para) < 2e-5 and abs(e1[0] - ferro) < 2e-5, (fid, e0, e1)
+
+
+OPEN_SHELL_LITERATURE = [
+    # NIST atomic reference data (LSD = Slater exchange + VWN), numerical UHF limits, PBE hydrogen atom
+    ("H_LSD", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn", M=2), -0.478671, 1e-6),
+    ("Li_LSD", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn", M=2), -7.343957, 1e-6),
+    ("H_PBE", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="gga_x_pbe-gga_c_pbe", M=2), -0.499990, 1e-6),
+    ("H_UHF", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=2), -0.5, 1e-9),
+    ("Li_UHF", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=2), -7.432751, 1e-6),
+    ("N_UHF", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=15, method="HF", M=4), -54.404548, 1e-6),
+]
+
+
+@pytest.mark.parametrize("name,kw,lit,tol", OPEN_SHELL_LITERATURE, ids=[c[0] for c in OPEN_SHELL_LITERATURE])
+def test_unrestricted_oracle_literature_energies(name, kw, lit, tol):
+    r = orc.scf_atomic(convthr=1e-8, maxit=80, **kw)
+    assert r["converged"]
+    assert abs(r["Etot"] - lit) < tol, (name, r["Etot"], lit)

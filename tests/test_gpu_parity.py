@@ -224,6 +224,90 @@ def test_atomic_xc_parity(acase, hf, funcs):
         assert common.relerr(H, Ho) < 1e-10, (name, tag, funcs, common.relerr(H, Ho))
 
 
+def _spin_densities(gb):
+    """two different positive block-diagonal spin densities"""
+    import common
+    N = gb.Nbf()
+    blocks = gb.get_sym_idx(1)
+    Pa = common.random_density(N, 2, seed=21, blocks=blocks) + 0.03 * common.random_density(N, 3, seed=23)
+    Pb = common.random_density(N, 1, seed=22, blocks=blocks)
+    return Pa, Pb
+
+
+@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (1, 12), (101, 0), (0, 130)])
+def test_xc_polarized_parity(case, hf, funcs):
+    import common
+    name, gb, ob, ldft, mdft = case
+    grid = hf.DFTGrid(gb, ldft, mdft)
+    x, c = funcs
+    Pa, Pb = _spin_densities(gb)
+    Ha, Hb, Exc, Nel, _ = grid.eval_Fxc_pol(x, c, Pa, Pb)
+    Hao, Hbo, Exco, Nelo, _ = ob.eval_Fxc_pol(ldft, mdft, x, c, Pa, Pb)
+    assert abs(Nel - Nelo) < 1e-11 * max(1.0, abs(Nelo)), (name, Nel, Nelo)
+    assert abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco)), (name, Exc, Exco)
+    assert common.relerr(Ha, Hao) < 1e-10, (name, funcs, common.relerr(Ha, Hao))
+    assert common.relerr(Hb, Hbo) < 1e-10, (name, funcs, common.relerr(Hb, Hbo))
+    # a fully polarised density (Pb = 0, the hydrogen-like case) must stay finite and agree too
+    Ha, Hb, Exc, Nel, _ = grid.eval_Fxc_pol(x, c, Pa, 0.0 * Pb)
+    Hao, Hbo, Exco, Nelo, _ = ob.eval_Fxc_pol(ldft, mdft, x, c, Pa, 0.0 * Pb)
+    assert np.all(np.isfinite(Ha)) and np.all(np.isfinite(Hb))
+    assert abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco))
+    # the empty channel's potential is evaluated at rho_b = threshold where d/d rho_b of (1 - zeta)^{2/3, 4/3} is
+    # huge: two arithmetic routes agree to ~1e-7 there, not to rounding
+    assert common.relerr(Ha, Hao) < 1e-10 and common.relerr(Hb, Hbo) < 1e-5, (name, funcs)
+
+
+def test_xc_polarized_equals_restricted_for_equal_spins(case, hf):
+    import common
+    name, gb, ob, ldft, mdft = case
+    grid = hf.DFTGrid(gb, ldft, mdft)
+    Pa, _ = _spin_densities(gb)
+    Ha, Hb, Exc, Nel, _ = grid.eval_Fxc_pol(101, 130, Pa, Pa)
+    H, Exc0, Nel0, _ = grid.eval_Fxc(101, 130, 2.0 * Pa)
+    assert abs(Exc - Exc0) < 1e-11 * abs(Exc0) and abs(Nel - Nel0) < 1e-11 * Nel0
+    assert common.relerr(Ha, H) < 1e-10 and common.relerr(Hb, H) < 1e-10
+
+
+@pytest.mark.parametrize("funcs", [(1, 7), (101, 130)])
+def test_atomic_xc_polarized_parity(acase, hf, funcs):
+    import common
+    name, gb, ob, ldft, mdft = acase
+    grid = hf.DFTGrid(gb, ldft, mdft)
+    x, c = funcs
+    Pa, Pb = _spin_densities(gb)
+    Ha, Hb, Exc, Nel, _ = grid.eval_Fxc_pol(x, c, Pa, Pb)
+    Hao, Hbo, Exco, Nelo, _ = ob.eval_Fxc_pol(ldft, mdft, x, c, Pa, Pb)
+    assert abs(Nel - Nelo) < 1e-11 * max(1.0, abs(Nelo)), (name, Nel, Nelo)
+    assert abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco)), (name, Exc, Exco)
+    assert common.relerr(Ha, Hao) < 1e-10 and common.relerr(Hb, Hbo) < 1e-10, (name, funcs)
+
+
+OPEN_SHELL_CASES = [
+    # unrestricted runs: NIST LSD (VWN) atomic reference data, numerical UHF limits, H/PBE
+    ("H_LSD", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn", M=2), -0.478671, 2e-6),
+    ("H_PBE", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="gga_x_pbe-gga_c_pbe", M=2), -0.499990, 2e-6),
+    ("Li_UHF", "atomic", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=2), -7.432751, 2e-6),
+    ("N_LSD", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=12, method="lda_x-lda_c_vwn", M=4), -54.136799, 5e-6),
+    ("H2+_like_HeH2+", "diatomic", dict(Z1=1, Z2=1, Rbond=2.0, lmmax=[6], nelem=3, nnodes=10, method="HF", M=3), None, None),
+    ("OH_like_LiH+_PBE", "diatomic", dict(Z1=3, Z2=0, Rbond=3.0, lmmax=[4, 2], nelem=3, nnodes=8,
+                                          method="gga_x_pbe-gga_c_pbe", M=2), None, None),
+]
+
+
+@pytest.mark.parametrize("name,prog,kw,lit,littol", OPEN_SHELL_CASES, ids=[c[0] for c in OPEN_SHELL_CASES])
+def test_unrestricted_scf_energy_parity(hf, name, prog, kw, lit, littol):
+    import oracle_lib as orc
+    gfn, ofn = (hf.scf_atomic, orc.scf_atomic) if prog == "atomic" else (hf.scf_diatomic, orc.scf_diatomic)
+    g = gfn(convthr=1e-9, maxit=80, **kw)
+    o = ofn(convthr=1e-9, maxit=80, **kw)
+    assert g["converged"] and o["converged"]
+    assert abs(g["Etot"] - o["Etot"]) < 1e-8 * max(1.0, abs(o["Etot"]) / 10), (name, g["Etot"], o["Etot"])
+    for k in ("Ekin", "Epot", "Ecoul", "Exx", "Exc"):
+        assert abs(g[k] - o[k]) < 1e-6 * max(1.0, abs(o[k]) / 10), (name, k, g[k], o[k])
+    if lit is not None:
+        assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
+
+
 ATOMIC_SCF_CASES = [
     # BASELINE config 1: He, LDA (NIST reference-data total energy) ; config 2-like: Ne / Be with l up to 1
     ("He_LDA", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -2.834836, 2e-6),
