@@ -23,6 +23,7 @@ void fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, co
 void fock_finish_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dFc, const double *dH0, const int *dBlockId,
                      double *dF);
 void exchange_release(hfg_dev_tables *t);
+void exchange_lr_release(hfg_dev_tables *t);
 void eig_release(hfg_ctx *ctx);
 void dc_release(hfg_ctx *ctx);
 void trd_release(hfg_ctx *ctx);
@@ -240,6 +241,7 @@ int hfg_basis_destroy(hfg_basis *b) {
   if (b->dev) {
     fock_release(b->dev);
     exchange_release(b->dev);
+    exchange_lr_release(b->dev);
     delete b->dev;
   }
   delete b;
@@ -343,6 +345,7 @@ int hfg_basis_upload(hfg_ctx *ctx, hfg_basis *b, int ldft, int mdft) {
   if (b->dev) {
     fock_release(b->dev);
     exchange_release(b->dev);
+    exchange_lr_release(b->dev);
   }
   upload_tables(ctx, b, ldft, mdft);
   HFG_CATCH

@@ -99,6 +99,15 @@ struct hfg_basis {
 };
 
 namespace hfg {
+// one product C = A B (column-major) of a device-side task list (k_dgemm_tasks, dc.hip)
+struct GemmTask {
+  const double *A;
+  const double *B;
+  double *C;
+  int M, N, K, lda, ldb, ldc;
+  int tA = 0, tB = 0;  // op(A), op(B) transposed (k_dgemm_tasklist only)
+};
+
 struct ProfScope {
   hfg_ctx *c;
   const char *n;

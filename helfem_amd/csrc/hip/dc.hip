@@ -31,13 +31,6 @@ struct DCNode {
   int blk, lo, mid, hi;
 };
 
-struct GemmTask {
-  const double *A;
-  const double *B;
-  double *C;
-  int M, N, K, lda, ldb, ldc;
-};
-
 struct DCBatch {
   int n[DC_MAXB];
   double *d[DC_MAXB];   // in: torn diagonal / leaf+merge eigenvalues (ping)
@@ -603,6 +596,15 @@ __global__ __launch_bounds__(256) void k_dgemm_tasks(const GemmTask *__restrict_
         int gm = bm + wm + i * 16 + l15, gn = bn + wn + j * 16 + l4 + 4 * r;
         if (gm < M && gn < N) t.C[(size_t)gn * t.ldc + gm] = acc[i][j][r];
       }
+}
+
+void gemm_tasks_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int max_tiles) {
+  if (ntasks <= 0 || max_tiles <= 0) return;
+  for (int t0 = 0; t0 < ntasks; t0 += 65535) {
+    int nt = std::min(65535, ntasks - t0);
+    hipLaunchKernelGGL(k_dgemm_tasks, dim3(max_tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
+  }
+  HFG_HIP_CHECK(hipGetLastError());
 }
 
 // -------------------------------------------------------------------------------------------------

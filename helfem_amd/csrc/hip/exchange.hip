@@ -270,12 +270,20 @@ static ExAux &exaux_for(hfg_ctx *ctx, hfg_basis *basis) {
   return *a;
 }
 
+bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+
 void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK) {
   if (!basis->dev || !basis->dev->have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
   if (basis->dev_device != ctx->device) throw std::logic_error("basis tables live on a different device\n");
   hfg_dev_tables *t = basis->dev;
-  ExAux &a = exaux_for(ctx, basis);
   ProfScope ps(ctx, "exchange");
+  // fast path for the low-rank densities of SCF runs (exchange_lr.hip); HELFEM_EXCHANGE=general forces the
+  // general kernels below, which take any symmetric P
+  {
+    const char *mode = getenv("HELFEM_EXCHANGE");
+    if (!(mode && std::string(mode) == "general") && exchange_lowrank_dev(ctx, basis, dP, dK)) return;
+  }
+  ExAux &a = exaux_for(ctx, basis);
   hipStream_t s = ctx->stream;
   const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, Nlm = t->Ntab, ntt = t->ntt;
   const size_t RR = (size_t)R * R;

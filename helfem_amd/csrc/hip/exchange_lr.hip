@@ -1,0 +1,602 @@
+// Exact exchange for low-rank densities (gfx950): the fast path of TwoDBasis::exchange
+// (/root/reference/src/diatomic/basis.cpp:1532-1733, src/atomic/TwoDBasis.cpp:957-1140).
+//
+// Every density matrix an SCF run hands to exchange() is P = sum_o s_o l_o l_o^T with a handful of terms
+// (occupied orbitals).  The reference does not use this: it forms, for every output shell pair (j,k) and
+// channel, the R x R matrix  Rmat = sum_{i,l} cpl P_il  and pushes it through the radial integrals.  With the
+// factors the same sums reorganise into dense products:
+//
+//   V^t[(j n),(c o)]   = sum_{i: m_i = m_j - M_c} c_t(j,i,L_c) l_o[(i n)]           channel c = (L,M), t = 0,2
+//   cross-element part:  aP[(j e a),(c o)] = (P0_e V^0 - P2_e V^2)(a),  aQ likewise with the Q integrals,
+//        G = (aQ diag(w)) aP^T   (one GEMM, w = LMfac_c s_o),   K(e>f) -= G[(j e a),(k f b)],  K(e<f) -= G^T
+//   in-element part: for every primitive-table slot tau and element e one GEMM
+//        C_tau,e[(a b),(j k)] = sum_{tt,(i' l')} ktei_tau,e,tt[(a b),(i' l')] RB_tau,e[(tt i' l'),(j k)]
+//        with RB = +-sum_{c in tau, o} w V^t_j[i'] V^t'_k[l'] and ktei the exchange-ordered table
+//        (utils::exchange_tei, libhelfem/src/utils.cpp:130), restricted to the shells that have a channel in tau.
+//
+// The factors come from a diagonally pivoted LDL^T of P (exact for the positive semi-definite, rank-nocc
+// matrices of an SCF run; signs s_o make rank-deficient indefinite inputs work too).  The factorisation is
+// verified (max |P - L S L^T|); if it does not reproduce P to 1e-13 within HFG_EXL_RMAX columns the caller falls
+// back to the general kernels of exchange.hip.  Same sums as the reference, different association order.
+#include "tables.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace hfg {
+
+void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
+              const double *B, int ldb, double beta, double *C, int ldc);
+void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+
+constexpr int EXL_RMAX = 64;
+constexpr int EXL_QMAX = 16;  // rows per thread in the factorisation kernel: N <= 1024 * EXL_QMAX
+
+// -------------------------------------------------------------------------------------------------
+// pivoted LDL^T, one workgroup
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_exl_factor(const double *__restrict__ P, int N, int rmax, double tol,
+                                                     double *__restrict__ L, double *__restrict__ sgn,
+                                                     int *__restrict__ info) {
+  __shared__ double red_v[16];
+  __shared__ int red_i[16];
+  __shared__ double lrow[EXL_RMAX];
+  __shared__ double ssgn[EXL_RMAX];
+  __shared__ double piv_d;
+  __shared__ int piv_i;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double d[EXL_QMAX];
+#pragma unroll
+  for (int q = 0; q < EXL_QMAX; q++) {
+    int i = tid + 1024 * q;
+    d[q] = (i < N) ? P[(size_t)i * N + i] : 0.0;
+  }
+  double dmax0 = 0.0;
+  int r = 0;
+  for (int k = 0; k < rmax; k++) {
+    // ---- pivot: largest |d|, ties to the smallest index (deterministic) ----
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < EXL_QMAX; q++) {
+      int i = tid + 1024 * q;
+      double a = fabs(d[q]);
+      if (i < N && (a > bv || (a == bv && i < bi))) {
+        bv = a;
+        bi = i;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      double ov = __shfl_down(bv, o, 64);
+      int oi = __shfl_down(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      red_v[wave] = bv;
+      red_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double v = red_v[0];
+      int ii = red_i[0];
+      for (int w = 1; w < 16; w++)
+        if (red_v[w] > v || (red_v[w] == v && red_i[w] < ii)) {
+          v = red_v[w];
+          ii = red_i[w];
+        }
+      piv_i = ii;
+    }
+    __syncthreads();
+    const int p = piv_i;
+    // the owner of row p publishes d_p and the row of L built so far (its own earlier stores)
+    if (tid == (p & 1023)) {
+      double dv = 0.0;
+#pragma unroll
+      for (int q = 0; q < EXL_QMAX; q++)
+        if (q == (p >> 10)) dv = d[q];
+      piv_d = dv;
+      for (int j = 0; j < k; j++) lrow[j] = L[(size_t)j * N + p];
+    }
+    __syncthreads();
+    const double dp = piv_d;
+    if (k == 0) dmax0 = fabs(dp);
+    if (!(fabs(dp) > tol * dmax0) || dmax0 == 0.0) break;
+    const double sk = (dp > 0.0) ? 1.0 : -1.0;
+    const double inv = 1.0 / sqrt(fabs(dp));
+    if (tid == 0) ssgn[k] = sk;
+#pragma unroll
+    for (int q = 0; q < EXL_QMAX; q++) {
+      int i = tid + 1024 * q;
+      if (i < N) {
+        double v = P[(size_t)p * N + i];
+        for (int j = 0; j < k; j++) v -= ssgn[j] * L[(size_t)j * N + i] * lrow[j];
+        v *= inv;
+        L[(size_t)k * N + i] = v;
+        d[q] -= sk * v * v;
+        if (i == p) d[q] = 0.0;
+      }
+    }
+    r = k + 1;
+    __syncthreads();
+  }
+  if (tid == 0) info[0] = r;
+  __syncthreads();
+  for (int j = tid; j < r; j += 1024) sgn[j] = ssgn[j];
+}
+
+__device__ inline void atomic_max_nonneg(double *addr, double v) {
+  atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// dinfo[0] = max |P - L S L^T|, dinfo[1] = max |P|.  Workgroup = 256 rows x 32 columns: a thread keeps its row of L
+// in registers, the 32 scaled rows of the column block sit in LDS.
+__global__ __launch_bounds__(256) void k_exl_resid(const double *__restrict__ P, int N, const double *__restrict__ L,
+                                                   const double *__restrict__ sgn, const int *__restrict__ info,
+                                                   double *__restrict__ dinfo) {
+  __shared__ double lj[32][EXL_RMAX + 1];
+  const int r = info[0];
+  const int j0 = blockIdx.y * 32;
+  for (int t = threadIdx.x; t < 32 * r; t += 256) {
+    int jj = t % 32, k = t / 32;
+    lj[jj][k] = (j0 + jj < N) ? sgn[k] * L[(size_t)k * N + j0 + jj] : 0.0;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double li[EXL_RMAX];
+#pragma unroll
+  for (int k = 0; k < EXL_RMAX; k++) li[k] = (k < r && i < N) ? L[(size_t)k * N + i] : 0.0;
+  __syncthreads();
+  double res = 0.0, pa = 0.0;
+  if (i < N)
+    for (int jj = 0; jj < 32 && j0 + jj < N; jj++) {
+      double pv = P[(size_t)(j0 + jj) * N + i];
+      double acc = pv;
+#pragma unroll
+      for (int k = 0; k < EXL_RMAX; k++)
+        if (k < r) acc -= li[k] * lj[jj][k];
+      res = fmax(res, fabs(acc));
+      pa = fmax(pa, fabs(pv));
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    res = fmax(res, __shfl_down(res, o, 64));
+    pa = fmax(pa, __shfl_down(pa, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomic_max_nonneg(dinfo, res);
+    atomic_max_nonneg(dinfo + 1, pa);
+  }
+}
+
+// Ld[(x,n), o] (Nd x r): the factor in the (shell, dummy radial index) numbering
+__global__ void k_exl_expand(const double *__restrict__ L, int N, int Nd, int R, int r, const int *__restrict__ shell_off,
+                             const int *__restrict__ shell_skip, double *__restrict__ Ld) {
+  int row = blockIdx.x * blockDim.x + threadIdx.x;
+  int o = blockIdx.y;
+  if (row >= Nd || o >= r) return;
+  int x = row / R, n = row % R;
+  double v = 0.0;
+  if (!(shell_skip[x] && n == 0)) v = L[(size_t)o * N + shell_off[x] + n];
+  Ld[(size_t)o * Nd + row] = v;
+}
+
+// V^t[(c,o)][(j,n)] = sum_{i: m_i = m_j - M_c} c_t(j,i,L_c) Ld[(i,n),o]
+__global__ void k_exl_V(const double *__restrict__ Ld, int Nd, int R, int A, int r, const int *__restrict__ LM_L,
+                        const int *__restrict__ LM_M, const int *__restrict__ shell_m,
+                        const double *__restrict__ c0tab, const double *__restrict__ c2tab, int Lp1, int two,
+                        double *__restrict__ V0, double *__restrict__ V2) {
+  const int c = blockIdx.x, j = blockIdx.y;
+  const int L = LM_L[c], need = shell_m[j] - LM_M[c];
+  for (int t = threadIdx.x; t < R * r; t += blockDim.x) {
+    int n = t % R, o = t / R;
+    double u0 = 0.0, u2 = 0.0;
+    for (int i = 0; i < A; i++) {
+      if (shell_m[i] != need) continue;
+      double a0 = c0tab[((size_t)j * A + i) * Lp1 + L];
+      double a2 = two ? c2tab[((size_t)j * A + i) * Lp1 + L] : 0.0;
+      if (a0 == 0.0 && a2 == 0.0) continue;
+      double lv = Ld[(size_t)o * Nd + i * R + n];
+      u0 += a0 * lv;
+      u2 += a2 * lv;
+    }
+    size_t off = ((size_t)c * r + o) * Nd + (size_t)j * R + n;
+    V0[off] = u0;
+    if (two) V2[off] = u2;
+  }
+}
+
+// aP[(c,o)][(j,e,a)] = sum_c' P0_e(a,c') V0[j, e(p-1)+c'] - P2_e(a,c') V2[...];  aQw = w_(c,o) * (same with Q0, Q2)
+__global__ void k_exl_alpha(const double *__restrict__ V0, const double *__restrict__ V2, const double *__restrict__ disj,
+                            const int *__restrict__ LM_tab, const int *__restrict__ LM_ilm,
+                            const double *__restrict__ LM_fac, const double *__restrict__ sgn, int Nd, int R, int A, int E,
+                            int p, int r, int Ntab, int two, int rank, int nranks, double *__restrict__ aP,
+                            double *__restrict__ aQw) {
+  const int col = blockIdx.x, j = blockIdx.y;
+  const int c = col / r, o = col % r;
+  const int tab = LM_tab[c];
+  const int pp = p * p;
+  // multi-GPU: the (L,M) channels of the cross-element part are dealt out over the ranks
+  const double w = (LM_ilm[c] % nranks == rank) ? LM_fac[c] * sgn[o] : 0.0;
+  const int tQ0 = two ? 2 : 1;
+  const size_t Na = (size_t)A * E * p;
+  const double *v0 = V0 + (size_t)col * Nd + (size_t)j * R;
+  const double *v2 = two ? V2 + (size_t)col * Nd + (size_t)j * R : nullptr;
+  for (int t = threadIdx.x; t < E * p; t += blockDim.x) {
+    int e = t / p, a = t % p;
+    const double *P0 = disj + (((size_t)0 * Ntab + tab) * E + e) * pp;
+    const double *Q0 = disj + (((size_t)tQ0 * Ntab + tab) * E + e) * pp;
+    const double *P2 = two ? disj + (((size_t)1 * Ntab + tab) * E + e) * pp : nullptr;
+    const double *Q2 = two ? disj + (((size_t)3 * Ntab + tab) * E + e) * pp : nullptr;
+    double sp = 0.0, sq = 0.0;
+    for (int cc = 0; cc < p; cc++) {
+      int n = e * (p - 1) + cc;
+      if (n >= R) continue;
+      double x0 = v0[n];
+      sp += P0[cc * p + a] * x0;
+      sq += Q0[cc * p + a] * x0;
+      if (two) {
+        double x2 = v2[n];
+        sp -= P2[cc * p + a] * x2;
+        sq -= Q2[cc * p + a] * x2;
+      }
+    }
+    size_t off = (size_t)col * Na + ((size_t)e * A + j) * p + a;  // rows ordered (element, shell, primitive)
+    aP[off] = sp;
+    aQw[off] = w * sq;
+  }
+}
+
+// ktei[tab][e][tt][(i' + p l')][(a + p b)] = tei_tt[tab][e][(a p + i'), (l' p + b)]   (utils::exchange_tei)
+__global__ void k_exl_permute_tei(const double *__restrict__ tei, int Ntab, int E, int p, int ntt,
+                                  double *__restrict__ ktei) {
+  const int blk = blockIdx.x;  // (tt*Ntab + tab)*E + e
+  const int e = blk % E, tab = (blk / E) % Ntab, tt = blk / (E * Ntab);
+  const int pp = p * p;
+  const double *T = tei + (size_t)blk * pp * pp;
+  double *K = ktei + (((size_t)tab * E + e) * ntt + tt) * (size_t)pp * pp;
+  const int lp = blockIdx.y;
+  for (int t = threadIdx.x; t < p * pp; t += blockDim.x) {
+    int m = t % pp, ip = t / pp;
+    int a = m % p, b = m / p;
+    K[(size_t)(ip + p * lp) * pp + m] = T[(size_t)(lp * p + b) * pp + a * p + ip];
+  }
+}
+
+// RB_tau,e[(tt, i', l'), (pj, pk)] = sign_tt sum_{c in tau} sum_o w V^t[(c,o)][(j,e,i')] V^t'[(c,o)][(k,e,l')]
+__global__ void k_exl_RB(const double *__restrict__ V0, const double *__restrict__ V2, const int *__restrict__ tab_ch_off,
+                         const int *__restrict__ tab_ch, const double *__restrict__ LM_fac,
+                         const double *__restrict__ sgn, const int *__restrict__ S_off, const int *__restrict__ S_list,
+                         const long long *__restrict__ rb_off, int tau, int Nd, int R, int E, int p, int r, int ntt,
+                         double *__restrict__ RB) {
+  extern __shared__ double sh[];  // vj[2][nco][p], vk[2][nco][p], w[nco]
+  const int e = blockIdx.y;
+  const int ns = S_off[tau + 1] - S_off[tau];
+  const int n = blockIdx.x;  // pair pj <= pk, n = pk (pk + 1) / 2 + pj  (K is symmetric: K_kj = K_jk^T)
+  const int npair = ns * (ns + 1) / 2;
+  if (n >= npair) return;
+  int pk = (int)((sqrt(8.0 * n + 1.0) - 1.0) * 0.5);
+  while ((pk + 1) * (pk + 2) / 2 <= n) pk++;
+  while (pk * (pk + 1) / 2 > n) pk--;
+  const int pj = n - pk * (pk + 1) / 2;
+  const int j = S_list[S_off[tau] + pj], k = S_list[S_off[tau] + pk];
+  const int c0 = tab_ch_off[tau], nch = tab_ch_off[tau + 1] - c0;
+  const int nco = nch * r;
+  double *vj = sh, *vk = sh + 2 * nco * p, *w = sh + 4 * nco * p;
+  const bool two = (ntt == 4);
+  for (int t = threadIdx.x; t < nco * p; t += blockDim.x) {
+    int ii = t % p, co = t / p;
+    int c = tab_ch[c0 + co / r], o = co % r;
+    int nn = e * (p - 1) + ii;
+    size_t col = (size_t)c * r + o;
+    bool ok = nn < R;
+    vj[t] = ok ? V0[col * Nd + (size_t)j * R + nn] : 0.0;
+    vk[t] = ok ? V0[col * Nd + (size_t)k * R + nn] : 0.0;
+    vj[nco * p + t] = (ok && two) ? V2[col * Nd + (size_t)j * R + nn] : 0.0;
+    vk[nco * p + t] = (ok && two) ? V2[col * Nd + (size_t)k * R + nn] : 0.0;
+    if (ii == 0) w[co] = LM_fac[c] * sgn[o];
+  }
+  __syncthreads();
+  const int pp = p * p;
+  const int Kt = ntt * pp;
+  double *out = RB + rb_off[tau] + ((size_t)e * npair + n) * Kt;
+  // thread (i', l') forms all type combinations at once: 4 LDS reads per 4 FMAs
+  for (int il = threadIdx.x; il < pp; il += blockDim.x) {
+    int ip = il % p, lp = il / p;
+    const double *a0 = vj, *a2 = vj + (size_t)nco * p, *b0 = vk, *b2 = vk + (size_t)nco * p;
+    double s00 = 0.0, s02 = 0.0, s20 = 0.0, s22 = 0.0;
+    if (two) {
+      for (int co = 0; co < nco; co++) {
+        double wa0 = w[co] * a0[co * p + ip], wa2 = w[co] * a2[co * p + ip];
+        double x0 = b0[co * p + lp], x2 = b2[co * p + lp];
+        s00 += wa0 * x0;
+        s02 += wa0 * x2;
+        s20 += wa2 * x0;
+        s22 += wa2 * x2;
+      }
+      out[il] = s00;            // tt = 00
+      out[pp + il] = -s02;      // 02
+      out[2 * pp + il] = -s20;  // 20
+      out[3 * pp + il] = s22;   // 22
+    } else {
+      for (int co = 0; co < nco; co++) s00 += w[co] * a0[co * p + ip] * b0[co * p + lp];
+      out[il] = s00;
+    }
+  }
+}
+
+// Kin[(j,k)][e][(a + p b)] = sum over the table slots that contain both shells of C_tau,e[(a b),(pj,pk)]; the GEMMs
+// only cover pj <= pk, the other half is the transpose
+__global__ void k_exl_reduce(const double *__restrict__ C, const long long *__restrict__ c_off,
+                             const int *__restrict__ S_off, const int *__restrict__ pos, int A, int E, int p, int Ntab,
+                             double *__restrict__ Kin) {
+  const int jk = blockIdx.x, e = blockIdx.y;
+  const int j = jk / A, k = jk % A;
+  const int pp = p * p;
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+    const int a = t % p, b = t / p;
+    double s = 0.0;
+    for (int tau = 0; tau < Ntab; tau++) {
+      if (c_off[tau] < 0) continue;
+      int pj = pos[tau * A + j], pk = pos[tau * A + k];
+      if (pj < 0 || pk < 0) continue;
+      int ns = S_off[tau + 1] - S_off[tau];
+      size_t npair = (size_t)ns * (ns + 1) / 2;
+      if (pj <= pk) s += C[c_off[tau] + ((size_t)e * npair + (size_t)pk * (pk + 1) / 2 + pj) * pp + a + p * b];
+      else s += C[c_off[tau] + ((size_t)e * npair + (size_t)pj * (pj + 1) / 2 + pk) * pp + b + p * a];
+    }
+    Kin[((size_t)jk * E + e) * pp + t] = s;
+  }
+}
+
+// K(pure row, pure col) = -(in-element + cross-element contributions)
+// G holds, for every element pair e > f, the block G_ef[(j,a),(k,b)] (A p x A p, column-major) at ((e (e-1))/2 + f)
+__global__ void k_exl_assemble(const double *__restrict__ Kin, const double *__restrict__ G, int N, int A, int E, int p,
+                               const int *__restrict__ pure_shell, const int *__restrict__ pure_n,
+                               double *__restrict__ K) {
+  int row = blockIdx.x * 64 + (threadIdx.x & 63);
+  int col = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (row >= N || col >= N) return;
+  const int j = pure_shell[row], n = pure_n[row], k = pure_shell[col], m = pure_n[col];
+  const int pm = p - 1, pp = p * p;
+  const size_t Ap = (size_t)A * p;
+  double v = 0.0;
+  for (int ce = 0; ce < 2; ce++) {
+    int e = n / pm - ce;
+    if (e < 0 || e >= E) continue;
+    int a = n - e * pm;
+    if (a < 0 || a > pm) continue;
+    for (int cf = 0; cf < 2; cf++) {
+      int f = m / pm - cf;
+      if (f < 0 || f >= E) continue;
+      int b = m - f * pm;
+      if (b < 0 || b > pm) continue;
+      size_t ra = (size_t)j * p + a, rb = (size_t)k * p + b;
+      if (e == f) v += Kin[(((size_t)j * A + k) * E + e) * pp + a + p * b];
+      else if (e > f) v += G[((size_t)e * (e - 1) / 2 + f) * Ap * Ap + rb * Ap + ra];
+      else v += G[((size_t)f * (f - 1) / 2 + e) * Ap * Ap + ra * Ap + rb];
+    }
+  }
+  K[(size_t)col * N + row] = -v;
+}
+
+struct ExLRAux {
+  DevBuf<double> c0tab, c2tab, ktei, L, sgn, dinfo, Ld, V0, V2, aP, aQw, G, RB, C, Kin;
+  DevBuf<int> info, LM_L, LM_M, tab_ch_off, tab_ch, S_off, S_list, pos, pure_shell, pure_n;
+  DevBuf<long long> rb_off, c_off;
+  DevBuf<GemmTask> tasks, ctasks;
+  std::vector<int> hS_off;
+  std::vector<int> h_nch;  // channels per slot
+  int max_nch = 0;
+};
+static std::map<hfg_dev_tables *, ExLRAux *> g_exlr;
+
+void exchange_lr_release(hfg_dev_tables *t) {
+  auto it = g_exlr.find(t);
+  if (it != g_exlr.end()) {
+    delete it->second;
+    g_exlr.erase(it);
+  }
+}
+
+static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
+  auto it = g_exlr.find(t);
+  if (it != g_exlr.end()) return *it->second;
+  ExLRAux *a = new ExLRAux();
+  hipStream_t s = ctx->stream;
+  const int A = t->A, Ntab = t->Ntab, NLM = t->NLM, Lp1 = t->Lp1;
+  a->c0tab.upload(t->h_c0tab, s);
+  a->c2tab.upload(t->h_c2tab, s);
+  a->LM_L.upload(t->h_LM_L, s);
+  a->LM_M.upload(t->h_LM_M, s);
+  // channels per table slot, shells per table slot
+  std::vector<std::vector<int> > ch_of(Ntab), S_of(Ntab);
+  std::vector<int> LM_tab(NLM);
+  for (int c = 0; c < NLM; c++) {
+    LM_tab[c] = t->h_lm_tab[t->h_LM_ilm[c]];
+    ch_of[LM_tab[c]].push_back(c);
+  }
+  std::vector<int> pos((size_t)Ntab * A, -1);
+  for (int tau = 0; tau < Ntab; tau++)
+    for (int j = 0; j < A; j++) {
+      bool has = false;
+      for (int c : ch_of[tau]) {
+        int L = t->h_LM_L[c], need = t->h_shell_m[j] - t->h_LM_M[c];
+        for (int i = 0; i < A && !has; i++)
+          if (t->h_shell_m[i] == need && (t->h_c0tab[((size_t)j * A + i) * Lp1 + L] != 0.0 ||
+                                          t->h_c2tab[((size_t)j * A + i) * Lp1 + L] != 0.0))
+            has = true;
+        if (has) break;
+      }
+      if (has) {
+        pos[(size_t)tau * A + j] = (int)S_of[tau].size();
+        S_of[tau].push_back(j);
+      }
+    }
+  std::vector<int> ch_off(Ntab + 1, 0), ch_list, S_off(Ntab + 1, 0), S_list;
+  a->h_nch.resize(Ntab);
+  for (int tau = 0; tau < Ntab; tau++) {
+    ch_off[tau] = (int)ch_list.size();
+    ch_list.insert(ch_list.end(), ch_of[tau].begin(), ch_of[tau].end());
+    S_off[tau] = (int)S_list.size();
+    S_list.insert(S_list.end(), S_of[tau].begin(), S_of[tau].end());
+    a->h_nch[tau] = (int)ch_of[tau].size();
+    a->max_nch = std::max(a->max_nch, a->h_nch[tau]);
+  }
+  ch_off[Ntab] = (int)ch_list.size();
+  S_off[Ntab] = (int)S_list.size();
+  a->hS_off = S_off;
+  a->tab_ch_off.upload(ch_off, s);
+  a->tab_ch.upload(ch_list, s);
+  a->S_off.upload(S_off, s);
+  a->S_list.upload(S_list, s);
+  a->pos.upload(pos, s);
+  std::vector<int> ps, pn;
+  for (int x = 0; x < A; x++)
+    for (int n = (t->h_shell_skip[x] ? 1 : 0); n < t->R; n++) {
+      ps.push_back(x);
+      pn.push_back(n);
+    }
+  a->pure_shell.upload(ps, s);
+  a->pure_n.upload(pn, s);
+  // exchange-ordered primitive tables
+  const size_t pp = (size_t)t->p * t->p;
+  a->ktei.resize((size_t)t->ntt * Ntab * t->E * pp * pp);
+  hipLaunchKernelGGL(k_exl_permute_tei, dim3(t->ntt * Ntab * t->E, t->p), dim3(256), 0, s, t->tei.p, Ntab, t->E, t->p,
+                     t->ntt, a->ktei.p);
+  HFG_HIP_CHECK(hipStreamSynchronize(s));
+  g_exlr[t] = a;
+  return *a;
+}
+
+/// K from P through the low-rank factors.  Returns false (nothing written) when P is not reproduced by at most
+/// EXL_RMAX factors; the caller then runs the general kernels.
+bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK) {
+  hfg_dev_tables *t = basis->dev;
+  const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, NLM = t->NLM, Ntab = t->Ntab, ntt = t->ntt;
+  if (N > 1024 * EXL_QMAX) return false;
+  ExLRAux &a = exlr_for(ctx, t);
+  hipStream_t s = ctx->stream;
+  const int two = (ntt == 4) ? 1 : 0;
+  const int pp = p * p;
+
+  // ---- factorise and verify ----
+  a.L.resize((size_t)N * EXL_RMAX);
+  a.sgn.resize(EXL_RMAX);
+  a.info.resize(4);
+  a.dinfo.resize(4);
+  HFG_HIP_CHECK(hipMemsetAsync(a.dinfo.p, 0, 4 * sizeof(double), s));
+  hipLaunchKernelGGL(k_exl_factor, dim3(1), dim3(1024), 0, s, dP, N, EXL_RMAX, 1e-14, a.L.p, a.sgn.p, a.info.p);
+  hipLaunchKernelGGL(k_exl_resid, dim3((N + 255) / 256, (N + 31) / 32), dim3(256), 0, s, dP, N, a.L.p, a.sgn.p, a.info.p, a.dinfo.p);
+  int r = 0;
+  double dinfo[2] = {0, 0};
+  HFG_HIP_CHECK(hipMemcpyAsync(&r, a.info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HFG_HIP_CHECK(hipMemcpyAsync(dinfo, a.dinfo.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HFG_HIP_CHECK(hipStreamSynchronize(s));
+  if (!(dinfo[0] <= 1e-13 * dinfo[1])) return false;
+  if ((size_t)(4 * a.max_nch * r * p + a.max_nch * r) * sizeof(double) > 150 * 1024) return false;  // LDS tile of k_exl_RB
+  if (r == 0) {  // P == 0
+    HFG_HIP_CHECK(hipMemsetAsync(dK, 0, sizeof(double) * (size_t)N * N, s));
+    return true;
+  }
+
+  // ---- angular stage ----
+  const size_t ncol = (size_t)NLM * r;
+  const size_t Na = (size_t)A * E * p;
+  a.Ld.resize((size_t)Nd * r);
+  a.V0.resize(ncol * Nd);
+  if (two) a.V2.resize(ncol * Nd);
+  a.aP.resize(ncol * Na);
+  a.aQw.resize(ncol * Na);
+  const size_t Ap = (size_t)A * p;
+  a.G.resize(std::max<size_t>((size_t)E * (E - 1) / 2 * Ap * Ap, 1));
+  hipLaunchKernelGGL(k_exl_expand, dim3((Nd + 255) / 256, r), dim3(256), 0, s, a.L.p, N, Nd, R, r, t->shell_off.p,
+                     t->shell_skip.p, a.Ld.p);
+  hipLaunchKernelGGL(k_exl_V, dim3(NLM, A), dim3(256), 0, s, a.Ld.p, Nd, R, A, r, a.LM_L.p, a.LM_M.p, t->shell_m.p,
+                     a.c0tab.p, a.c2tab.p, t->Lp1, two, a.V0.p, a.V2.p);
+  hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol, A), dim3(128), 0, s, a.V0.p, a.V2.p, t->disj.p, t->LM_tab.p,
+                     t->LM_ilm.p, t->LM_fac.p, a.sgn.p, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
+                     a.aQw.p);
+  // ---- cross-element part: G_ef = aQw_e aP_f^T for e > f (the other half of K is its transpose) ----
+  {
+    std::vector<GemmTask> ct;
+    for (int e = 1; e < E; e++)
+      for (int f = 0; f < e; f++) {
+        GemmTask g;
+        g.A = a.aQw.p + (size_t)e * Ap;
+        g.B = a.aP.p + (size_t)f * Ap;
+        g.C = a.G.p + ((size_t)e * (e - 1) / 2 + f) * Ap * Ap;
+        g.M = g.N = (int)Ap;
+        g.K = (int)ncol;
+        g.lda = g.ldb = (int)Na;
+        g.ldc = (int)Ap;
+        g.tB = 1;
+        ct.push_back(g);
+      }
+    if (!ct.empty()) {
+      a.ctasks.upload(ct, s);
+      HFG_HIP_CHECK(hipStreamSynchronize(s));  // ct lives on this stack frame
+      gemm_tasklist_dev(ctx, a.ctasks.p, (int)ct.size(), (int)Ap, (int)Ap);
+    }
+  }
+
+  // ---- in-element part: one GEMM per (table slot, element); slots are dealt out over the ranks ----
+  std::vector<long long> rb_off(Ntab, -1), c_off(Ntab, -1);
+  std::vector<GemmTask> tasks;
+  const int Kt = ntt * pp;
+  size_t rb_tot = 0, c_tot = 0;
+  int maxN = 0;
+  for (int tau = 0; tau < Ntab; tau++) {
+    int ns = a.hS_off[tau + 1] - a.hS_off[tau];
+    if (ns == 0 || (tau % ctx->shard_n) != ctx->shard_rank) continue;
+    rb_off[tau] = (long long)rb_tot;
+    c_off[tau] = (long long)c_tot;
+    rb_tot += (size_t)E * (ns * (ns + 1) / 2) * Kt;
+    c_tot += (size_t)E * (ns * (ns + 1) / 2) * pp;
+    maxN = std::max(maxN, ns * (ns + 1) / 2);
+  }
+  a.RB.resize(std::max<size_t>(rb_tot, 1));
+  a.C.resize(std::max<size_t>(c_tot, 1));
+  for (int tau = 0; tau < Ntab; tau++) {
+    if (rb_off[tau] < 0) continue;
+    int ns = a.hS_off[tau + 1] - a.hS_off[tau];
+    const size_t npair = (size_t)ns * (ns + 1) / 2;
+    for (int e = 0; e < E; e++) {
+      GemmTask g;
+      g.A = a.ktei.p + (((size_t)tau * E + e) * ntt) * (size_t)pp * pp;
+      g.B = a.RB.p + rb_off[tau] + (size_t)e * npair * Kt;
+      g.C = a.C.p + c_off[tau] + (size_t)e * npair * pp;
+      g.M = pp;
+      g.N = (int)npair;
+      g.K = Kt;
+      g.lda = pp;
+      g.ldb = Kt;
+      g.ldc = pp;
+      tasks.push_back(g);
+    }
+  }
+  a.rb_off.upload(rb_off, s);
+  a.c_off.upload(c_off, s);
+  a.Kin.resize((size_t)A * A * E * pp);
+  if (!tasks.empty()) {
+    a.tasks.upload(tasks, s);
+    size_t shb = (size_t)(4 * a.max_nch * r * p + a.max_nch * r) * sizeof(double);
+    if (shb > 64 * 1024)
+      HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_RB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+    for (int tau = 0; tau < Ntab; tau++) {
+      if (rb_off[tau] < 0) continue;
+      int ns = a.hS_off[tau + 1] - a.hS_off[tau];
+      hipLaunchKernelGGL(k_exl_RB, dim3(ns * (ns + 1) / 2, E), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p, a.tab_ch.p,
+                         t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau, Nd, R, E, p, r, ntt, a.RB.p);
+    }
+    gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
+  }
+  hipLaunchKernelGGL(k_exl_reduce, dim3(A * A, E), dim3(256), 0, s, a.C.p, a.c_off.p, a.S_off.p, a.pos.p, A, E, p, Ntab,
+                     a.Kin.p);
+  dim3 grid((N + 63) / 64, (N + 3) / 4);
+  hipLaunchKernelGGL(k_exl_assemble, grid, dim3(256), 0, s, a.Kin.p, a.G.p, N, A, E, p, a.pure_shell.p, a.pure_n.p, dK);
+  HFG_HIP_CHECK(hipGetLastError());
+  HFG_HIP_CHECK(hipStreamSynchronize(s));  // host task list and offsets live on this stack frame
+  return true;
+}
+
+}  // namespace hfg

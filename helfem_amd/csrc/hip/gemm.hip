@@ -18,28 +18,29 @@
 // LDS tiles are stored [k][m] with the row padded by 16 doubles: the four k-rows a wave reads at
 // once then fall on disjoint 128-B bank groups (conflict-free ds_read_b64).
 #include "common.h"
+#include <algorithm>
 
 namespace hfg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// one BM x BN tile (linear tile index id) of one product; As/Bs are the workgroup's LDS tiles
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
-                                               const double *__restrict__ A, int lda, const double *__restrict__ B,
-                                               int ldb, double beta, double *__restrict__ C, int ldc) {
+__device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
+                                           const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
+                                           double beta, double *__restrict__ C, int ldc, double (*As)[BM + 16],
+                                           double (*Bs)[BN + 16]) {
   constexpr int BK = 16;
   constexpr int PAD = 16;
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int EA = BM * BK / 256, EB = BN * BK / 256;  // elements per thread per tile
-  __shared__ double As[BK][BM + PAD];
-  __shared__ double Bs[BK][BN + PAD];
+  static_assert(PAD == 16, "LDS row padding is part of the tile types");
 
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
   // contiguous strip of tiles (they share A row panels / B column panels in that XCD's L2)
   int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
   int nwg = nbm * nbn;
-  int id = blockIdx.x;
   {
     int q = nwg / 8, r = nwg % 8, xcd = id % 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
@@ -155,6 +156,39 @@ __global__ __launch_bounds__(256) void k_dgemm(int transA, int transB, int M, in
           C[o] = v;
         }
       }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
+                                               const double *__restrict__ A, int lda, const double *__restrict__ B,
+                                               int ldb, double beta, double *__restrict__ C, int ldc) {
+  __shared__ double As[16][BM + 16];
+  __shared__ double Bs[16][BN + 16];
+  dgemm_tile<BM, BN>(blockIdx.x, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, As, Bs);
+}
+
+// the same tile engine over a device-side task list: C_t = A_t B_t, grid (max tiles, tasks)
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_dgemm_tasklist(const GemmTask *__restrict__ tasks) {
+  __shared__ double As[16][BM + 16];
+  __shared__ double Bs[16][BN + 16];
+  const GemmTask t = tasks[blockIdx.y];
+  if (t.M <= 0 || t.N <= 0) return;
+  const int nt = ((t.M + BM - 1) / BM) * ((t.N + BN - 1) / BN);
+  if ((int)blockIdx.x >= nt) return;
+  dgemm_tile<BM, BN>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, 1.0, t.A, t.lda, t.B, t.ldb, 0.0, t.C, t.ldc, As, Bs);
+}
+
+/// launches the task list with 128 x 128 tiles; max_mn = largest (M, N) over the tasks
+void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
+  if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
+  for (int t0 = 0; t0 < ntasks; t0 += 65535) {
+    int nt = std::min(65535, ntasks - t0);
+    hipLaunchKernelGGL((k_dgemm_tasklist<128, 128>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
+  }
+  HFG_HIP_CHECK(hipGetLastError());
 }
 
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,

@@ -102,6 +102,50 @@ def test_exchange_parity(case):
         assert common.relerr(K, Ko) < 1e-12, (name, tag, common.relerr(K, Ko))
 
 
+def test_exchange_general_kernels_parity(case, monkeypatch):
+    """HELFEM_EXCHANGE=general: the kernels that take any symmetric P (the fallback of the low-rank fast path)"""
+    import common
+    name, gb, ob, _, _ = case
+    monkeypatch.setenv("HELFEM_EXCHANGE", "general")
+    tag, P = list(_densities(gb))[1]
+    K = gb.exchange(P)
+    assert common.relerr(K, ob.exchange(P)) < 1e-12, name
+
+
+def test_exchange_indefinite_and_full_rank_inputs(case):
+    """a difference density (indefinite, low rank: signed factors) and a full-rank symmetric matrix (falls back)"""
+    import common
+    name, gb, ob, _, _ = case
+    N = gb.Nbf()
+    P1 = common.random_density(N, 3, seed=31) - common.random_density(N, 2, seed=32)
+    K = gb.exchange(P1)
+    assert common.relerr(K, ob.exchange(P1)) < 1e-11, (name, "indefinite")
+    rng = np.random.RandomState(5)
+    P2 = rng.uniform(-1, 1, size=(N, N))
+    P2 = np.asfortranarray(P2 + P2.T)
+    K = gb.exchange(P2)
+    assert common.relerr(K, ob.exchange(P2)) < 1e-12, (name, "full rank")
+    K0 = gb.exchange(np.zeros((N, N), order="F"))
+    assert np.all(K0 == 0.0)
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_exchange_shards_sum_to_full(case, hf, nranks):
+    import common
+    name, gb, ob, _, _ = case
+    tag, P = list(_densities(gb))[1]
+    ctx = gb.ctx
+    full = gb.exchange(P)
+    acc = np.zeros_like(full)
+    try:
+        for rk in range(nranks):
+            ctx.set_shard(rk, nranks)
+            acc += gb.exchange(P)
+    finally:
+        ctx.set_shard(0, 1)
+    assert common.relerr(acc, full) < 1e-12, name
+
+
 @pytest.mark.parametrize("funcs", [(1, 7), (1, 0), (101, 130), (101, 0), (0, 130), (1, 12)])
 def test_xc_parity(case, hf, funcs):
     import common
