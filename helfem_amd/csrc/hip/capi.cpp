@@ -555,7 +555,7 @@ int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launche
 
 int hfg_measure_kernel(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches) {
   HFG_TRY
-  if (std::string(name) == "k_trdb_gemv") trd_measure_gemv(ctx, ms, launches);
+  if (std::string(name) == "k_trdb_gemv" || std::string(name) == "k_trdf") trd_measure_gemv(ctx, ms, launches);
   else throw std::logic_error("hfg_measure_kernel: unknown kernel");
   HFG_CATCH
 }

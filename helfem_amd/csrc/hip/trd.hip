@@ -16,6 +16,8 @@
 //                                          together with the partial norms its Householder vector needs.
 // No atomics; all reductions have a fixed order, so the factorisation is bitwise reproducible.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace hfg {
 
@@ -25,6 +27,8 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
 constexpr int TB_MAXB = 8;
 constexpr int TB_NB = 32;   // panel width
 constexpr int TB_NCS = 8;   // column slabs of the trailing-matrix sweep
+constexpr int TF_T = 128;    // tile edge of the fused kernel
+constexpr int TF_MAXS = 40;  // max slabs per dimension: n <= TF_T * (TF_MAXS - 1)
 
 struct TrdBatch {
   int n[TB_MAXB];
@@ -36,6 +40,12 @@ struct TrdBatch {
   double *pp[TB_MAXB];               // NCS x n partial A22 v
   double *dots[TB_MAXB];             // partial v^T A22 v per gemv workgroup
   double *cpart[TB_MAXB];            // nslab x 2NB partial V^T v, W^T v
+  // fused one-launch-per-column variant (k_trdf): everything below is double buffered by column parity
+  double *fx[TB_MAXB];               // 2 x n: unnormalised current column x
+  double *fpp[TB_MAXB];              // 2 x TF_MAXS x n: partial A22 x per column slab
+  double *fdots[TB_MAXB];            // 2 x TF_MAXS^2: partial x^T A22 x per workgroup
+  double *fxn2[TB_MAXB];             // 2 x TF_MAXS: partial |x[1:]|^2 per column slab
+  double *fcp[TB_MAXB];              // 2 x TF_MAXS x 2NB: partial V^T x, W^T x per column slab
 };
 
 __device__ inline void tb_householder(const double *__restrict__ x, int m, double xn2, double &tau, double &beta,
@@ -359,6 +369,339 @@ __global__ __launch_bounds__(256) void k_trdb_w(const TrdBatch *__restrict__ bp,
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// One launch per Householder column.
+//
+// The reflector of column j is v = (x - beta e1)/(alpha - beta) with x the (already updated) column and
+// beta = -sign(alpha) |x|.  Everything dlatrd needs from the trailing matrix is linear in v, so the sweep can be
+// done with the UNNORMALISED x before |x| is known:
+//     q = P x,   P = A22 - V W^T - W V^T  (stale trailing matrix + panel correction),   z = P e1 = next true column
+//     p = P v = scale (q - beta z),   v^T p = scale^2 (x^T q - 2 beta q_0 + beta^2 z_0),   scale = 1/(alpha - beta)
+//     w = tau p - (tau^2/2)(v^T p) v,     next column x' = z - v w_0 - w  (rows below its diagonal), d' = z_0 - 2 w_0
+// Kernel K_i therefore (A) reduces the partial sums column i-1 left behind and finishes that column for the rows
+// it needs (its tile's row slab and column slab; redundantly per workgroup, all loads independent), which yields
+// x_i there, and (B) sweeps its 128 x 128 tile of the trailing matrix with x_i, leaving partial q, x^T q, |x|^2,
+// V^T x, W^T x for K_{i+1}.  No norm, no second launch, no atomics; fixed summation orders.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, int i, int c, int sweep) {
+  // 1024 threads: the panel corrections of a row are split over four thread groups (cc = grp, grp+4, ...), the
+  // 128 columns of the tile over sixteen waves -- every serial loop of the column step is a quarter as long.
+  const TrdBatch &b = *bp;
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  const int j = i - 1;
+  const bool has_prev = (c > 0) && (j >= 0) && (j <= n - 3);
+  const bool has_cur = (sweep & 1) && (i <= n - 3);
+  const int dbg = sweep >> 1;  // measurement-only switches of the replay (0 in the factorisation)
+  if (!has_prev && !has_cur) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int grp = tid >> 8, rid = tid & 255;  // thread group, row slot
+  const int m = n - i - 1;                    // rows below the diagonal of column i
+  double *A = b.A[blk];
+  const int par = i & 1, ppar = par ^ 1;
+  const int cp = c - 1;  // panel column of the previous reflector; panel columns cc < cp precede it
+
+  // ---- tile of this workgroup ----
+  const bool vec2 = ((n & 1) == 0);
+  const int delta = (has_cur && vec2) ? ((i + 1) & 1) : 0;  // shift that makes every row pair a 16-byte aligned double2
+  int rs, cs, ncs, nrt;
+  if (has_cur) {
+    ncs = (m + TF_T - 1) / TF_T;
+    nrt = (m + 1 + TF_T - 1) / TF_T;
+    rs = blockIdx.x / ncs;
+    cs = blockIdx.x % ncs;
+    if (rs >= nrt) return;
+  } else {  // finishing only: row slabs over g >= i
+    ncs = 1;
+    nrt = (m + 1 + TF_T - 1) / TF_T;
+    rs = blockIdx.x;
+    cs = 0;
+    if (rs >= nrt) return;
+  }
+  const int gR0 = has_cur ? (i + 1 + TF_T * rs - delta) : (i + TF_T * rs);  // first row of the row slab
+  const int gC0 = i + 1 + TF_T * cs;                                        // first row/col of the column slab
+
+  __shared__ double xR[TF_T], xC[TF_T], vC[TF_T], wC[TF_T];
+  __shared__ double red[16 * TF_T];
+  __shared__ double qpart[4][2 * TF_T], zpart[4][2 * TF_T];
+  __shared__ double sVtX[TB_NB], sWtX[TB_NB], sVi[TB_NB], sWi[TB_NB];
+  __shared__ double sred[48];
+  __shared__ double scal[8];  // 0 beta 1 tau 2 scale 3 pv 4 w_i0
+
+  // ---- (B, early) issue the loads of the trailing-matrix tile: independent of everything else ----
+  constexpr int NU = TF_T / 16;  // columns per wave
+  double r0[NU], r1[NU];
+  const int row = gR0 - (i + 1) + 2 * lane;  // local row (relative to i+1) of this lane's pair
+  if (has_cur) {
+    const double *a = A + (size_t)(i + 1) * n + (i + 1) + row;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      int cc = TF_T * cs + wave * NU + u;  // local column
+      r0[u] = 0.0;
+      r1[u] = 0.0;
+      if (cc < m) {
+        if (vec2 && row >= 0 && row + 1 < m) {
+          double2 t = *reinterpret_cast<const double2 *>(a + (size_t)cc * n);
+          r0[u] = t.x;
+          r1[u] = t.y;
+        } else {
+          if (row >= 0 && row < m) r0[u] = a[(size_t)cc * n];
+          if (row + 1 >= 0 && row + 1 < m) r1[u] = a[(size_t)cc * n + 1];
+        }
+      }
+    }
+  }
+
+  // ---- (A) finish column j = i-1 on the rows this workgroup needs ----
+  // row slot rid < 128: row gR0 + rid of the row slab; rid >= 128: row gC0 + rid - 128 of the column slab
+  const bool isR = rid < TF_T;
+  const int g = isR ? gR0 + rid : gC0 + (rid - TF_T);
+  const bool live = (g >= i + 1) && g < n && (isR || (has_cur && (rs != cs || delta)));
+  double xnew = 0.0, vg = 0.0, wg = 0.0;
+  if (has_prev) {
+    const int mp = m + 1;                         // rows of column j's reflector, g >= i
+    const int pncs = (mp + TF_T - 1) / TF_T;      // column slabs of K_{i-1}
+    const int pnrt = (mp + 1 + TF_T - 1) / TF_T;  // its row slabs
+    const double *ppv = b.fpp[blk] + (size_t)ppar * TF_MAXS * n;
+    const double *pdots = b.fdots[blk] + (size_t)ppar * TF_MAXS * TF_MAXS;
+    const double *pxn2 = b.fxn2[blk] + (size_t)ppar * TF_MAXS;
+    const double *pcp = b.fcp[blk] + (size_t)ppar * TF_MAXS * 2 * TB_NB;
+    const double *px = b.fx[blk] + (size_t)ppar * n;
+    const double *Vb = b.V[blk], *Wb = b.W[blk];
+    // per-row loads (all independent): group grp holds the panel columns cc = grp + 4u
+    double aii = 0.0, alpha = 0.0;
+    if (tid == 0) {
+      aii = A[(size_t)i * n + i];
+      alpha = px[i];
+    }
+    constexpr int HB = TB_NB / 4;
+    double vv[HB], ww[HB];
+    double qraw = 0.0, xg = 0.0, ag = 0.0;
+    if (live && grp == 0) {
+      for (int k = 0; k < pncs; k++) qraw += ppv[(size_t)k * n + g];
+      xg = px[g];
+      ag = A[(size_t)i * n + g];
+    }
+#pragma unroll
+    for (int u = 0; u < HB; u++) {
+      int cc = grp + 4 * u;
+      bool ok = live && cc < cp && !(dbg & 2);
+      vv[u] = ok ? Vb[(size_t)cc * n + g] : 0.0;
+      ww[u] = ok ? Wb[(size_t)cc * n + g] : 0.0;
+    }
+    // scalar stage (every workgroup, redundantly): reductions of the partials of K_{i-1}
+    {
+      double s = 0.0;  // x^T A22 x
+      const int nd = pnrt * pncs;
+      for (int k = tid; k < nd; k += 1024) s += pdots[k];
+      double t2 = (tid < pncs) ? pxn2[tid] : 0.0;                 // |x[1:]|^2
+      double qi = (tid < pncs) ? ppv[(size_t)tid * n + i] : 0.0;  // q_raw at row i
+      for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        t2 += __shfl_down(t2, o, 64);
+        qi += __shfl_down(qi, o, 64);
+      }
+      if (lane == 0) {
+        sred[wave] = s;
+        if (wave == 0) {
+          sred[16] = t2;
+          sred[17] = qi;
+        }
+      }
+      // waves 4..7: V^T x, W^T x of the panel columns cc < cp and the rows i of V and W
+      if (tid >= 256 && tid < 256 + 2 * TB_NB) {
+        int t = tid - 256, cc = t % TB_NB;
+        double a2 = 0.0;
+        if (cc < cp)
+          for (int k = 0; k < pncs; k++) a2 += pcp[(size_t)k * 2 * TB_NB + t];
+        if (t < TB_NB) sVtX[cc] = a2;
+        else sWtX[cc] = a2;
+      } else if (tid >= 512 && tid < 512 + 2 * TB_NB) {
+        int t = tid - 512, cc = t % TB_NB;
+        bool isV = t < TB_NB;
+        double a2 = (cc < cp) ? (isV ? Vb[(size_t)cc * n + i] : Wb[(size_t)cc * n + i]) : 0.0;
+        if (isV) sVi[cc] = a2;
+        else sWi[cc] = a2;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lanes 0..31 hold one panel column each: three small dot products by shuffles, then lane 0 finishes
+      double vi = (lane < TB_NB) ? sVi[lane & (TB_NB - 1)] : 0.0, wi = (lane < TB_NB) ? sWi[lane & (TB_NB - 1)] : 0.0;
+      double vx = (lane < TB_NB) ? sVtX[lane & (TB_NB - 1)] : 0.0, wx = (lane < TB_NB) ? sWtX[lane & (TB_NB - 1)] : 0.0;
+      double dq = vi * wx + wi * vx, dz = 2.0 * vi * wi, dx = 2.0 * vx * wx;
+      for (int o = 32; o > 0; o >>= 1) {
+        dq += __shfl_down(dq, o, 64);
+        dz += __shfl_down(dz, o, 64);
+        dx += __shfl_down(dx, o, 64);
+      }
+      if (lane == 0) {
+        double xAx = 0.0;
+        for (int k = 0; k < 16; k++) xAx += sred[k];
+        double xn2 = sred[16];
+        double qi = sred[17] - dq;
+        double zi = aii - dz, xq = xAx - dx;
+        double tau, beta, scale;
+        if (xn2 == 0.0) {
+          tau = 0.0;
+          beta = alpha;
+          scale = 0.0;
+        } else {
+          double nrm = sqrt(alpha * alpha + xn2);
+          beta = (alpha >= 0.0) ? -nrm : nrm;
+          tau = (beta - alpha) / beta;
+          scale = 1.0 / (alpha - beta);
+        }
+        double pvv = scale * scale * (xq - 2.0 * beta * qi + beta * beta * zi);
+        double pi0 = scale * (qi - beta * zi);
+        double wi0 = tau * pi0 - 0.5 * tau * tau * pvv;  // v_i = 1
+        scal[0] = beta;
+        scal[1] = tau;
+        scal[2] = scale;
+        scal[3] = pvv;
+        scal[4] = wi0;
+        if (blockIdx.x == 0) {
+          b.e[blk][j] = beta;
+          b.tau[blk][j] = tau;
+          b.V[blk][(size_t)cp * n + i] = 1.0;
+          b.W[blk][(size_t)cp * n + i] = wi0;
+          if (has_cur) b.d[blk][i] = zi - 2.0 * wi0;
+        }
+      }
+    }
+    // partial panel corrections of this group
+    {
+      double qc = 0.0, zc = 0.0;
+#pragma unroll
+      for (int u = 0; u < HB; u++) {
+        int cc = grp + 4 * u;  // entries cc >= cp are zero
+        qc += vv[u] * sWtX[cc] + ww[u] * sVtX[cc];
+        zc += vv[u] * sWi[cc] + ww[u] * sVi[cc];
+      }
+      qpart[grp][rid] = qc;
+      zpart[grp][rid] = zc;
+    }
+    __syncthreads();
+    const double beta = scal[0], tau = scal[1], scale = scal[2], pvv = scal[3], wi0 = scal[4];
+    if (grp == 0 && live) {
+      double q = qraw - ((qpart[0][rid] + qpart[1][rid]) + (qpart[2][rid] + qpart[3][rid]));
+      double z = ag - ((zpart[0][rid] + zpart[1][rid]) + (zpart[2][rid] + zpart[3][rid]));
+      vg = xg * scale;
+      double pr = scale * (q - beta * z);
+      wg = tau * pr - 0.5 * tau * tau * pvv * vg;
+      xnew = z - vg * wi0 - wg;
+      // one writer per row: the workgroups of the first column slab
+      if (isR && cs == 0) {
+        b.V[blk][(size_t)cp * n + g] = vg;
+        b.W[blk][(size_t)cp * n + g] = wg;
+        A[(size_t)j * n + g] = vg;  // Householder vector for the back-transformation
+        if (has_cur) b.fx[blk][(size_t)par * n + g] = xnew;
+      }
+    }
+  } else if (has_cur) {
+    // first column of a panel: the trailing matrix is up to date
+    if (grp == 0 && live) {
+      xnew = A[(size_t)i * n + g];
+      if (isR && cs == 0) b.fx[blk][(size_t)par * n + g] = xnew;
+    }
+    if (blockIdx.x == 0 && tid == 0) b.d[blk][i] = A[(size_t)i * n + i];
+  }
+  if (!has_cur) return;
+
+  // x_i on the row slab and the column slab (and v, w of the previous column on the column slab)
+  const bool same = (rs == cs) && !delta;  // the two slabs are the same rows
+  if (grp == 0) {
+    if (isR) {
+      xR[rid] = live ? xnew : 0.0;
+      if (same) {
+        xC[rid] = live ? xnew : 0.0;
+        vC[rid] = live ? vg : 0.0;
+        wC[rid] = live ? wg : 0.0;
+      }
+    } else if (!same) {
+      xC[rid - TF_T] = live ? xnew : 0.0;
+      vC[rid - TF_T] = live ? vg : 0.0;
+      wC[rid - TF_T] = live ? wg : 0.0;
+    }
+  }
+  __syncthreads();
+
+  // ---- (B) sweep: partial q over this tile ----
+  double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    double xc = xC[wave * NU + u];
+    acc0 += r0[u] * xc;
+    acc1 += r1[u] * xc;
+  }
+  red[wave * TF_T + 2 * lane] = acc0;
+  red[wave * TF_T + 2 * lane + 1] = acc1;
+  __syncthreads();
+  double dv = 0.0;
+  if (tid < TF_T) {
+    const int gr = gR0 + tid;
+    const bool okr = (gr >= i + 1 && gr < n);
+    double pq = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) pq += red[w * TF_T + tid];
+    if (okr) b.fpp[blk][((size_t)par * TF_MAXS + cs) * n + gr] = pq;
+    dv = okr ? pq * xR[tid] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) dv += __shfl_down(dv, o, 64);
+    if (lane == 0) sred[32 + wave] = dv;
+  }
+  // ---- per column slab (first row slab only): |x[1:]|^2, V^T x, W^T x over the slab ----
+  if (rs == 0) {
+    if (tid >= TF_T && tid < 2 * TF_T) {
+      int k = tid - TF_T;
+      int h = gC0 + k;
+      double xv = (h >= i + 2 && h < n) ? xC[k] : 0.0;
+      double s2 = xv * xv;
+      for (int o = 32; o > 0; o >>= 1) s2 += __shfl_down(s2, o, 64);
+      if (lane == 0) sred[34 + (wave - 2)] = s2;
+    }
+    // panel columns cc < c (cc = c-1 is the reflector just finished: v, w of the slab are in LDS).  Wave q takes
+    // q2 = q, q+16, ...; all global loads are issued before the first reduction.
+    if (c > 0 && !(dbg & 1)) {
+      double m0[4], m1[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int q2 = wave + 16 * u;
+        m0[u] = 0.0;
+        m1[u] = 0.0;
+        if (q2 < 2 * c) {
+          int cc = (q2 < c) ? q2 : q2 - c;
+          bool isV = q2 < c;
+          if (cc != c - 1) {
+            const double *M = (isV ? b.V[blk] : b.W[blk]) + (size_t)cc * n;
+            int h0 = gC0 + lane, h1 = gC0 + 64 + lane;
+            if (h0 < n) m0[u] = M[h0];
+            if (h1 < n) m1[u] = M[h1];
+          } else {
+            m0[u] = isV ? vC[lane] : wC[lane];
+            m1[u] = isV ? vC[64 + lane] : wC[64 + lane];
+          }
+        }
+      }
+      const double x0 = xC[lane], x1 = xC[64 + lane];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int q2 = wave + 16 * u;
+        if (q2 < 2 * c) {  // wave-uniform
+          double t = m0[u] * x0 + m1[u] * x1;
+          for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+          int cc = (q2 < c) ? q2 : q2 - c;
+          if (lane == 0) b.fcp[blk][((size_t)par * TF_MAXS + cs) * 2 * TB_NB + ((q2 < c) ? cc : TB_NB + cc)] = t;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    b.fdots[blk][(size_t)par * TF_MAXS * TF_MAXS + blockIdx.x] = sred[32] + sred[33];
+    if (rs == 0) b.fxn2[blk][(size_t)par * TF_MAXS + cs] = sred[34] + sred[35];
+  }
+}
+
 // d, e of the last 2x2 block (after the final trailing update)
 __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
   const TrdBatch &b = *bp;
@@ -378,6 +721,8 @@ __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
 
 struct TrdWork {
   DevBuf<double> V[TB_MAXB], W[TB_MAXB], col[TB_MAXB], normp[TB_MAXB], pp[TB_MAXB], dots[TB_MAXB], cpart[TB_MAXB];
+  DevBuf<double> fx[TB_MAXB], fpp[TB_MAXB], fdots[TB_MAXB], fxn2[TB_MAXB], fcp[TB_MAXB];
+  bool last_fused = false;
   DevBuf<TrdBatch> desc;
   std::vector<int> last_ns;  // sizes of the last batch (for the measurement replay)
 };
@@ -427,6 +772,16 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     b.pp[i] = w.pp[i].p;
     b.dots[i] = w.dots[i].p;
     b.cpart[i] = w.cpart[i].p;
+    w.fx[i].resize((size_t)2 * n);
+    w.fpp[i].resize((size_t)2 * TF_MAXS * n);
+    w.fdots[i].resize((size_t)2 * TF_MAXS * TF_MAXS);
+    w.fxn2[i].resize((size_t)2 * TF_MAXS);
+    w.fcp[i].resize((size_t)2 * TF_MAXS * 2 * TB_NB);
+    b.fx[i] = w.fx[i].p;
+    b.fpp[i] = w.fpp[i].p;
+    b.fdots[i] = w.fdots[i].p;
+    b.fxn2[i] = w.fxn2[i].p;
+    b.fcp[i] = w.fcp[i].p;
   }
   hipStream_t s = ctx->stream;
   w.desc.resize(1);
@@ -436,7 +791,20 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
   size_t shb = (size_t)(nmax + 4 * 128 + 8) * sizeof(double);
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_trdb_gemv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+  // HELFEM_TRD=twokernel keeps the earlier two-launches-per-column variant (k_trdb_gemv + k_trdb_w)
+  static const bool twokernel = (getenv("HELFEM_TRD") && !strcmp(getenv("HELFEM_TRD"), "twokernel"));
+  const bool fused = !twokernel && nmax <= TF_T * (TF_MAXS - 1);
+  w.last_fused = fused;
   for (int j0 = 0; j0 <= nmax - 3; j0 += TB_NB) {
+    if (fused) {
+      const int jend = std::min(j0 + TB_NB, nmax - 2);
+      for (int i = j0; i <= jend; i++) {
+        const int sweep = (i < jend) ? 1 : 0;  // the last launch of the panel only finishes column jend-1
+        const int m = nmax - i - 1;
+        const int nrt = (m + 1 + TF_T - 1) / TF_T, ncs = std::max(1, (m + TF_T - 1) / TF_T);
+        hipLaunchKernelGGL(k_trdf, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(1024), 0, s, db, i, i - j0, sweep);
+      }
+    } else {
     {
       int m = nmax - j0 - 1;
       hipLaunchKernelGGL(k_trdb_loadcol, dim3((m + 63) / 64, nblk), dim3(64), 0, s, db, j0);
@@ -450,6 +818,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
       int ncs = std::max(1, std::min(64, (m + 63) / 64));
       hipLaunchKernelGGL(k_trdb_gemv, dim3(nrg * ncs, nblk), dim3(256), shb, s, db, i, c, ncs);
       hipLaunchKernelGGL(k_trdb_w, dim3(nrs, nblk), dim3(256), 0, s, db, i, c, (i + 1 < jend) ? 1 : 0, ncs);
+    }
     }
     // trailing update per block: columns processed in this panel for block k: j0 .. min(j0+NB, n_k-2)-1
     for (int k = 0; k < nblk; k++) {
@@ -492,9 +861,16 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
   for (int i = 0; i <= nmax - 3; i++) {
     const int c = i % TB_NB;
     const int m = nmax - i - 1;
-    const int nrg = (m + 1 + 127) / 128;
-    int ncs = std::max(1, std::min(64, (m + 63) / 64));
-    hipLaunchKernelGGL(k_trdb_gemv, dim3(nrg * ncs, nblk), dim3(256), shb, s, db, i, c, ncs);
+    if (w.last_fused) {
+      const int nrt = (m + 1 + TF_T - 1) / TF_T, ncs = std::max(1, (m + TF_T - 1) / TF_T);
+      const int cfix = getenv("HELFEM_TRDF_C") ? atoi(getenv("HELFEM_TRDF_C")) : c;
+      const int dbg = getenv("HELFEM_TRDF_DBG") ? atoi(getenv("HELFEM_TRDF_DBG")) : 0;
+      hipLaunchKernelGGL(k_trdf, dim3(nrt * ncs, nblk), dim3(1024), 0, s, db, i, cfix, 1 | (dbg << 1));
+    } else {
+      const int nrg = (m + 1 + 127) / 128;
+      int ncs = std::max(1, std::min(64, (m + 63) / 64));
+      hipLaunchKernelGGL(k_trdb_gemv, dim3(nrg * ncs, nblk), dim3(256), shb, s, db, i, c, ncs);
+    }
     count++;
   }
   HFG_HIP_CHECK(hipEventRecord(e1, s));

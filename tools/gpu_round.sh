@@ -16,7 +16,7 @@ echo fetch done
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 echo write done
 cd $REPO
-python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json k_trdb k_coulomb_tei k_backtransform k_dgemm > $OUT/pmc_traffic.txt
+python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json k_trd k_coulomb_tei k_backtransform k_dgemm > $OUT/pmc_traffic.txt
 cat $OUT/pmc_traffic.txt
 # keep only the summaries (the per-dispatch CSVs are large)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
