@@ -106,6 +106,7 @@ struct GemmTask {
   double *C;
   int M, N, K, lda, ldb, ldc;
   int tA = 0, tB = 0;  // op(A), op(B) transposed (k_dgemm_tasklist only)
+  double alpha = 1.0, beta = 0.0;  // C = alpha op(A) op(B) + beta C (k_dgemm_tasklist only)
 };
 
 struct ProfScope {

@@ -21,6 +21,7 @@
 
 namespace hfg {
 
+void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 
@@ -425,6 +426,7 @@ struct EigWork {
   DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
+  DevBuf<GemmTask> gtasks;
   bool used_dc = true;
 };
 static std::map<hfg_ctx *, EigWork *> g_work;
@@ -651,34 +653,63 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
   DevBuf<double> &Fb = ctx->ws[5];
   DevBuf<double> &T1 = ctx->ws[0];
   DevBuf<double> &Xall = ctx->ws[4];
-  Fb.resize(nmax * nmax);
-  T1.resize(nmax * nmax);
+  Fb.resize(nmax * nmax * MAXB);
+  T1.resize(nmax * nmax * MAXB);
   Xall.resize(nmax * nmax * MAXB);
   for (size_t c0 = 0; c0 < mine.size(); c0 += MAXB) {
     int nb = (int)std::min<size_t>(MAXB, mine.size() - c0);
     std::vector<int> ns(nb);
+    // the three products of every block (F X, X^T (F X), X Z) go through one task-list launch each, so that the
+    // blocks fill the chip together with 128 x 128 tiles
+    std::vector<GemmTask> gt(3 * (size_t)nb);
+    int nm = 0;
+    for (int k = 0; k < nb; k++) {
+      int ib = mine[c0 + k];
+      int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
+      ns[k] = n;
+      nm = std::max(nm, n);
+      w.A[k].resize((size_t)n * n);
+      w.Z[k].resize((size_t)n * n);
+      double *Xb = Xall.p + (size_t)k * nmax * nmax, *Fk = Fb.p + (size_t)k * nmax * nmax, *Tk = T1.p + (size_t)k * nmax * nmax;
+      GemmTask g;
+      g.M = g.N = g.K = n;
+      g.lda = g.ldb = g.ldc = n;
+      g.A = Fk;
+      g.B = Xb;
+      g.C = Tk;
+      gt[k] = g;
+      g.A = Xb;
+      g.tA = 1;
+      g.B = Tk;
+      g.C = w.A[k].p;
+      gt[nb + k] = g;
+      g.tA = 0;
+      g.A = Xb;
+      g.B = w.Z[k].p;
+      g.C = dBlockBuf + (size_t)ib * slot;
+      gt[2 * nb + k] = g;
+    }
+    w.gtasks.upload(gt, s);
+    HFG_HIP_CHECK(hipStreamSynchronize(s));  // gt lives on this stack frame
     {
       ProfScope ps(ctx, "eig_reduce");
       for (int k = 0; k < nb; k++) {
         int ib = mine[c0 + k];
-        int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
-        ns[k] = n;
-        w.A[k].resize((size_t)n * n);
-        double *Xb = Xall.p + (size_t)k * nmax * nmax;
+        int n = ns[k];
         hipLaunchKernelGGL(k_gather_block, dim3((n + 255) / 256, n), dim3(256), 0, s, dF, dS, N, drows + blk_ptr[ib],
-                           dcols + coff[ib], n, Fb.p, Xb);
-        gemm_dev(ctx, false, false, n, n, n, 1.0, Fb.p, n, Xb, n, 0.0, T1.p, n);
-        gemm_dev(ctx, true, false, n, n, n, 1.0, Xb, n, T1.p, n, 0.0, w.A[k].p, n);
+                           dcols + coff[ib], n, Fb.p + (size_t)k * nmax * nmax, Xall.p + (size_t)k * nmax * nmax);
       }
+      gemm_tasklist_dev(ctx, w.gtasks.p, nb, nm, nm);
+      gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);
     }
     eig_sym_batch(ctx, w, nb, ns.data());
     {
       ProfScope ps(ctx, "eig_backtransform");
+      gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
       for (int k = 0; k < nb; k++) {
         int ib = mine[c0 + k];
         int n = ns[k];
         double *slotp = dBlockBuf + (size_t)ib * slot;
-        gemm_dev(ctx, false, false, n, n, n, 1.0, Xall.p + (size_t)k * nmax * nmax, n, w.Z[k].p, n, 0.0, slotp, n);
         HFG_HIP_CHECK(hipMemcpyAsync(slotp + nmax * nmax, w.d[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
       }
     }

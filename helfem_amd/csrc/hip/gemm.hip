@@ -176,7 +176,16 @@ __global__ __launch_bounds__(256) void k_dgemm_tasklist(const GemmTask *__restri
   if (t.M <= 0 || t.N <= 0) return;
   const int nt = ((t.M + BM - 1) / BM) * ((t.N + BN - 1) / BN);
   if ((int)blockIdx.x >= nt) return;
-  dgemm_tile<BM, BN>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, 1.0, t.A, t.lda, t.B, t.ldb, 0.0, t.C, t.ldc, As, Bs);
+  dgemm_tile<BM, BN>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As, Bs);
+}
+
+/// launches the task list with 64 x 64 tiles (small products, more workgroups)
+void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
+  if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  const int tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
+  hipLaunchKernelGGL((k_dgemm_tasklist<64, 64>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  HFG_HIP_CHECK(hipGetLastError());
 }
 
 /// launches the task list with 128 x 128 tiles; max_mn = largest (M, N) over the tasks

@@ -16,6 +16,7 @@
 //                                          together with the partial norms its Householder vector needs.
 // No atomics; all reductions have a fixed order, so the factorisation is bitwise reproducible.
 #include "common.h"
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
@@ -23,6 +24,8 @@ namespace hfg {
 
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
+void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 
 constexpr int TB_MAXB = 8;
 constexpr int TB_NB = 32;   // panel width
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
           b.e[blk][j] = beta;
           b.tau[blk][j] = tau;
           b.V[blk][(size_t)cp * n + i] = 1.0;
+          b.V[blk][(size_t)(2 * TB_NB + cp) * n + i] = 1.0;
           b.W[blk][(size_t)cp * n + i] = wi0;
           if (has_cur) b.d[blk][i] = zi - 2.0 * wi0;
         }
@@ -593,6 +597,7 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       // one writer per row: the workgroups of the first column slab
       if (isR && cs == 0) {
         b.V[blk][(size_t)cp * n + g] = vg;
+        b.V[blk][(size_t)(2 * TB_NB + cp) * n + g] = vg;  // [V | W | V]: the rank-2NB update is one product
         b.W[blk][(size_t)cp * n + g] = wg;
         A[(size_t)j * n + g] = vg;  // Householder vector for the back-transformation
         if (has_cur) b.fx[blk][(size_t)par * n + g] = xnew;
@@ -720,8 +725,9 @@ __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
 }
 
 struct TrdWork {
-  DevBuf<double> V[TB_MAXB], W[TB_MAXB], col[TB_MAXB], normp[TB_MAXB], pp[TB_MAXB], dots[TB_MAXB], cpart[TB_MAXB];
+  DevBuf<double> V[TB_MAXB], col[TB_MAXB], normp[TB_MAXB], pp[TB_MAXB], dots[TB_MAXB], cpart[TB_MAXB];
   DevBuf<double> fx[TB_MAXB], fpp[TB_MAXB], fdots[TB_MAXB], fxn2[TB_MAXB], fcp[TB_MAXB];
+  DevBuf<GemmTask> ptasks;  // panel updates of the fused variant, [panel][block]
   bool last_fused = false;
   DevBuf<TrdBatch> desc;
   std::vector<int> last_ns;  // sizes of the last batch (for the measurement replay)
@@ -753,8 +759,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     int n = ns[i];
     nmax = std::max(nmax, n);
     int nslab = (n + 63) / 64 + 1;
-    w.V[i].resize((size_t)n * TB_NB);
-    w.W[i].resize((size_t)n * TB_NB);
+    w.V[i].resize((size_t)n * 3 * TB_NB);  // [V | W | V]
     w.col[i].resize(n);
     w.normp[i].resize(nslab);
     w.pp[i].resize((size_t)64 * n);
@@ -766,7 +771,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     b.e[i] = e[i];
     b.tau[i] = tau[i];
     b.V[i] = w.V[i].p;
-    b.W[i] = w.W[i].p;
+    b.W[i] = w.V[i].p + (size_t)n * TB_NB;
     b.col[i] = w.col[i].p;
     b.normp[i] = w.normp[i].p;
     b.pp[i] = w.pp[i].p;
@@ -795,6 +800,36 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
   static const bool twokernel = (getenv("HELFEM_TRD") && !strcmp(getenv("HELFEM_TRD"), "twokernel"));
   const bool fused = !twokernel && nmax <= TF_T * (TF_MAXS - 1);
   w.last_fused = fused;
+  // fused variant: the trailing updates A22 -= [V|W][W|V]^T of all blocks of a full panel are one task-list launch
+  const int npanel = (nmax - 3) / TB_NB + 1;
+  if (fused) {
+    std::vector<GemmTask> pt((size_t)npanel * nblk);
+    for (int pi = 0; pi < npanel; pi++)
+      for (int k = 0; k < nblk; k++) {
+        GemmTask g;
+        g.A = g.B = nullptr;
+        g.C = nullptr;
+        g.M = g.N = g.K = 0;
+        g.lda = g.ldb = g.ldc = 1;
+        const int n = ns[k], j0 = pi * TB_NB;
+        const int ncols = std::min(TB_NB, std::max(0, n - 2 - j0));
+        const int j1 = j0 + ncols, mt = n - j1;
+        if (ncols == TB_NB && mt > 0) {
+          g.A = w.V[k].p + j1;                          // [V | W], rows j1..
+          g.B = w.V[k].p + (size_t)n * TB_NB + j1;      // [W | V]
+          g.C = A[k] + (size_t)j1 * n + j1;
+          g.M = g.N = mt;
+          g.K = 2 * TB_NB;
+          g.lda = g.ldb = g.ldc = n;
+          g.tB = 1;
+          g.alpha = -1.0;
+          g.beta = 1.0;
+        }
+        pt[(size_t)pi * nblk + k] = g;
+      }
+    w.ptasks.upload(pt, s);
+    HFG_HIP_CHECK(hipStreamSynchronize(s));  // pt lives on this stack frame
+  }
   for (int j0 = 0; j0 <= nmax - 3; j0 += TB_NB) {
     if (fused) {
       const int jend = std::min(j0 + TB_NB, nmax - 2);
@@ -821,16 +856,25 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     }
     }
     // trailing update per block: columns processed in this panel for block k: j0 .. min(j0+NB, n_k-2)-1
+    if (fused) {
+      const int mt = nmax - j0 - TB_NB;
+      if (mt > 0) {
+        const GemmTask *pt = w.ptasks.p + (size_t)(j0 / TB_NB) * nblk;
+        if ((long)((mt + 127) / 128) * ((mt + 127) / 128) * nblk >= 200) gemm_tasklist_dev(ctx, pt, nblk, mt, mt);
+        else gemm_tasklist64_dev(ctx, pt, nblk, mt, mt);
+      }
+    }
     for (int k = 0; k < nblk; k++) {
       int n = ns[k];
       int ncols = std::min(TB_NB, std::max(0, n - 2 - j0));
       if (ncols <= 0) continue;
+      if (fused && ncols == TB_NB) continue;  // done above
       int j1 = j0 + ncols;
       int mt = n - j1;
       if (mt <= 0) continue;
       double *A22 = A[k] + (size_t)j1 * n + j1;
-      gemm_dev(ctx, false, true, mt, mt, ncols, -1.0, w.V[k].p + j1, n, w.W[k].p + j1, n, 1.0, A22, n);
-      gemm_dev(ctx, false, true, mt, mt, ncols, -1.0, w.W[k].p + j1, n, w.V[k].p + j1, n, 1.0, A22, n);
+      gemm_dev(ctx, false, true, mt, mt, ncols, -1.0, w.V[k].p + j1, n, w.V[k].p + (size_t)n * TB_NB + j1, n, 1.0, A22, n);
+      gemm_dev(ctx, false, true, mt, mt, ncols, -1.0, w.V[k].p + (size_t)n * TB_NB + j1, n, w.V[k].p + j1, n, 1.0, A22, n);
     }
   }
   hipLaunchKernelGGL(k_trdb_finish, dim3(nblk), dim3(64), 0, s, db);
