@@ -167,7 +167,7 @@ def main():
         try:
             if args.workload == "n2_pbe_nbf4230" and world == 1:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    traffic = json.load(fh)["hfg::" + TRD_KERNEL]["traffic_bytes_per_launch"]
+                    traffic = json.load(fh).get("hfg::" + TRD_KERNEL, {}).get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
         out = {

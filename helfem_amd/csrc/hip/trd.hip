@@ -16,6 +16,7 @@
 //                                          together with the partial norms its Householder vector needs.
 // No atomics; all reductions have a fixed order, so the factorisation is bitwise reproducible.
 #include "common.h"
+#include <cstdio>
 #include <vector>
 #include <cstdlib>
 #include <cstring>
@@ -386,24 +387,48 @@ __global__ __launch_bounds__(256) void k_trdb_w(const TrdBatch *__restrict__ bp,
 // x_i there, and (B) sweeps its 128 x 128 tile of the trailing matrix with x_i, leaving partial q, x^T q, |x|^2,
 // V^T x, W^T x for K_{i+1}.  No norm, no second launch, no atomics; fixed summation orders.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, int i, int c, int sweep) {
-  // 1024 threads: the panel corrections of a row are split over four thread groups (cc = grp, grp+4, ...), the
-  // 128 columns of the tile over sixteen waves -- every serial loop of the column step is a quarter as long.
+// Pointers read from the descriptor are generic to the compiler (flat_load, counted on vmcnt AND lgkmcnt); every
+// buffer here is global memory, so the kernel casts them to the global address space once (global_load).
+typedef __attribute__((address_space(1))) double gdouble;
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) d2_t gdouble2;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define HFG_G(p) ((gdouble *)(p))
+#define HFG_GC(p) ((const gdouble *)(p))
+
+constexpr int TF_NTH = 1024;            // threads per workgroup
+constexpr int TF_NG = TF_NTH / 256;     // thread groups sharing a row's panel corrections
+constexpr int TF_NW = TF_NTH / 64;      // waves
+__global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp, int i, int c, int sweep) {
+  // 512 threads: the panel corrections of a row are split over two thread groups (cc = grp, grp+2, ...), the 128
+  // columns of the tile over eight waves.  Load order matters more than thread count here: a workgroup pulls its
+  // 128 KB tile through one CU in 2-3 us, so the small phase-A loads are issued first and the tile streams in
+  // behind them while the reductions and the scalar algebra run.
   const TrdBatch &b = *bp;
   const int blk = blockIdx.y;
+  const unsigned long long tk0 = wall_clock64();
   const int n = b.n[blk];
   const int j = i - 1;
   const bool has_prev = (c > 0) && (j >= 0) && (j <= n - 3);
   const bool has_cur = (sweep & 1) && (i <= n - 3);
   const int dbg = sweep >> 1;  // measurement-only switches of the replay (0 in the factorisation)
+  // dbg & 4: workgroup 0 of block 0 records wall-clock stamps (100 MHz) of its phases into fdots' spare tail
+#define TRDF_STAMP(k)                                                                                        \
+  if ((dbg & 4) && blockIdx.x == 0 && blk == 0 && threadIdx.x == 0)                                          \
+    ((gu64 *)(b.fcp[blk] + (size_t)2 * TF_MAXS * 2 * TB_NB))[(size_t)i * 8 + (k)] = wall_clock64() - tk0;
   if (!has_prev && !has_cur) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int grp = tid >> 8, rid = tid & 255;  // thread group, row slot
   const int m = n - i - 1;                    // rows below the diagonal of column i
-  double *A = b.A[blk];
+  gdouble *A = HFG_G(b.A[blk]);
+  gdouble *Vw = HFG_G(b.V[blk]), *Ww = HFG_G(b.W[blk]);
+  gdouble *fxw = HFG_G(b.fx[blk]), *fppw = HFG_G(b.fpp[blk]), *fdotsw = HFG_G(b.fdots[blk]), *fxn2w = HFG_G(b.fxn2[blk]),
+          *fcpw = HFG_G(b.fcp[blk]);
+  gdouble *dw = HFG_G(b.d[blk]), *ew = HFG_G(b.e[blk]), *tauw = HFG_G(b.tau[blk]);
   const int par = i & 1, ppar = par ^ 1;
   const int cp = c - 1;  // panel column of the previous reflector; panel columns cc < cp precede it
 
+  TRDF_STAMP(0)
   // ---- tile of this workgroup ----
   const bool vec2 = ((n & 1) == 0);
   const int delta = (has_cur && vec2) ? ((i + 1) & 1) : 0;  // shift that makes every row pair a 16-byte aligned double2
@@ -425,18 +450,20 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
   const int gC0 = i + 1 + TF_T * cs;                                        // first row/col of the column slab
 
   __shared__ double xR[TF_T], xC[TF_T], vC[TF_T], wC[TF_T];
-  __shared__ double red[16 * TF_T];
-  __shared__ double qpart[4][2 * TF_T], zpart[4][2 * TF_T];
+  __shared__ double red[TF_NW * TF_T];
+  __shared__ double qpart[TF_NG][2 * TF_T], zpart[TF_NG][2 * TF_T];
   __shared__ double sVtX[TB_NB], sWtX[TB_NB], sVi[TB_NB], sWi[TB_NB];
-  __shared__ double sred[48];
+  __shared__ double sred[64];
   __shared__ double scal[8];  // 0 beta 1 tau 2 scale 3 pv 4 w_i0
 
-  // ---- (B, early) issue the loads of the trailing-matrix tile: independent of everything else ----
-  constexpr int NU = TF_T / 16;  // columns per wave
+  constexpr int NU = TF_T / TF_NW;  // columns per wave
   double r0[NU], r1[NU];
   const int row = gR0 - (i + 1) + 2 * lane;  // local row (relative to i+1) of this lane's pair
-  if (has_cur) {
-    const double *a = A + (size_t)(i + 1) * n + (i + 1) + row;
+  // (B, early) the loads of the trailing-matrix tile are independent of everything else; they are issued right
+  // BEHIND the small phase-A loads so that those return first (vmcnt is in order)
+  auto issue_tile = [&]() {
+    if (!has_cur) return;
+    const gdouble *a = A + (size_t)(i + 1) * n + (i + 1) + row;
 #pragma unroll
     for (int u = 0; u < NU; u++) {
       int cc = TF_T * cs + wave * NU + u;  // local column
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       r1[u] = 0.0;
       if (cc < m) {
         if (vec2 && row >= 0 && row + 1 < m) {
-          double2 t = *reinterpret_cast<const double2 *>(a + (size_t)cc * n);
+          d2_t t = *(const gdouble2 *)(a + (size_t)cc * n);
           r0[u] = t.x;
           r1[u] = t.y;
         } else {
@@ -453,7 +480,7 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
         }
       }
     }
-  }
+  };
 
   // ---- (A) finish column j = i-1 on the rows this workgroup needs ----
   // row slot rid < 128: row gR0 + rid of the row slab; rid >= 128: row gC0 + rid - 128 of the column slab
@@ -465,19 +492,19 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
     const int mp = m + 1;                         // rows of column j's reflector, g >= i
     const int pncs = (mp + TF_T - 1) / TF_T;      // column slabs of K_{i-1}
     const int pnrt = (mp + 1 + TF_T - 1) / TF_T;  // its row slabs
-    const double *ppv = b.fpp[blk] + (size_t)ppar * TF_MAXS * n;
-    const double *pdots = b.fdots[blk] + (size_t)ppar * TF_MAXS * TF_MAXS;
-    const double *pxn2 = b.fxn2[blk] + (size_t)ppar * TF_MAXS;
-    const double *pcp = b.fcp[blk] + (size_t)ppar * TF_MAXS * 2 * TB_NB;
-    const double *px = b.fx[blk] + (size_t)ppar * n;
-    const double *Vb = b.V[blk], *Wb = b.W[blk];
+    const gdouble *ppv = fppw + (size_t)ppar * TF_MAXS * n;
+    const gdouble *pdots = fdotsw + (size_t)ppar * TF_MAXS * TF_MAXS;
+    const gdouble *pxn2 = fxn2w + (size_t)ppar * TF_MAXS;
+    const gdouble *pcp = fcpw + (size_t)ppar * TF_MAXS * 2 * TB_NB;
+    const gdouble *px = fxw + (size_t)ppar * n;
+    const gdouble *Vb = Vw, *Wb = Ww;
     // per-row loads (all independent): group grp holds the panel columns cc = grp + 4u
     double aii = 0.0, alpha = 0.0;
     if (tid == 0) {
       aii = A[(size_t)i * n + i];
       alpha = px[i];
     }
-    constexpr int HB = TB_NB / 4;
+    constexpr int HB = TB_NB / TF_NG;
     double vv[HB], ww[HB];
     double qraw = 0.0, xg = 0.0, ag = 0.0;
     if (live && grp == 0) {
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
     }
 #pragma unroll
     for (int u = 0; u < HB; u++) {
-      int cc = grp + 4 * u;
+      int cc = grp + TF_NG * u;
       bool ok = live && cc < cp && !(dbg & 2);
       vv[u] = ok ? Vb[(size_t)cc * n + g] : 0.0;
       ww[u] = ok ? Wb[(size_t)cc * n + g] : 0.0;
@@ -496,9 +523,19 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
     {
       double s = 0.0;  // x^T A22 x
       const int nd = pnrt * pncs;
-      for (int k = tid; k < nd; k += 1024) s += pdots[k];
+      for (int k = tid; k < nd; k += TF_NTH) s += pdots[k];
       double t2 = (tid < pncs) ? pxn2[tid] : 0.0;                 // |x[1:]|^2
       double qi = (tid < pncs) ? ppv[(size_t)tid * n + i] : 0.0;  // q_raw at row i
+      double cpl = 0.0;  // this thread's share of the V^T x, W^T x partials / rows i of V, W (loads issued here)
+      if (tid >= 256 && tid < 256 + 2 * TB_NB) {
+        int t = tid - 256, cc = t % TB_NB;
+        if (cc < cp)
+          for (int k2 = 0; k2 < pncs; k2++) cpl += pcp[(size_t)k2 * 2 * TB_NB + t];
+      } else if (tid >= 384 && tid < 384 + 2 * TB_NB) {
+        int t = tid - 384, cc = t % TB_NB;
+        if (cc < cp) cpl = (t < TB_NB) ? Vb[(size_t)cc * n + i] : Wb[(size_t)cc * n + i];
+      }
+      issue_tile();
       for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_down(s, o, 64);
         t2 += __shfl_down(t2, o, 64);
@@ -507,27 +544,23 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       if (lane == 0) {
         sred[wave] = s;
         if (wave == 0) {
-          sred[16] = t2;
-          sred[17] = qi;
+          sred[40] = t2;
+          sred[41] = qi;
         }
       }
       // waves 4..7: V^T x, W^T x of the panel columns cc < cp and the rows i of V and W
       if (tid >= 256 && tid < 256 + 2 * TB_NB) {
         int t = tid - 256, cc = t % TB_NB;
-        double a2 = 0.0;
-        if (cc < cp)
-          for (int k = 0; k < pncs; k++) a2 += pcp[(size_t)k * 2 * TB_NB + t];
-        if (t < TB_NB) sVtX[cc] = a2;
-        else sWtX[cc] = a2;
-      } else if (tid >= 512 && tid < 512 + 2 * TB_NB) {
-        int t = tid - 512, cc = t % TB_NB;
-        bool isV = t < TB_NB;
-        double a2 = (cc < cp) ? (isV ? Vb[(size_t)cc * n + i] : Wb[(size_t)cc * n + i]) : 0.0;
-        if (isV) sVi[cc] = a2;
-        else sWi[cc] = a2;
+        if (t < TB_NB) sVtX[cc] = cpl;
+        else sWtX[cc] = cpl;
+      } else if (tid >= 384 && tid < 384 + 2 * TB_NB) {
+        int t = tid - 384, cc = t % TB_NB;
+        if (t < TB_NB) sVi[cc] = cpl;
+        else sWi[cc] = cpl;
       }
     }
     __syncthreads();
+    TRDF_STAMP(1)
     if (wave == 0) {
       // lanes 0..31 hold one panel column each: three small dot products by shuffles, then lane 0 finishes
       double vi = (lane < TB_NB) ? sVi[lane & (TB_NB - 1)] : 0.0, wi = (lane < TB_NB) ? sWi[lane & (TB_NB - 1)] : 0.0;
@@ -540,9 +573,9 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       }
       if (lane == 0) {
         double xAx = 0.0;
-        for (int k = 0; k < 16; k++) xAx += sred[k];
-        double xn2 = sred[16];
-        double qi = sred[17] - dq;
+        for (int k = 0; k < TF_NW; k++) xAx += sred[k];
+        double xn2 = sred[40];
+        double qi = sred[41] - dq;
         double zi = aii - dz, xq = xAx - dx;
         double tau, beta, scale;
         if (xn2 == 0.0) {
@@ -552,8 +585,8 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
         } else {
           double nrm = sqrt(alpha * alpha + xn2);
           beta = (alpha >= 0.0) ? -nrm : nrm;
-          tau = (beta - alpha) / beta;
           scale = 1.0 / (alpha - beta);
+          tau = (beta - alpha) * (1.0 / beta);
         }
         double pvv = scale * scale * (xq - 2.0 * beta * qi + beta * beta * zi);
         double pi0 = scale * (qi - beta * zi);
@@ -564,12 +597,12 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
         scal[3] = pvv;
         scal[4] = wi0;
         if (blockIdx.x == 0) {
-          b.e[blk][j] = beta;
-          b.tau[blk][j] = tau;
-          b.V[blk][(size_t)cp * n + i] = 1.0;
-          b.V[blk][(size_t)(2 * TB_NB + cp) * n + i] = 1.0;
-          b.W[blk][(size_t)cp * n + i] = wi0;
-          if (has_cur) b.d[blk][i] = zi - 2.0 * wi0;
+          ew[j] = beta;
+          tauw[j] = tau;
+          Vw[(size_t)cp * n + i] = 1.0;
+          Vw[(size_t)(2 * TB_NB + cp) * n + i] = 1.0;
+          Ww[(size_t)cp * n + i] = wi0;
+          if (has_cur) dw[i] = zi - 2.0 * wi0;
         }
       }
     }
@@ -578,7 +611,7 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       double qc = 0.0, zc = 0.0;
 #pragma unroll
       for (int u = 0; u < HB; u++) {
-        int cc = grp + 4 * u;  // entries cc >= cp are zero
+        int cc = grp + TF_NG * u;  // entries cc >= cp are zero
         qc += vv[u] * sWtX[cc] + ww[u] * sVtX[cc];
         zc += vv[u] * sWi[cc] + ww[u] * sVi[cc];
       }
@@ -586,30 +619,39 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       zpart[grp][rid] = zc;
     }
     __syncthreads();
+    TRDF_STAMP(2)
     const double beta = scal[0], tau = scal[1], scale = scal[2], pvv = scal[3], wi0 = scal[4];
     if (grp == 0 && live) {
-      double q = qraw - ((qpart[0][rid] + qpart[1][rid]) + (qpart[2][rid] + qpart[3][rid]));
-      double z = ag - ((zpart[0][rid] + zpart[1][rid]) + (zpart[2][rid] + zpart[3][rid]));
+      double qs = 0.0, zs = 0.0;
+#pragma unroll
+      for (int gg = 0; gg < TF_NG; gg++) {
+        qs += qpart[gg][rid];
+        zs += zpart[gg][rid];
+      }
+      double q = qraw - qs, z = ag - zs;
       vg = xg * scale;
       double pr = scale * (q - beta * z);
       wg = tau * pr - 0.5 * tau * tau * pvv * vg;
       xnew = z - vg * wi0 - wg;
       // one writer per row: the workgroups of the first column slab
       if (isR && cs == 0) {
-        b.V[blk][(size_t)cp * n + g] = vg;
-        b.V[blk][(size_t)(2 * TB_NB + cp) * n + g] = vg;  // [V | W | V]: the rank-2NB update is one product
-        b.W[blk][(size_t)cp * n + g] = wg;
+        Vw[(size_t)cp * n + g] = vg;
+        Vw[(size_t)(2 * TB_NB + cp) * n + g] = vg;  // [V | W | V]: the rank-2NB update is one product
+        Ww[(size_t)cp * n + g] = wg;
         A[(size_t)j * n + g] = vg;  // Householder vector for the back-transformation
-        if (has_cur) b.fx[blk][(size_t)par * n + g] = xnew;
+        if (has_cur) fxw[(size_t)par * n + g] = xnew;
       }
     }
   } else if (has_cur) {
     // first column of a panel: the trailing matrix is up to date
+    double xl = 0.0;
+    if (grp == 0 && live) xl = A[(size_t)i * n + g];
+    issue_tile();
     if (grp == 0 && live) {
-      xnew = A[(size_t)i * n + g];
-      if (isR && cs == 0) b.fx[blk][(size_t)par * n + g] = xnew;
+      xnew = xl;
+      if (isR && cs == 0) fxw[(size_t)par * n + g] = xnew;
     }
-    if (blockIdx.x == 0 && tid == 0) b.d[blk][i] = A[(size_t)i * n + i];
+    if (blockIdx.x == 0 && tid == 0) dw[i] = A[(size_t)i * n + i];
   }
   if (!has_cur) return;
 
@@ -630,6 +672,7 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
     }
   }
   __syncthreads();
+  TRDF_STAMP(3)
 
   // ---- (B) sweep: partial q over this tile ----
   double acc0 = 0.0, acc1 = 0.0;
@@ -642,17 +685,18 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
   red[wave * TF_T + 2 * lane] = acc0;
   red[wave * TF_T + 2 * lane + 1] = acc1;
   __syncthreads();
+  TRDF_STAMP(4)
   double dv = 0.0;
   if (tid < TF_T) {
     const int gr = gR0 + tid;
     const bool okr = (gr >= i + 1 && gr < n);
     double pq = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) pq += red[w * TF_T + tid];
-    if (okr) b.fpp[blk][((size_t)par * TF_MAXS + cs) * n + gr] = pq;
+    for (int w = 0; w < TF_NW; w++) pq += red[w * TF_T + tid];
+    if (okr) fppw[((size_t)par * TF_MAXS + cs) * n + gr] = pq;
     dv = okr ? pq * xR[tid] : 0.0;
     for (int o = 32; o > 0; o >>= 1) dv += __shfl_down(dv, o, 64);
-    if (lane == 0) sred[32 + wave] = dv;
+    if (lane == 0) sred[48 + wave] = dv;
   }
   // ---- per column slab (first row slab only): |x[1:]|^2, V^T x, W^T x over the slab ----
   if (rs == 0) {
@@ -662,22 +706,23 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       double xv = (h >= i + 2 && h < n) ? xC[k] : 0.0;
       double s2 = xv * xv;
       for (int o = 32; o > 0; o >>= 1) s2 += __shfl_down(s2, o, 64);
-      if (lane == 0) sred[34 + (wave - 2)] = s2;
+      if (lane == 0) sred[50 + (wave - 2)] = s2;
     }
     // panel columns cc < c (cc = c-1 is the reflector just finished: v, w of the slab are in LDS).  Wave q takes
-    // q2 = q, q+16, ...; all global loads are issued before the first reduction.
+    // q2 = q, q+8, ...; all global loads are issued before the first reduction.
     if (c > 0 && !(dbg & 1)) {
-      double m0[4], m1[4];
+      constexpr int NQ = 2 * TB_NB / TF_NW;
+      double m0[NQ], m1[NQ];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        int q2 = wave + 16 * u;
+      for (int u = 0; u < NQ; u++) {
+        int q2 = wave + TF_NW * u;
         m0[u] = 0.0;
         m1[u] = 0.0;
         if (q2 < 2 * c) {
           int cc = (q2 < c) ? q2 : q2 - c;
           bool isV = q2 < c;
           if (cc != c - 1) {
-            const double *M = (isV ? b.V[blk] : b.W[blk]) + (size_t)cc * n;
+            const gdouble *M = (isV ? Vw : Ww) + (size_t)cc * n;
             int h0 = gC0 + lane, h1 = gC0 + 64 + lane;
             if (h0 < n) m0[u] = M[h0];
             if (h1 < n) m1[u] = M[h1];
@@ -689,22 +734,24 @@ __global__ __launch_bounds__(1024) void k_trdf(const TrdBatch *__restrict__ bp, 
       }
       const double x0 = xC[lane], x1 = xC[64 + lane];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        int q2 = wave + 16 * u;
+      for (int u = 0; u < NQ; u++) {
+        int q2 = wave + TF_NW * u;
         if (q2 < 2 * c) {  // wave-uniform
           double t = m0[u] * x0 + m1[u] * x1;
           for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
           int cc = (q2 < c) ? q2 : q2 - c;
-          if (lane == 0) b.fcp[blk][((size_t)par * TF_MAXS + cs) * 2 * TB_NB + ((q2 < c) ? cc : TB_NB + cc)] = t;
+          if (lane == 0) fcpw[((size_t)par * TF_MAXS + cs) * 2 * TB_NB + ((q2 < c) ? cc : TB_NB + cc)] = t;
         }
       }
     }
   }
   __syncthreads();
+  TRDF_STAMP(5)
   if (tid == 0) {
-    b.fdots[blk][(size_t)par * TF_MAXS * TF_MAXS + blockIdx.x] = sred[32] + sred[33];
-    if (rs == 0) b.fxn2[blk][(size_t)par * TF_MAXS + cs] = sred[34] + sred[35];
+    fdotsw[(size_t)par * TF_MAXS * TF_MAXS + blockIdx.x] = sred[48] + sred[49];
+    if (rs == 0) fxn2w[(size_t)par * TF_MAXS + cs] = sred[50] + sred[51];
   }
+#undef TRDF_STAMP
 }
 
 // d, e of the last 2x2 block (after the final trailing update)
@@ -781,7 +828,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     w.fpp[i].resize((size_t)2 * TF_MAXS * n);
     w.fdots[i].resize((size_t)2 * TF_MAXS * TF_MAXS);
     w.fxn2[i].resize((size_t)2 * TF_MAXS);
-    w.fcp[i].resize((size_t)2 * TF_MAXS * 2 * TB_NB);
+    w.fcp[i].resize((size_t)2 * TF_MAXS * 2 * TB_NB + (size_t)8 * n + 64);  // + phase stamps of the measurement replay
     b.fx[i] = w.fx[i].p;
     b.fpp[i] = w.fpp[i].p;
     b.fdots[i] = w.fdots[i].p;
@@ -837,7 +884,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
         const int sweep = (i < jend) ? 1 : 0;  // the last launch of the panel only finishes column jend-1
         const int m = nmax - i - 1;
         const int nrt = (m + 1 + TF_T - 1) / TF_T, ncs = std::max(1, (m + TF_T - 1) / TF_T);
-        hipLaunchKernelGGL(k_trdf, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(1024), 0, s, db, i, i - j0, sweep);
+        hipLaunchKernelGGL(k_trdf, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(TF_NTH), 0, s, db, i, i - j0, sweep);
       }
     } else {
     {
@@ -909,7 +956,7 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
       const int nrt = (m + 1 + TF_T - 1) / TF_T, ncs = std::max(1, (m + TF_T - 1) / TF_T);
       const int cfix = getenv("HELFEM_TRDF_C") ? atoi(getenv("HELFEM_TRDF_C")) : c;
       const int dbg = getenv("HELFEM_TRDF_DBG") ? atoi(getenv("HELFEM_TRDF_DBG")) : 0;
-      hipLaunchKernelGGL(k_trdf, dim3(nrt * ncs, nblk), dim3(1024), 0, s, db, i, cfix, 1 | (dbg << 1));
+      hipLaunchKernelGGL(k_trdf, dim3(nrt * ncs, nblk), dim3(TF_NTH), 0, s, db, i, cfix, 1 | (dbg << 1));
     } else {
       const int nrg = (m + 1 + 127) / 128;
       int ncs = std::max(1, std::min(64, (m + 63) / 64));
@@ -925,6 +972,20 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
   (void)hipEventDestroy(e1);
   *ms = t;
   *launches = count;
+  if (w.last_fused && getenv("HELFEM_TRDF_DBG") && (atoi(getenv("HELFEM_TRDF_DBG")) & 4)) {
+    const int n0 = w.last_ns[0];
+    std::vector<unsigned long long> st((size_t)8 * n0);
+    HFG_HIP_CHECK(hipMemcpy(st.data(), w.fcp[0].p + (size_t)2 * TF_MAXS * 2 * TB_NB, st.size() * 8, hipMemcpyDeviceToHost));
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int i = 40; i < n0 - 40; i++) {
+      if (i % TB_NB == 0) continue;
+      for (int k = 0; k < 6; k++) acc[k] += (double)st[(size_t)i * 8 + k];
+      cnt++;
+    }
+    fprintf(stderr, "k_trdf phase stamps (us since kernel entry, mean over %d columns): desc %.2f | loads+barrier1 %.2f | scalars+barrier2 %.2f | rows+barrier3 %.2f | tile+barrier4 %.2f | end %.2f\n",
+            cnt, acc[0] / cnt / 100.0, acc[1] / cnt / 100.0, acc[2] / cnt / 100.0, acc[3] / cnt / 100.0, acc[4] / cnt / 100.0, acc[5] / cnt / 100.0);
+  }
 }
 
 }  // namespace hfg
