@@ -22,6 +22,7 @@
 namespace hfg {
 
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 
@@ -422,11 +423,75 @@ __global__ void k_scatter_cols(const double *__restrict__ Cb, int nrow, int ncol
 // -------------------------------------------------------------------------------------------------
 // host-side drivers
 // -------------------------------------------------------------------------------------------------
+// ---- 5b. back-transformation through compact-WY blocks on the matrix cores --------------------------------------
+// Q = H_0 ... H_{n-3} = Q_0 ... Q_{P-1},  Q_p = I - V_p T_p V_p^T over BT_KB consecutive reflectors (dlarft,
+// forward / columnwise), applied from the last block to the first:  Z <- Z - (V_p T_p)(V_p^T Z).
+constexpr int BT_KB = 64;
+
+// explicit reflector matrix: Vx[g, j] = 1 at g = j+1, A[g, j] below, 0 above; columns j > n-3 are zero
+__global__ void k_bt_extract(EigBatch b, double *const *__restrict__ Vx) {
+  const int blk = blockIdx.z;
+  const int n = b.n[blk];
+  const int j = blockIdx.y;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || g >= n) return;
+  double v = 0.0;
+  if (j <= n - 3) {
+    if (g == j + 1) v = 1.0;
+    else if (g > j + 1) v = b.A[blk][(size_t)j * n + g];
+  }
+  Vx[blk][(size_t)j * n + g] = v;
+}
+
+// W = sum of the split-K partial products (S slabs of ldw x n each, only the first kb rows are used)
+__global__ void k_bt_wsum(EigBatch b, double *const *__restrict__ Wpart, double *const *__restrict__ W, int S) {
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  const size_t tot = (size_t)BT_KB * n;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+    double a = 0.0;
+    for (int k = 0; k < S; k++) a += Wpart[blk][(size_t)k * tot + t];
+    W[blk][t] = a;
+  }
+}
+
+// T_p from the Gram matrix G_p = V_p^T V_p and tau (one workgroup per block p of one matrix):
+//   T(i,i) = tau_i,   T(0:i, i) = -tau_i T(0:i,0:i) G(0:i, i)
+__global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restrict__ G, double *const *__restrict__ T) {
+  __shared__ double sT[BT_KB][BT_KB + 1];
+  __shared__ double sg[BT_KB];
+  const int blk = blockIdx.y, p = blockIdx.x;
+  const int n = b.n[blk];
+  const int j0 = p * BT_KB;
+  if (j0 > n - 3) return;
+  const int kb = min(BT_KB, n - 2 - j0);
+  const double *Gp = G[blk] + (size_t)p * BT_KB * BT_KB;
+  double *Tp = T[blk] + (size_t)p * BT_KB * BT_KB;
+  const int t = threadIdx.x;
+  for (int c = 0; c < BT_KB; c++) sT[t][c] = 0.0;
+  __syncthreads();
+  for (int i = 0; i < kb; i++) {
+    const double ti = b.tau[blk][j0 + i];
+    sg[t] = (t < i) ? Gp[(size_t)i * BT_KB + t] : 0.0;
+    __syncthreads();
+    if (t < i) {
+      double acc = 0.0;
+      for (int k = t; k < i; k++) acc += sT[t][k] * sg[k];  // row t of the triangle times G(0:i, i)
+      sT[t][i] = -ti * acc;
+    }
+    if (t == i) sT[i][i] = ti;
+    __syncthreads();
+  }
+  for (int c = 0; c < BT_KB; c++) Tp[(size_t)c * BT_KB + t] = sT[t][c];
+}
+
 struct EigWork {
   DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
-  DevBuf<GemmTask> gtasks;
+  DevBuf<GemmTask> gtasks, bttasks, btslab;
+  DevBuf<double> Vx[MAXB], G[MAXB], T[MAXB], VT[MAXB], Wb[MAXB], Wp[MAXB];
+  DevBuf<double *> btptr;
   bool used_dc = true;
 };
 static std::map<hfg_ctx *, EigWork *> g_work;
@@ -447,6 +512,124 @@ void eig_release(hfg_ctx *ctx) {
 
 /// Eigen-decomposition of nblk symmetric matrices already in w.A[blk] (n x n); eigenvalues end up in
 /// w.d[blk] (unsorted), eigenvectors in w.Z[blk].
+static void backtransform_wy(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, const int *ns, int nmax) {
+  hipStream_t s = ctx->stream;
+  const int P = (nmax - 3) / BT_KB + 1;  // reflector blocks of the largest matrix
+  constexpr int BT_S = 6;                // split-K slabs of the skinny product W = V^T Z (few tiles, long K otherwise)
+  std::vector<double *> ptrs(5 * (size_t)nblk);
+  for (int k = 0; k < nblk; k++) {
+    const int n = ns[k];
+    w.Vx[k].resize((size_t)n * n);
+    w.G[k].resize((size_t)P * BT_KB * BT_KB);
+    w.T[k].resize((size_t)P * BT_KB * BT_KB);
+    w.VT[k].resize((size_t)n * P * BT_KB);
+    w.Wb[k].resize((size_t)BT_KB * n);
+    w.Wp[k].resize((size_t)BT_S * BT_KB * n);
+    ptrs[3 * nblk + k] = w.Wp[k].p;
+    ptrs[4 * nblk + k] = w.Wb[k].p;
+    ptrs[k] = w.Vx[k].p;
+    ptrs[nblk + k] = w.G[k].p;
+    ptrs[2 * nblk + k] = w.T[k].p;
+  }
+  w.btptr.upload(ptrs, s);
+  // task lists: [0, P*nblk) Gram, [P*nblk, 2P*nblk) VT = V T, then per block p two lists (W = V^T Z ; Z -= VT W)
+  std::vector<GemmTask> t((size_t)(3 + BT_S) * P * nblk);
+  for (int p = 0; p < P; p++)
+    for (int k = 0; k < nblk; k++) {
+      const int n = ns[k], j0 = p * BT_KB;
+      const int kb = std::min(BT_KB, n - 2 - j0);
+      GemmTask g;  // inactive by default
+      g.A = g.B = nullptr;
+      g.C = nullptr;
+      g.M = g.N = g.K = 0;
+      g.lda = g.ldb = g.ldc = 1;
+      GemmTask gram = g, vt = g, wz = g, upd = g;
+      if (kb > 0) {
+        const int r0 = j0 + 1;  // first row where the block's reflectors are non-zero
+        const int mr = n - r0;
+        const double *Vp = w.Vx[k].p + (size_t)j0 * n + r0;
+        gram.A = Vp;
+        gram.B = Vp;
+        gram.C = w.G[k].p + (size_t)p * BT_KB * BT_KB;
+        gram.tA = 1;
+        gram.M = gram.N = kb;
+        gram.K = mr;
+        gram.lda = gram.ldb = n;
+        gram.ldc = BT_KB;
+        vt.A = Vp;
+        vt.B = w.T[k].p + (size_t)p * BT_KB * BT_KB;
+        vt.C = w.VT[k].p + (size_t)j0 * n + r0;
+        vt.M = mr;
+        vt.N = vt.K = kb;
+        vt.lda = n;
+        vt.ldb = BT_KB;
+        vt.ldc = n;
+        wz.tA = 1;
+        wz.M = kb;
+        wz.N = n;
+        wz.lda = n;
+        wz.ldb = n;
+        wz.ldc = BT_KB;
+        upd.A = w.VT[k].p + (size_t)j0 * n + r0;
+        upd.B = w.Wb[k].p;
+        upd.C = b.Z[k] + r0;
+        upd.M = mr;
+        upd.N = n;
+        upd.K = kb;
+        upd.lda = n;
+        upd.ldb = BT_KB;
+        upd.ldc = n;
+        upd.alpha = -1.0;
+        upd.beta = 1.0;
+      }
+      t[(size_t)p * nblk + k] = gram;
+      t[((size_t)P + p) * nblk + k] = vt;
+      t[((size_t)2 * P + p) * nblk + k] = upd;
+      {
+        // split-K slabs of W = V_p^T Z: rows r0 + [sl*chunk, ...)
+        const int mr = (kb > 0) ? n - (j0 + 1) : 0;
+        const int chunk = ((mr + BT_S - 1) / BT_S + 15) / 16 * 16;
+        for (int sl = 0; sl < BT_S; sl++) {
+          GemmTask q = wz;
+          const int k0 = sl * chunk;
+          const int kk = std::max(0, std::min(chunk, mr - k0));
+          q.C = w.Wp[k].p + (size_t)sl * BT_KB * n;
+          if (kb > 0 && kk > 0) {
+            q.A = w.Vx[k].p + (size_t)j0 * n + (j0 + 1) + k0;
+            q.B = b.Z[k] + (j0 + 1) + k0;
+            q.K = kk;
+          } else if (kb > 0) {  // empty slab: its partial must still read as zero -> K = 0 writes alpha*0 + 0
+            q.A = w.Vx[k].p;
+            q.B = b.Z[k];
+            q.K = 0;
+          }
+          t[(((size_t)3 + sl) * P + p) * nblk + k] = q;
+        }
+      }
+    }
+  w.bttasks.upload(t, s);
+  std::vector<GemmTask> slab((size_t)P * BT_S * nblk);
+  for (int p = 0; p < P; p++)
+    for (int sl = 0; sl < BT_S; sl++)
+      for (int k = 0; k < nblk; k++) slab[((size_t)p * BT_S + sl) * nblk + k] = t[(((size_t)3 + sl) * P + p) * nblk + k];
+  w.btslab.upload(slab, s);
+  HFG_HIP_CHECK(hipStreamSynchronize(s));  // ptrs, t and slab live on this stack frame
+  double *const *dptr = w.btptr.p;
+  hipLaunchKernelGGL(k_bt_extract, dim3((nmax + 255) / 256, nmax, nblk), dim3(256), 0, s, b, dptr);
+  gemm_tasklist64_dev(ctx, w.bttasks.p, P * nblk, BT_KB, BT_KB);
+  hipLaunchKernelGGL(k_bt_T, dim3(P, nblk), dim3(BT_KB), 0, s, b, dptr + nblk, dptr + 2 * nblk);
+  gemm_tasklist64_dev(ctx, w.bttasks.p + (size_t)P * nblk, P * nblk, nmax, BT_KB);
+  // the slabs of one reflector block are P*nblk tasks apart: launch them as BT_S lists in one go per block p by
+  // laying the lists out [slab][p][blk] and launching slab by slab would cost BT_S launches; instead the slab lists
+  // of block p are gathered contiguously below
+  for (int p = P - 1; p >= 0; p--) {
+    gemm_tasklist64_dev(ctx, w.btslab.p + (size_t)p * BT_S * nblk, BT_S * nblk, BT_KB, nmax);
+    hipLaunchKernelGGL(k_bt_wsum, dim3(64, nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk, BT_S);
+    gemm_tasklist_dev(ctx, w.bttasks.p + ((size_t)2 * P + p) * nblk, nblk, nmax, nmax);
+  }
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
 static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
   EigBatch b;
   b.nblk = nblk;
@@ -525,6 +708,10 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
   }
   {
     ProfScope ps(ctx, "eig_backtransform");
+    static const bool bt_column = (getenv("HELFEM_BT") && !strcmp(getenv("HELFEM_BT"), "column"));
+    if (!bt_column && nmax >= 4 * BT_KB) {
+      backtransform_wy(ctx, w, b, nblk, ns, nmax);
+    } else {
     dim3 grid((nmax + 3) / 4, nblk);
     if (nmax <= 64 * 8)
       hipLaunchKernelGGL(k_backtransform<8>, grid, dim3(256), 0, s, b);
@@ -536,6 +723,7 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
         HFG_HIP_CHECK(
             hipFuncSetAttribute((const void *)k_backtransform_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
       hipLaunchKernelGGL(k_backtransform_lds, grid, dim3(256), shb, s, b);
+    }
     }
   }
   HFG_HIP_CHECK(hipGetLastError());
