@@ -745,7 +745,7 @@ static void check_status(hfg_ctx *ctx, EigWork &w, int nblk) {
 // E (n), C (n x n) <- eig_sym(A) ; all device pointers
 void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC) {
   EigWork &w = work_for(ctx);
-  w.A[0].resize((size_t)n * n);
+  w.A[0].resize((size_t)n * n + 2);
   HFG_HIP_CHECK(hipMemcpyAsync(w.A[0].p, dA, sizeof(double) * n * n, hipMemcpyDeviceToDevice, ctx->stream));
   eig_sym_batch(ctx, w, 1, &n);
   DevBuf<int> &rank = w.ibuf1;
@@ -759,7 +759,7 @@ void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC) 
 // scf::eig_gsym: F N x N, Sinvh N x n  ->  E (n), C (N x n)
 void eig_gsym_dev(hfg_ctx *ctx, int N, int n, const double *dF, const double *dS, double *dE, double *dC) {
   EigWork &w = work_for(ctx);
-  w.A[0].resize((size_t)n * n);
+  w.A[0].resize((size_t)n * n + 2);
   DevBuf<double> &T1 = ctx->ws[0];
   DevBuf<double> &Ctmp = ctx->ws[1];
   T1.resize((size_t)N * n);
@@ -856,7 +856,7 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
       int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
       ns[k] = n;
       nm = std::max(nm, n);
-      w.A[k].resize((size_t)n * n);
+      w.A[k].resize((size_t)n * n + 2);  // + 2: the sweep's 16-byte row pairs may straddle the last element
       w.Z[k].resize((size_t)n * n);
       double *Xb = Xall.p + (size_t)k * nmax * nmax, *Fk = Fb.p + (size_t)k * nmax * nmax, *Tk = T1.p + (size_t)k * nmax * nmax;
       GemmTask g;

@@ -404,6 +404,9 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   // columns of the tile over eight waves.  Load order matters more than thread count here: a workgroup pulls its
   // 128 KB tile through one CU in 2-3 us, so the small phase-A loads are issued first and the tile streams in
   // behind them while the reductions and the scalar algebra run.
+  // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the
+  // 128 KB tile that is deliberately still in flight during phase A
+#define TRDF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   const TrdBatch &b = *bp;
   const int blk = blockIdx.y;
   const unsigned long long tk0 = wall_clock64();
@@ -463,21 +466,35 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   // BEHIND the small phase-A loads so that those return first (vmcnt is in order)
   auto issue_tile = [&]() {
     if (!has_cur) return;
-    const gdouble *a = A + (size_t)(i + 1) * n + (i + 1) + row;
+    // 32-bit element offsets from the (uniform) base pointer: n^2 < 2^31 for every n the launcher admits, and the
+    // saddr + voffset form of global_load needs two VALU instructions per load instead of 64-bit multiply-adds
+    const unsigned a0 = (unsigned)(i + 1) * (unsigned)n + (unsigned)(i + 1) + (unsigned)row;  // row = -1 wraps by one
+    const bool ok0 = row >= 0 && row < m, ok1 = row + 1 >= 0 && row + 1 < m;
+    if (vec2) {
+      // one 16-byte load per column for every lane that owns at least one valid row.  The pair may straddle the edge
+      // of the trailing block (row -1 above it, row m below it): those 8 bytes are still inside the matrix buffer
+      // (the callers allocate two spare doubles behind the last column) and are discarded.  A single load
+      // instruction per register pair: mixing 8- and 16-byte variants makes the compiler drain vmcnt between them.
+      // Unconditional loads with clamped indices (lanes below the block re-read a pair near its top, columns right of
+      // it re-read the last column; both are masked later): loads inside divergent branches -- or selects between
+      // two addresses, which the compiler turns into branches -- make its vmcnt bookkeeping fall back to vmcnt(0)
+      // at the next use of ANY load.
+      const int rowc = (row < m) ? row : (row & 1);  // same parity (alignment); row = -1 and row = m-1 stay as they are
+      const unsigned a1 = (unsigned)(i + 1) * (unsigned)n + (unsigned)(i + 1) + (unsigned)rowc;
 #pragma unroll
-    for (int u = 0; u < NU; u++) {
-      int cc = TF_T * cs + wave * NU + u;  // local column
-      r0[u] = 0.0;
-      r1[u] = 0.0;
-      if (cc < m) {
-        if (vec2 && row >= 0 && row + 1 < m) {
-          d2_t t = *(const gdouble2 *)(a + (size_t)cc * n);
-          r0[u] = t.x;
-          r1[u] = t.y;
-        } else {
-          if (row >= 0 && row < m) r0[u] = a[(size_t)cc * n];
-          if (row + 1 >= 0 && row + 1 < m) r1[u] = a[(size_t)cc * n + 1];
-        }
+      for (int u = 0; u < NU; u++) {
+        const int cc = min(TF_T * cs + wave * NU + u, m - 1);  // local column, clamped
+        d2_t t = *(const gdouble2 *)(A + (a1 + (unsigned)cc * (unsigned)n));
+        r0[u] = t.x;  // rows outside the block are masked after the FMAs, x is zero on the clamped columns
+        r1[u] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        const int cc = TF_T * cs + wave * NU + u;
+        const unsigned off = a0 + (unsigned)cc * (unsigned)n;
+        r0[u] = (ok0 && cc < m) ? A[off] : 0.0;
+        r1[u] = (ok1 && cc < m) ? A[off + 1u] : 0.0;
       }
     }
   };
@@ -507,35 +524,58 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     constexpr int HB = TB_NB / TF_NG;
     double vv[HB], ww[HB];
     double qraw = 0.0, xg = 0.0, ag = 0.0;
+    // sums over the column slabs of K_{i-1}: predicated, fully unrolled loads (a rolled "load, wait, add" loop costs
+    // one memory round trip per slab); slabs beyond 12 (n > 1536) take the rolled tail
+    constexpr int PU = 12;
+    double qp[PU];
+    const unsigned ug = (unsigned)g, un = (unsigned)n;
+#pragma unroll
+    for (int k = 0; k < PU; k++) qp[k] = (live && grp == 0 && k < pncs) ? ppv[(unsigned)k * un + ug] : 0.0;
     if (live && grp == 0) {
-      for (int k = 0; k < pncs; k++) qraw += ppv[(size_t)k * n + g];
-      xg = px[g];
-      ag = A[(size_t)i * n + g];
+      xg = px[ug];
+      ag = A[(unsigned)i * un + ug];
     }
 #pragma unroll
     for (int u = 0; u < HB; u++) {
       int cc = grp + TF_NG * u;
       bool ok = live && cc < cp && !(dbg & 2);
-      vv[u] = ok ? Vb[(size_t)cc * n + g] : 0.0;
-      ww[u] = ok ? Wb[(size_t)cc * n + g] : 0.0;
+      vv[u] = ok ? Vb[(unsigned)cc * un + ug] : 0.0;
+      ww[u] = ok ? Wb[(unsigned)cc * un + ug] : 0.0;
     }
     // scalar stage (every workgroup, redundantly): reductions of the partials of K_{i-1}
     {
-      double s = 0.0;  // x^T A22 x
       const int nd = pnrt * pncs;
-      for (int k = tid; k < nd; k += TF_NTH) s += pdots[k];
+      double s0 = (tid < nd) ? pdots[tid] : 0.0, s1 = (tid + TF_NTH < nd) ? pdots[tid + TF_NTH] : 0.0;  // x^T A22 x
       double t2 = (tid < pncs) ? pxn2[tid] : 0.0;                 // |x[1:]|^2
-      double qi = (tid < pncs) ? ppv[(size_t)tid * n + i] : 0.0;  // q_raw at row i
+      double qi = (tid < pncs) ? ppv[(unsigned)tid * un + (unsigned)i] : 0.0;  // q_raw at row i
       double cpl = 0.0;  // this thread's share of the V^T x, W^T x partials / rows i of V, W (loads issued here)
+      double cq[PU];
+#pragma unroll
+      for (int k2 = 0; k2 < PU; k2++) cq[k2] = 0.0;
       if (tid >= 256 && tid < 256 + 2 * TB_NB) {
         int t = tid - 256, cc = t % TB_NB;
-        if (cc < cp)
-          for (int k2 = 0; k2 < pncs; k2++) cpl += pcp[(size_t)k2 * 2 * TB_NB + t];
+        if (cc < cp) {
+#pragma unroll
+          for (int k2 = 0; k2 < PU; k2++)
+            if (k2 < pncs) cq[k2] = pcp[(unsigned)(k2 * 2 * TB_NB + t)];
+          for (int k2 = PU; k2 < pncs; k2++) cpl += pcp[(size_t)k2 * 2 * TB_NB + t];
+        }
       } else if (tid >= 384 && tid < 384 + 2 * TB_NB) {
         int t = tid - 384, cc = t % TB_NB;
-        if (cc < cp) cpl = (t < TB_NB) ? Vb[(size_t)cc * n + i] : Wb[(size_t)cc * n + i];
+        if (cc < cp) cpl = (t < TB_NB) ? Vb[(unsigned)cc * un + (unsigned)i] : Wb[(unsigned)cc * un + (unsigned)i];
       }
+      TRDF_STAMP(6)
       issue_tile();
+      TRDF_STAMP(7)
+      double s = s0 + s1;
+      for (int k = tid + 2 * TF_NTH; k < nd; k += TF_NTH) s += pdots[k];
+#pragma unroll
+      for (int k2 = 0; k2 < PU; k2++) {
+        cpl += cq[k2];
+        qraw += qp[k2];
+      }
+      if (live && grp == 0)
+        for (int k = PU; k < pncs; k++) qraw += ppv[(size_t)k * n + g];
       for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_down(s, o, 64);
         t2 += __shfl_down(t2, o, 64);
@@ -548,6 +588,10 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
           sred[41] = qi;
         }
       }
+      if (dbg & 4) {
+        if (blockIdx.x == 0 && blk == 0 && threadIdx.x == 0)
+          ((gu64 *)(b.fcp[blk] + (size_t)2 * TF_MAXS * 2 * TB_NB))[(size_t)i * 8 + 6] |= ((wall_clock64() - tk0) << 32);
+      }
       // waves 4..7: V^T x, W^T x of the panel columns cc < cp and the rows i of V and W
       if (tid >= 256 && tid < 256 + 2 * TB_NB) {
         int t = tid - 256, cc = t % TB_NB;
@@ -559,7 +603,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
         else sWi[cc] = cpl;
       }
     }
-    __syncthreads();
+    TRDF_LDS_BARRIER();
     TRDF_STAMP(1)
     if (wave == 0) {
       // lanes 0..31 hold one panel column each: three small dot products by shuffles, then lane 0 finishes
@@ -618,7 +662,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
       qpart[grp][rid] = qc;
       zpart[grp][rid] = zc;
     }
-    __syncthreads();
+    TRDF_LDS_BARRIER();
     TRDF_STAMP(2)
     const double beta = scal[0], tau = scal[1], scale = scal[2], pvv = scal[3], wi0 = scal[4];
     if (grp == 0 && live) {
@@ -671,7 +715,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
       wC[rid - TF_T] = live ? wg : 0.0;
     }
   }
-  __syncthreads();
+  TRDF_LDS_BARRIER();
   TRDF_STAMP(3)
 
   // ---- (B) sweep: partial q over this tile ----
@@ -682,8 +726,11 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     acc0 += r0[u] * xc;
     acc1 += r1[u] * xc;
   }
-  red[wave * TF_T + 2 * lane] = acc0;
-  red[wave * TF_T + 2 * lane + 1] = acc1;
+  {
+    const bool ok0 = row >= 0 && row < m, ok1 = row + 1 >= 0 && row + 1 < m;
+    red[wave * TF_T + 2 * lane] = ok0 ? acc0 : 0.0;
+    red[wave * TF_T + 2 * lane + 1] = ok1 ? acc1 : 0.0;
+  }
   __syncthreads();
   TRDF_STAMP(4)
   double dv = 0.0;
@@ -752,6 +799,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     if (rs == 0) fxn2w[(size_t)par * TF_MAXS + cs] = sred[50] + sred[51];
   }
 #undef TRDF_STAMP
+#undef TRDF_LDS_BARRIER
 }
 
 // d, e of the last 2x2 block (after the final trailing update)
@@ -982,6 +1030,19 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
       if (i % TB_NB == 0) continue;
       for (int k = 0; k < 6; k++) acc[k] += (double)st[(size_t)i * 8 + k];
       cnt++;
+    }
+    {
+      double a6 = 0, a7 = 0, a8 = 0;
+      int cn = 0;
+      for (int i = 40; i < n0 - 40; i++) {
+        if (i % TB_NB == 0) continue;
+        a6 += (double)(st[(size_t)i * 8 + 6] & 0xffffffffull);
+        a8 += (double)(st[(size_t)i * 8 + 6] >> 32);
+        a7 += (double)st[(size_t)i * 8 + 7];
+        cn++;
+      }
+      fprintf(stderr, "  phase A detail: loads issued %.2f | tile issued %.2f | own reductions done %.2f us\n", a6 / cn / 100.0,
+              a7 / cn / 100.0, a8 / cn / 100.0);
     }
     fprintf(stderr, "k_trdf phase stamps (us since kernel entry, mean over %d columns): desc %.2f | loads+barrier1 %.2f | scalars+barrier2 %.2f | rows+barrier3 %.2f | tile+barrier4 %.2f | end %.2f\n",
             cnt, acc[0] / cnt / 100.0, acc[1] / cnt / 100.0, acc[2] / cnt / 100.0, acc[3] / cnt / 100.0, acc[4] / cnt / 100.0, acc[5] / cnt / 100.0);
