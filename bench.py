@@ -99,7 +99,10 @@ def main():
     basis, bval, lval, mval, ldft, mdft = build_basis(hf, w)
     basis.compute_tei(False)
     N = basis.Nbf()
-    step = hf.DeviceSCFStep(basis, w["x"], w["c"], ldft, mdft, w["nocc"], symmetry=1, device=local_rank, rank=rank,
+    # one rank per GPU; HELFEM_BENCH_DEVICE pins every rank to one device (rehearsal of the N>1 path on a 1-GPU box
+    # together with HELFEM_DIST_BACKEND=gloo)
+    dev_index = int(os.environ.get("HELFEM_BENCH_DEVICE", local_rank))
+    step = hf.DeviceSCFStep(basis, w["x"], w["c"], ldft, mdft, w["nocc"], symmetry=1, device=dev_index, rank=rank,
                             nranks=world)
     ctx = step.ctx
     S = basis.overlap()
@@ -134,6 +137,15 @@ def main():
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, device=step.dev if world > 1 else "cpu")
     ms_per_step = dt / args.steps * 1e3
+
+    # self-check of the timed path, independent of the number of ranks: ONE step from the fixed guess density
+    # (the undamped iteration itself is chaotic from a core guess, its later iterates are not comparable)
+    step.set_density(P0)
+    one_step()
+    torch.cuda.synchronize()
+    check = {"sum_lowest_eigenvalues_after_one_step": float(step.E[:w["nocc"]].sum().item()),
+             "sum_all_eigenvalues_after_one_step": float(step.E.sum().item()),
+             "xc_energy_after_one_step": float(step.scal[0].item())}
 
     fams = {}
     for name in ("coulomb", "xc", "scatter", "eig_reduce", "eig_tridiag", "eig_tridiag_solve", "eig_backtransform",
@@ -186,6 +198,8 @@ def main():
                          "avg_launch_us": avg_ms * 1e3, "launches_per_step": launches_per_step,
                          "note": "latency-bound: one dependent launch per Householder column (see DESIGN.md 3.4)"},
             "stages_ms": {k: round(v["ms_per_step"], 4) for k, v in fams.items()},
+            # size-independent self-check of the timed path: must not depend on the number of ranks
+            "check": check,
         }
         if not args.no_cpu_baseline and world == 1:
             P = step.numpy(step.P, (N, N))

@@ -109,8 +109,17 @@ class Context(object):
     """hfg_ctx: one device + one stream."""
 
     def __init__(self, device=0, stream=None):
+        """stream: None -> the context creates its own stream; an integer hipStream_t handle -> enqueue there, where
+        the handle 0 (what torch.cuda.current_stream().cuda_stream returns for the default stream) means the null
+        stream itself (HFG_NULL_STREAM), so that the kernels stay ordered with torch operations and collectives"""
         h = ctypes.c_void_p()
-        _check(lib().hfg_ctx_create(ctypes.byref(h), int(device), ctypes.c_void_p(stream) if stream else None))
+        if stream is None:
+            sp = None
+        elif int(stream) == 0:
+            sp = ctypes.c_void_p(-1)  # HFG_NULL_STREAM
+        else:
+            sp = ctypes.c_void_p(int(stream))
+        _check(lib().hfg_ctx_create(ctypes.byref(h), int(device), sp))
         self.h = h
         self.device = device
 

@@ -150,7 +150,10 @@ int hfg_ctx_create(hfg_ctx **out, int device, void *stream) {
   HFG_HIP_CHECK(hipSetDevice(device));
   hfg_ctx *c = new hfg_ctx();
   c->device = device;
-  if (stream) {
+  if (stream == HFG_NULL_STREAM) {
+    c->stream = nullptr;  // the device's default (null) stream: ordered with everything a framework enqueues there
+    c->own_stream = false;
+  } else if (stream) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
   } else {

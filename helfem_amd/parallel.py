@@ -27,7 +27,9 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # HELFEM_DIST_BACKEND=gloo lets several ranks rehearse the N>1 path on ONE GPU (RCCL refuses two ranks
+            # on the same device); the default on a GPU node is RCCL ("nccl")
+            backend = os.environ.get("HELFEM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

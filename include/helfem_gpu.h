@@ -35,8 +35,11 @@ typedef struct hfg_ctx hfg_ctx;
 typedef struct hfg_basis hfg_basis;
 
 /* ---- context ------------------------------------------------------------------------------ */
-/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream) or NULL to
- * let the context create its own non-blocking stream. */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), HFG_NULL_STREAM for the
+ * device's default (null) stream -- which is what a framework's "current stream" handle 0 means: kernels must be
+ * enqueued THERE to stay ordered with the framework's own operations and collectives -- or NULL to let the context
+ * create its own non-blocking stream. */
+#define HFG_NULL_STREAM ((void *)(intptr_t)-1)
 int hfg_ctx_create(hfg_ctx **ctx, int device, void *stream);
 int hfg_ctx_destroy(hfg_ctx *ctx);
 int hfg_ctx_synchronize(hfg_ctx *ctx);
