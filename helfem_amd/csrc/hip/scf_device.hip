@@ -1,0 +1,419 @@
+// Device-resident SCF loop: the per-iteration part of the reference drivers (src/diatomic/main.cpp:780-995,
+// src/atomic/main.cpp:760-1005) with every matrix kept in HBM between the steps -- density, Fock build, DIIS
+// (uDIIS::update / solve_F, src/general/diis.cpp:129-168, 392-412), generalized eigensolve.  Only a handful of
+// scalars (energies, the DIIS error norm and the small B matrix) cross PCIe per iteration.  The host-pointer
+// driver (host/scf.cpp with GPUBackend, scf_gpu.cpp) computes the same numbers and is kept as the checker of
+// this one (HELFEM_SCF=host).
+#include "tables.h"
+#include "../host/dftfuncs.h"
+#include "../host/scf.h"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <deque>
+#include <memory>
+
+namespace hfg {
+
+void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
+              const double *B, int ldb, double beta, double *C, int ldc);
+void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
+                 double thr);
+void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
+                     double *dHa, double *dHb, double *dScal, double thr);
+void form_sinvh_dev(hfg_ctx *ctx, int N, const double *dS, bool chol, int nblk, const int64_t *blk_ptr,
+                    const int64_t *blk_idx, double *dSinvh);
+void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc, double *dP);
+void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
+                      const int64_t *blk_idx, double *dE, double *dC);
+void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
+void fock_release(hfg_dev_tables *t);
+void exchange_release(hfg_dev_tables *t);
+void exchange_lr_release(hfg_dev_tables *t);
+
+namespace {
+
+// y = a x + b y
+__global__ void k_axpby(size_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += st) y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+}
+// E = X - X^T
+__global__ void k_antisym(const double *__restrict__ X, int N, double *__restrict__ E) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= N) return;
+  E[(size_t)j * N + i] = X[(size_t)j * N + i] - X[(size_t)i * N + j];
+}
+// F(i,j) = 0 when i and j belong to different symmetry blocks   (scf::enforce_fock_symmetry, scf_helpers.cpp:249)
+__global__ void k_mask_blocks(double *__restrict__ F, int N, const int *__restrict__ blockid) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= N) return;
+  if (blockid[i] != blockid[j]) F[(size_t)j * N + i] = 0.0;
+}
+// two-stage deterministic reductions: partial[b] = sum / max over the block's grid-stride range
+__global__ __launch_bounds__(256) void k_dot_partial(size_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                     double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * y[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void k_maxabs_partial(size_t n, const double *__restrict__ x, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s = fmax(s, fabs(x[i]));
+  for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_down(s, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+__global__ void k_finish_reduce(const double *__restrict__ partial, int nb, int is_max, double *__restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  double s = 0.0;
+  for (int i = 0; i < nb; i++) s = is_max ? fmax(s, partial[i]) : s + partial[i];
+  *out = s;
+}
+
+double wall() {
+  using namespace std::chrono;
+  return duration_cast<duration<double> >(steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr int RED_BLOCKS = 512;
+
+struct DevSCF {
+  hfg_ctx *ctx;
+  hipStream_t s;
+  size_t N = 0, NN = 0;
+  DevBuf<double> S, T, V, H0, Sinvh, Ca, Cb, Ea, Eb, Pa, Pb, P, J, Ka, Kb, XCa, XCb, Fa, Fb, T1, T2, Err, scal, partial, res;
+  DevBuf<int> blockid;
+  std::unique_ptr<DevBuf<double>[]> histF, histE;  // DIIS history (ring)
+  std::vector<double> hres;
+
+  explicit DevSCF(hfg_ctx *c) : ctx(c), s(c->stream) {}
+
+  void up(DevBuf<double> &d, const helfem::Mat &M) {
+    d.resize(M.n_elem());
+    HFG_HIP_CHECK(hipMemcpyAsync(d.p, M.memptr(), sizeof(double) * M.n_elem(), hipMemcpyHostToDevice, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  void axpby(double a, const double *x, double b, double *y, size_t n) {
+    hipLaunchKernelGGL(k_axpby, dim3(2048), dim3(256), 0, s, n, a, x, b, y);
+  }
+  // result slot k of the device scalar array <- x . y
+  void dot(const double *x, const double *y, size_t n, int slot) {
+    hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(256), 0, s, n, x, y, partial.p);
+    hipLaunchKernelGGL(k_finish_reduce, dim3(1), dim3(64), 0, s, partial.p, RED_BLOCKS, 0, res.p + slot);
+  }
+  void maxabs(const double *x, size_t n, int slot) {
+    hipLaunchKernelGGL(k_maxabs_partial, dim3(RED_BLOCKS), dim3(256), 0, s, n, x, partial.p);
+    hipLaunchKernelGGL(k_finish_reduce, dim3(1), dim3(64), 0, s, partial.p, RED_BLOCKS, 1, res.p + slot);
+  }
+  void fetch(int nslots) {
+    hres.resize(nslots);
+    HFG_HIP_CHECK(hipMemcpyAsync(hres.data(), res.p, sizeof(double) * nslots, hipMemcpyDeviceToHost, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  // err = Sinvh^T (F P S - S P F) Sinvh    (diis.cpp:139-146)
+  void diis_error(const double *F, const double *Ps, double *err) {
+    const int n = (int)N;
+    gemm_dev(ctx, false, false, n, n, n, 1.0, F, n, Ps, n, 0.0, T1.p, n);
+    gemm_dev(ctx, false, false, n, n, n, 1.0, T1.p, n, S.p, n, 0.0, T2.p, n);
+    hipLaunchKernelGGL(k_antisym, dim3((n + 255) / 256, n), dim3(256), 0, s, T2.p, n, T1.p);
+    gemm_dev(ctx, true, false, n, n, n, 1.0, Sinvh.p, n, T1.p, n, 0.0, T2.p, n);
+    gemm_dev(ctx, false, false, n, n, n, 1.0, T2.p, n, Sinvh.p, n, 0.0, err, n);
+  }
+};
+
+}  // namespace
+
+/// the shared part of both programs, everything on the device; `basis` already holds the host tables of S, T, V
+helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::scf::Options &opt, int nel, double Enucr,
+                                    int symm, const std::vector<std::vector<size_t> > &dsym, int ldft, int mdft) {
+  using helfem::Mat;
+  helfem::scf::Result res;
+  res.Enucr = Enucr;
+  const bool verbose = opt.verbose;
+  const bool dft = (opt.x_func > 0 || opt.c_func > 0);
+  const int M = opt.multiplicity;
+  if (M < 1 || (nel + M - 1) % 2 != 0 || M - 1 > nel) throw std::logic_error("Requested multiplicity not achievable.\n");
+  const int nela = (nel + M - 1) / 2, nelb = nel - nela;
+  const bool restr = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
+  if (restr && nela != nelb)
+    throw std::logic_error("Restricted open-shell (ROHF) runs are not implemented in this build.\n");
+  res.nela = nela;
+  res.nelb = nelb;
+
+  DevSCF d(ctx);
+  hipStream_t s = d.s;
+  {
+    Mat S = hb->kind ? hb->ab.overlap() : hb->b.overlap();
+    Mat T = hb->kind ? hb->ab.kinetic() : hb->b.kinetic();
+    Mat V = hb->kind ? hb->ab.nuclear() : hb->b.nuclear();
+    d.N = S.n_rows;
+    d.NN = d.N * d.N;
+    d.up(d.S, S);
+    d.up(d.T, T);
+    d.up(d.V, V);
+    Mat H0 = T + V;
+    d.up(d.H0, H0);
+  }
+  const size_t N = d.N, NN = d.NN;
+  const int n = (int)N;
+  res.Nbf = N;
+  // symmetry blocks
+  std::vector<int64_t> ptr(1, 0), idx;
+  std::vector<int> blockid(N, 0);
+  for (size_t ib = 0; ib < dsym.size(); ib++) {
+    for (size_t v : dsym[ib]) {
+      idx.push_back((int64_t)v);
+      blockid[v] = (int)ib;
+    }
+    ptr.push_back((int64_t)idx.size());
+  }
+  d.blockid.upload(blockid, s);
+  for (DevBuf<double> *b : {&d.Sinvh, &d.Ca, &d.Pa, &d.P, &d.J, &d.Fa, &d.T1, &d.T2, &d.Err}) b->resize(NN);
+  d.Ea.resize(N);
+  d.scal.resize(4);
+  d.partial.resize(RED_BLOCKS);
+  d.res.resize(64);
+  if (!restr) {
+    for (DevBuf<double> *b : {&d.Cb, &d.Pb, &d.Fb}) b->resize(NN);
+    d.Eb.resize(N);
+  }
+  if (opt.kfrac != 0.0) {
+    d.Ka.resize(NN);
+    if (!restr) d.Kb.resize(NN);
+  }
+  if (dft) {
+    d.XCa.resize(NN);
+    if (!restr) d.XCb.resize(NN);
+  }
+  const int nspin = restr ? 1 : 2;
+  const int order = opt.diisorder;
+  d.histF.reset(new DevBuf<double>[order]);
+  d.histE.reset(new DevBuf<double>[order]);
+  for (int k = 0; k < order; k++) {
+    d.histF[k].resize(nspin * NN);
+    d.histE[k].resize(nspin * NN);
+  }
+
+  double t0 = wall();
+  form_sinvh_dev(ctx, n, d.S.p, !opt.diag, (int)dsym.size(), ptr.data(), idx.data(), d.Sinvh.p);
+  HFG_HIP_CHECK(hipStreamSynchronize(s));
+  if (verbose) printf("Half-inverse formed in %.6f\n", wall() - t0);
+  if (verbose) printf("Guess orbitals from core Hamiltonian\n");
+  eig_gsym_sub_dev(ctx, n, d.H0.p, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), d.Ea.p, d.Ca.p);
+  if (!restr) {
+    HFG_HIP_CHECK(hipMemcpyAsync(d.Cb.p, d.Ca.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+    HFG_HIP_CHECK(hipMemcpyAsync(d.Eb.p, d.Ea.p, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
+  }
+
+  if (verbose) printf("Computing two-electron integrals\n");
+  t0 = wall();
+  if (hb->kind) hb->ab.compute_tei(opt.kfrac != 0.0);
+  else hb->b.compute_tei(opt.kfrac != 0.0);
+  if (hb->dev) {
+    fock_release(hb->dev);
+    exchange_release(hb->dev);
+    exchange_lr_release(hb->dev);
+  }
+  upload_tables(ctx, hb, ldft, mdft);
+  if (verbose) printf("Done in %.6f\n", wall() - t0);
+
+  std::vector<std::vector<double> > B;  // DIIS inner products of the stored errors, indexed by ring slot
+  B.assign(order, std::vector<double>(order, 0.0));
+  std::deque<int> slots;  // ring slots in age order
+  double Eold = 0.0;
+  for (int it = 1; it <= opt.maxit; it++) {
+    if (verbose) printf("\n**** Iteration %i ****\n\n", it);
+    form_density_dev(ctx, n, n, d.Ca.p, nela, d.Pa.p);
+    const double *Pb = d.Pa.p;
+    if (!restr) {
+      if (nelb) form_density_dev(ctx, n, n, d.Cb.p, nelb, d.Pb.p);
+      else HFG_HIP_CHECK(hipMemsetAsync(d.Pb.p, 0, sizeof(double) * NN, s));
+      Pb = d.Pb.p;
+    }
+    HFG_HIP_CHECK(hipMemcpyAsync(d.P.p, d.Pa.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+    d.axpby(1.0, Pb, 1.0, d.P.p, NN);
+
+    double tJ0 = wall();
+    coulomb_dev(ctx, hb, d.P.p, d.J.p);
+    if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
+    res.tJ = wall() - tJ0;
+    double tK0 = wall();
+    if (opt.kfrac != 0.0) {
+      exchange_dev(ctx, hb, d.Pa.p, d.Ka.p);
+      d.axpby(0.0, d.Ka.p, opt.kfrac, d.Ka.p, NN);  // Ka *= kfrac
+      if (!restr) {
+        if (nelb) {
+          exchange_dev(ctx, hb, d.Pb.p, d.Kb.p);
+          d.axpby(0.0, d.Kb.p, opt.kfrac, d.Kb.p, NN);
+        } else
+          HFG_HIP_CHECK(hipMemsetAsync(d.Kb.p, 0, sizeof(double) * NN, s));
+      }
+      if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    res.tK = wall() - tK0;
+    double tX0 = wall();
+    if (dft) {
+      if (restr) xc_fock_dev(ctx, hb, opt.x_func, opt.c_func, d.P.p, d.XCa.p, d.scal.p, opt.dftthr);
+      else xc_fock_pol_dev(ctx, hb, opt.x_func, opt.c_func, d.Pa.p, d.Pb.p, d.XCa.p, d.XCb.p, d.scal.p, opt.dftthr);
+      if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    res.tXC = wall() - tX0;
+
+    // energies: res slots 0 Ekin, 1 Epot, 2 2*Ecoul, 3 Tr PaKa, 4 Tr PbKb
+    d.dot(d.P.p, d.T.p, NN, 0);
+    d.dot(d.P.p, d.V.p, NN, 1);
+    d.dot(d.P.p, d.J.p, NN, 2);
+    if (opt.kfrac != 0.0) {
+      d.dot(d.Pa.p, d.Ka.p, NN, 3);
+      if (!restr) d.dot(d.Pb.p, d.Kb.p, NN, 4);
+    }
+
+    // Fock matrices
+    for (int sp = 0; sp < nspin; sp++) {
+      double *F = sp ? d.Fb.p : d.Fa.p;
+      HFG_HIP_CHECK(hipMemcpyAsync(F, d.H0.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+      d.axpby(1.0, d.J.p, 1.0, F, NN);
+      if (opt.kfrac != 0.0) d.axpby(1.0, sp ? d.Kb.p : d.Ka.p, 1.0, F, NN);
+      if (dft) d.axpby(1.0, sp ? d.XCb.p : d.XCa.p, 1.0, F, NN);
+      if (symm) hipLaunchKernelGGL(k_mask_blocks, dim3((n + 255) / 256, n), dim3(256), 0, s, F, n, d.blockid.p);
+    }
+
+    // DIIS: store (F, err) in a ring slot, new row of B, slot 5 = max |err|
+    t0 = wall();
+    int slot;
+    if ((int)slots.size() == order) {
+      slot = slots.front();
+      slots.pop_front();
+    } else
+      slot = (int)slots.size();
+    slots.push_back(slot);
+    for (int sp = 0; sp < nspin; sp++) {
+      double *F = sp ? d.Fb.p : d.Fa.p;
+      d.diis_error(F, sp ? d.Pb.p : d.Pa.p, d.histE[slot].p + sp * NN);
+      HFG_HIP_CHECK(hipMemcpyAsync(d.histF[slot].p + sp * NN, F, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+    }
+    d.maxabs(d.histE[slot].p, nspin * NN, 5);
+    for (size_t k = 0; k < slots.size(); k++) d.dot(d.histE[slot].p, d.histE[slots[k]].p, nspin * NN, 8 + (int)k);
+    d.fetch(8 + (int)slots.size());
+    if (dft) {
+      double sc[3];
+      HFG_HIP_CHECK(hipMemcpyAsync(sc, d.scal.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+      HFG_HIP_CHECK(hipStreamSynchronize(s));
+      res.Exc = sc[0];
+      if (verbose) {
+        printf("DFT energy %.10e % .6f\n", res.Exc, res.tXC);
+        printf("Error in integrated number of electrons % e\n", sc[1] - nel);
+      }
+    }
+    res.Ekin = d.hres[0];
+    res.Epot = d.hres[1];
+    res.Ecoul = 0.5 * d.hres[2];
+    res.Exx = 0.0;
+    if (opt.kfrac != 0.0) res.Exx = restr ? d.hres[3] : 0.5 * d.hres[3] + 0.5 * d.hres[4];
+    const double diiserr = d.hres[5];
+    for (size_t k = 0; k < slots.size(); k++) B[slot][slots[k]] = B[slots[k]][slot] = d.hres[8 + k];
+    if (verbose) {
+      printf("Coulomb energy %.10e % .6f\n", res.Ecoul, res.tJ);
+      if (opt.kfrac != 0.0) printf("Exchange energy %.10e % .6f\n", res.Exx, res.tK);
+    }
+    res.Etot = res.Ekin + res.Epot + res.Ecoul + res.Exx + res.Exc + res.Enucr;
+    const double dE = res.Etot - Eold;
+    if (verbose) {
+      printf("Total energy is % .10f\n", res.Etot);
+      if (it > 1) printf("Energy changed by %e\n", dE);
+      printf("DIIS error is %e, update done in %.6f\n", diiserr, wall() - t0);
+    }
+    Eold = res.Etot;
+
+    // Pulay coefficients on the host (tiny), extrapolated Fock matrices on the device
+    const size_t nh = slots.size();
+    std::vector<double> coef(nh, 0.0);
+    if (nh == 1)
+      coef[0] = 1.0;
+    else {
+      const size_t m = nh + 1;
+      std::vector<double> A(m * m, 0.0), rhs(m, 0.0);
+      for (size_t a = 0; a < nh; a++)
+        for (size_t b2 = 0; b2 < nh; b2++) A[a * m + b2] = B[slots[a]][slots[b2]];
+      for (size_t a = 0; a < nh; a++) A[a * m + nh] = A[nh * m + a] = 1.0;
+      rhs[nh] = 1.0;
+      bool ok = true;
+      for (size_t c = 0; c < m && ok; c++) {
+        size_t p = c;
+        for (size_t r = c + 1; r < m; r++)
+          if (fabs(A[r * m + c]) > fabs(A[p * m + c])) p = r;
+        if (p != c) {
+          for (size_t k = 0; k < m; k++) std::swap(A[c * m + k], A[p * m + k]);
+          std::swap(rhs[c], rhs[p]);
+        }
+        if (A[c * m + c] == 0.0) {
+          ok = false;
+          break;
+        }
+        for (size_t r = c + 1; r < m; r++) {
+          double f = A[r * m + c] / A[c * m + c];
+          for (size_t k = c; k < m; k++) A[r * m + k] -= f * A[c * m + k];
+          rhs[r] -= f * rhs[c];
+        }
+      }
+      if (ok) {
+        std::vector<double> x(m);
+        for (size_t ii = m; ii-- > 0;) {
+          double sv = rhs[ii];
+          for (size_t k = ii + 1; k < m; k++) sv -= A[ii * m + k] * x[k];
+          x[ii] = sv / A[ii * m + ii];
+        }
+        for (size_t a = 0; a < nh; a++) coef[a] = x[a];
+      } else
+        coef[nh - 1] = 1.0;
+    }
+    const bool convd = (diiserr < opt.convthr) && (fabs(dE) < opt.convthr);
+
+    t0 = wall();
+    for (int sp = 0; sp < nspin; sp++) {
+      double *Fd = d.T1.p;
+      for (size_t a = 0; a < nh; a++) d.axpby(coef[a], d.histF[slots[a]].p + sp * NN, a ? 1.0 : 0.0, Fd, NN);
+      eig_gsym_sub_dev(ctx, n, Fd, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), sp ? d.Eb.p : d.Ea.p,
+                       sp ? d.Cb.p : d.Ca.p);
+    }
+    if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
+    res.tdiag = wall() - t0;
+    if (verbose) {
+      printf("%s diagonalization done in %.6f\n", symm ? "Subspace" : "Full", res.tdiag);
+      fflush(stdout);
+    }
+    res.iterations = it;
+    if (convd) {
+      res.converged = true;
+      break;
+    }
+  }
+  // results the callers read back
+  res.E.resize(N);
+  HFG_HIP_CHECK(hipMemcpyAsync(res.E.data(), d.Ea.p, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+  res.C.zeros(N, N);
+  HFG_HIP_CHECK(hipMemcpyAsync(res.C.memptr(), d.Ca.p, sizeof(double) * NN, hipMemcpyDeviceToHost, s));
+  HFG_HIP_CHECK(hipStreamSynchronize(s));
+  if (verbose) {
+    printf("%-21s energy: % .16f\n", "Kinetic", res.Ekin);
+    printf("%-21s energy: % .16f\n", "Nuclear attraction", res.Epot);
+    printf("%-21s energy: % .16f\n", "Nuclear repulsion", res.Enucr);
+    printf("%-21s energy: % .16f\n", "Coulomb", res.Ecoul);
+    printf("%-21s energy: % .16f\n", "Exact exchange", res.Exx);
+    printf("%-21s energy: % .16f\n", "Exchange-correlation", res.Exc);
+    printf("%-21s energy: % .16f\n", "Total", res.Etot);
+    printf("%-21s energy: % .16f\n", "Virial ratio", -res.Etot / res.Ekin);
+  }
+  return res;
+}
+
+}  // namespace hfg

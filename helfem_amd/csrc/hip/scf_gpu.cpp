@@ -3,7 +3,9 @@
 #include "common.h"
 #include "../host/dftfuncs.h"
 #include "../host/scf.h"
+#include <cstdlib>
 #include <cstring>
+#include <string>
 
 namespace {
 using helfem::Mat;
@@ -91,6 +93,94 @@ struct GPUBackend : public helfem::scf::Backend {
 };
 }  // namespace
 
+namespace hfg {
+helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::scf::Options &opt, int nel, double Enucr,
+                                    int symm, const std::vector<std::vector<size_t> > &dsym, int ldft, int mdft);
+}
+
+namespace {
+bool host_driver() {
+  const char *e = getenv("HELFEM_SCF");
+  return e && std::string(e) == "host";
+}
+
+// set-up of src/diatomic/main.cpp:245-430 (basis, quadrature defaults, symmetry), then the device-resident loop
+helfem::scf::Result run_diatomic_device(hfg_ctx *ctx, const helfem::scf::Options &opt) {
+  int nel = opt.Z1 + opt.Z2;
+  int Nquad = opt.nquad;
+  if (Nquad == 0) Nquad = 5 * opt.nnodes;
+  else if (Nquad < 2 * opt.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
+  helfem::IVec lval, mval;
+  helfem::diatomic::lm_to_l_m(opt.lmmax, lval, mval);
+  const double Rhalf = 0.5 * opt.Rbond;
+  helfem::Vec bval = helfem::get_grid(helfem::arcosh(opt.Rmax / Rhalf), opt.nelem, opt.igrid, opt.zexp);
+  hfg_basis *hb = new hfg_basis();
+  helfem::scf::Result r;
+  try {
+    hb->kind = 0;
+    hb->b = helfem::diatomic::TwoDBasis(opt.Z1, opt.Z2, Rhalf, opt.nnodes, Nquad, bval, lval, mval, opt.lpad);
+    if (opt.verbose)
+      printf("Basis set consists of %i angular shells composed of %i radial functions, totaling %i basis functions\n",
+             (int)hb->b.Nang(), (int)hb->b.Nrad(), (int)hb->b.Nbf());
+    const bool dft = (opt.x_func > 0 || opt.c_func > 0);
+    int ldft = opt.ldft, mdft = opt.mdft;
+    if (dft) {
+      int lmaxmax = 0;
+      for (int l : opt.lmmax) lmaxmax = std::max(lmaxmax, l);
+      if (ldft == 0) ldft = 4 * lmaxmax + 12;
+      if (ldft < 2 * lmaxmax + 2) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
+      if (mdft == 0) mdft = 4 * (int)opt.lmmax.size() + 5;
+      if (mdft < 2 * (int)opt.lmmax.size()) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
+    } else
+      ldft = mdft = 0;
+    int symm = opt.symmetry;
+    if (symm == 2 && opt.Z1 != opt.Z2) symm = 1;
+    r = hfg::scf_device_loop(ctx, hb, opt, nel, opt.Z1 * opt.Z2 / opt.Rbond, symm, hb->b.get_sym_idx(symm), ldft, mdft);
+  } catch (...) {
+    hfg_basis_destroy(hb);
+    throw;
+  }
+  hfg_basis_destroy(hb);
+  return r;
+}
+
+helfem::scf::Result run_atomic_device(hfg_ctx *ctx, const helfem::scf::AtomicOptions &a) {
+  const helfem::scf::Options &opt = a.common;
+  int nel = a.Z - a.Q;
+  if (nel <= 0) throw std::logic_error("No electrons.\n");
+  int Nquad = opt.nquad;
+  if (Nquad == 0) Nquad = 5 * opt.nnodes;
+  else if (Nquad < 2 * opt.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
+  helfem::IVec lval, mval;
+  helfem::atomic::angular_basis(a.lmax, a.mmax, lval, mval);
+  helfem::Vec bval = helfem::get_grid(opt.Rmax, opt.nelem, opt.igrid, opt.zexp);
+  hfg_basis *hb = new hfg_basis();
+  helfem::scf::Result r;
+  try {
+    hb->kind = 1;
+    hb->ab = helfem::atomic::TwoDBasis(a.Z, opt.nnodes, Nquad, bval, lval, mval);
+    if (opt.verbose)
+      printf("Basis set consists of %i angular shells composed of %i radial functions, totaling %i basis functions\n",
+             (int)hb->ab.Nang(), (int)hb->ab.Nrad(), (int)hb->ab.Nbf());
+    const bool dft = (opt.x_func > 0 || opt.c_func > 0);
+    int ldft = opt.ldft, mdft = opt.mdft;
+    if (dft) {
+      if (ldft == 0) ldft = 4 * a.lmax + 10;
+      if (ldft < 2 * a.lmax) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
+      if (mdft == 0) mdft = 4 * a.mmax + 5;
+      if (mdft < 2 * a.mmax) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
+    } else
+      ldft = mdft = 0;
+    r = hfg::scf_device_loop(ctx, hb, opt, nel, 0.0, opt.symmetry, hb->ab.get_sym_idx(opt.symmetry), ldft, mdft);
+  } catch (...) {
+    hfg_basis_destroy(hb);
+    throw;
+  }
+  hfg_basis_destroy(hb);
+  return r;
+}
+}  // namespace
+
 extern "C" {
 
 /// Restricted closed-shell diatomic SCF on the GPU (driver loop of src/diatomic/main.cpp:780-995).
@@ -122,8 +212,12 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
     o.maxit = maxit;
     o.convthr = convthr;
     o.verbose = verbose != 0;
-    GPUBackend be(ctx);
-    helfem::scf::Result r = helfem::scf::run_diatomic(o, be);
+    helfem::scf::Result r;
+    if (host_driver()) {
+      GPUBackend be(ctx);
+      r = helfem::scf::run_diatomic(o, be);
+    } else
+      r = run_diatomic_device(ctx, o);
     out[0] = r.Etot;
     out[1] = r.Ekin;
     out[2] = r.Epot;
@@ -169,8 +263,12 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
     o.maxit = maxit;
     o.convthr = convthr;
     o.verbose = verbose != 0;
-    GPUBackend be(ctx);
-    helfem::scf::Result r = helfem::scf::run_atomic(a, be);
+    helfem::scf::Result r;
+    if (host_driver()) {
+      GPUBackend be(ctx);
+      r = helfem::scf::run_atomic(a, be);
+    } else
+      r = run_atomic_device(ctx, a);
     out[0] = r.Etot;
     out[1] = r.Ekin;
     out[2] = r.Epot;

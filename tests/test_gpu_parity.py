@@ -399,6 +399,25 @@ def test_scf_energy_parity(hf, name, kw, lit, littol):
         assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
 
 
+def test_scf_device_resident_driver_matches_host_pointer_driver(hf, monkeypatch):
+    """hfg_scf_* keeps every matrix in HBM (DIIS included); HELFEM_SCF=host runs the same loop through the
+    host-pointer entry points -- both must give the same energies and iteration counts"""
+    kw = dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[4, 3], nelem=3, nnodes=8, method="gga_x_pbe-gga_c_pbe")
+    dev = hf.scf_diatomic(convthr=1e-8, maxit=60, **kw)
+    monkeypatch.setenv("HELFEM_SCF", "host")
+    host = hf.scf_diatomic(convthr=1e-8, maxit=60, **kw)
+    assert dev["converged"] and host["converged"] and dev["iterations"] == host["iterations"]
+    for k in ("Etot", "Ekin", "Epot", "Ecoul", "Exc"):
+        assert abs(dev[k] - host[k]) < 1e-8 * max(1.0, abs(host[k])), (k, dev[k], host[k])
+    kw = dict(Z=7, lmax=1, mmax=1, nelem=4, nnodes=10, method="HF", M=4)
+    monkeypatch.delenv("HELFEM_SCF")
+    dev = hf.scf_atomic(convthr=1e-8, maxit=60, **kw)
+    monkeypatch.setenv("HELFEM_SCF", "host")
+    host = hf.scf_atomic(convthr=1e-8, maxit=60, **kw)
+    assert dev["converged"] and host["converged"]
+    assert abs(dev["Etot"] - host["Etot"]) < 1e-8 and abs(dev["Exx"] - host["Exx"]) < 1e-7
+
+
 # ---------------------------------------------------------------------------------------------------
 # divide-and-conquer tridiagonal stage: hard spectra (through eig_sym on tridiagonal input)
 # ---------------------------------------------------------------------------------------------------
