@@ -138,6 +138,12 @@ def main():
     dt = parallel.max_over_ranks(dt, device=step.dev if world > 1 else "cpu")
     ms_per_step = dt / args.steps * 1e3
 
+    fams = {}
+    for name in ("coulomb", "xc", "scatter", "eig_reduce", "eig_tridiag", "eig_tridiag_solve", "eig_backtransform",
+                 "gemm", "density"):
+        ms, n = ctx.profile_get(name)
+        fams[name] = dict(ms_per_step=ms / args.steps, calls=n)
+    ctx.profile(False)
     # self-check of the timed path, independent of the number of ranks: ONE step from the fixed guess density
     # (the undamped iteration itself is chaotic from a core guess, its later iterates are not comparable)
     step.set_density(P0)
@@ -147,12 +153,6 @@ def main():
              "sum_all_eigenvalues_after_one_step": float(step.E.sum().item()),
              "xc_energy_after_one_step": float(step.scal[0].item())}
 
-    fams = {}
-    for name in ("coulomb", "xc", "scatter", "eig_reduce", "eig_tridiag", "eig_tridiag_solve", "eig_backtransform",
-                 "gemm", "density"):
-        ms, n = ctx.profile_get(name)
-        fams[name] = dict(ms_per_step=ms / args.steps, calls=n)
-    ctx.profile(False)
     # dominant kernel, measured live: all its launches of one eigensolve replayed back to back between two HIP
     # events on the launch stream (3 repetitions, the last is kept)
     for _ in range(3):
