@@ -33,7 +33,7 @@ def test_gemm_large_tile_path(hf):
     assert np.max(np.abs(C - A @ B)) < 1e-11
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 130, 400])
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 130, 257, 333, 400, 1025])
 def test_eig_sym_vs_lapack(hf, n):
     rng = np.random.RandomState(n)
     A = rng.uniform(-1, 1, size=(n, n))
@@ -200,6 +200,55 @@ def test_form_density_parity(case, hf):
     C = rng.uniform(-1, 1, size=(gb.Nbf(), 9))
     assert np.max(np.abs(hf.scf.form_density(C, 4) - orc.form_density(C, 4))) < 1e-13
     assert np.max(np.abs(hf.scf.form_density(C, 0))) == 0.0
+
+
+def test_edge_case_bases(hf):
+    """smallest shapes the reference accepts: one radial element, one angular shell, sigma-only with lmax 0"""
+    import common
+    for kw in (dict(Z1=1, Z2=1, Rbond=1.4, lmmax=(0,), nelem=1, nnodes=4),
+               dict(Z1=2, Z2=1, Rbond=1.5, lmmax=(2, 0), nelem=1, nnodes=5),
+               dict(Z1=1, Z2=1, Rbond=1.4, lmmax=(1,), nelem=4, nnodes=3)):
+        gb, ob = common.make_bases(**kw)
+        gb.compute_tei(True)
+        ob.compute_tei(True)
+        lmax = max(kw["lmmax"])
+        ldft, mdft = 4 * lmax + 12, 4 * len(kw["lmmax"]) + 5
+        gb.upload(ldft, mdft)
+        P = common.random_density(gb.Nbf(), 1, seed=7, blocks=gb.get_sym_idx(1))
+        assert common.relerr(gb.coulomb(P), ob.coulomb(P)) < 1e-12, kw
+        assert common.relerr(gb.exchange(P), ob.exchange(P)) < 1e-12, kw
+        H, Exc, Nel, _ = hf.DFTGrid(gb, ldft, mdft).eval_Fxc(101, 130, P)
+        Ho, Exco, Nelo, _ = ob.eval_Fxc(ldft, mdft, 101, 130, P)
+        assert common.relerr(H, Ho) < 1e-10 and abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco)), kw
+
+
+def test_eig_gsym_sub_many_small_and_odd_blocks(hf):
+    """ragged symmetry blocks (sizes 1, 2, odd, > 8 blocks is rejected loudly by the batch) through eig_gsym_sub"""
+    import oracle_lib as orc
+    rng = np.random.RandomState(3)
+    sizes = [1, 2, 7, 33, 129, 5]
+    N = sum(sizes)
+    perm = rng.permutation(N)
+    blocks, o = [], 0
+    for sz in sizes:
+        blocks.append(np.sort(perm[o:o + sz]))
+        o += sz
+    F = rng.uniform(-1, 1, (N, N))
+    F = F + F.T
+    A = rng.uniform(-1, 1, (N, N))
+    S = A @ A.T + N * np.eye(N)
+    for i, bi in enumerate(blocks):
+        for j, bj in enumerate(blocks):
+            if i != j:
+                S[np.ix_(bi, bj)] = 0.0
+                F[np.ix_(bi, bj)] = 0.0
+    X = hf.scf.form_Sinvh(S, False, blocks)
+    assert np.max(np.abs(X - orc.form_Sinvh(S, False, blocks))) < 1e-10
+    E, C = hf.scf.eig_gsym_sub(F, X, blocks)
+    Eo, _ = orc.eig_gsym_sub(F, X, blocks)
+    assert np.max(np.abs(E - Eo)) < 1e-10
+    assert np.max(np.abs(C.T @ S @ C - np.eye(N))) < 1e-10
+    assert np.max(np.abs(F @ C - S @ C * E)) < 1e-9
 
 
 # ---------------------------------------------------------------------------------------------------
