@@ -115,9 +115,9 @@ __host__ __device__ inline Dual eps_gga_c_pbe(Dual rho, Dual sigma) {
   return ec + H;
 }
 
-__host__ __device__ inline bool is_gga(int id) { return id == 101 || id == 130; }
+__host__ __device__ inline bool is_gga(int id) { return id == 101 || id == 130 || id == 406; }
 __host__ __device__ inline bool is_supported(int id) {
-  return id == 1 || id == 7 || id == 12 || id == 101 || id == 130;
+  return id == 1 || id == 7 || id == 12 || id == 101 || id == 130 || id == 406;
 }
 
 /// adds functional id's exc (per particle), vrho, vsigma at one point; rho >= threshold assumed
@@ -130,6 +130,7 @@ __host__ __device__ inline void eval_add(int id, double rho, double sigma, doubl
     case 12: e = eps_lda_c_pw(r); break;
     case 101: e = eps_gga_x_pbe(r, s); break;
     case 130: e = eps_gga_c_pbe(r, s); break;
+    case 406: e = 0.75 * eps_gga_x_pbe(r, s) + eps_gga_c_pbe(r, s); break;  // hyb_gga_xc_pbeh (PBE0), DFT part
     default: return;
   }
   Dual en = r * e;  // energy per volume
@@ -250,6 +251,18 @@ __host__ __device__ inline T3 pol_eps_pbe_c(T3 n, T3 rs, T3 z, T3 sig) {
 __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, double saa, double sab, double sbb, double &exc,
                                              double &va, double &vb, double &vsaa, double &vsab, double &vsbb) {
   const double rt = ra + rb;
+  if (id == 406) {  // hyb_gga_xc_pbeh (PBE0), DFT part: 0.75 gga_x_pbe + gga_c_pbe
+    double e = 0.0, a = 0.0, b = 0.0, saa2 = 0.0, sab2 = 0.0, sbb2 = 0.0;
+    eval_add_pol(101, ra, rb, saa, sab, sbb, e, a, b, saa2, sab2, sbb2);
+    exc += 0.75 * e;
+    va += 0.75 * a;
+    vb += 0.75 * b;
+    vsaa += 0.75 * saa2;
+    vsab += 0.75 * sab2;
+    vsbb += 0.75 * sbb2;
+    eval_add_pol(130, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+    return;
+  }
   if (id == 1 || id == 101) {
     Dual a = mk(2.0 * ra, 1.0, 0.0), b = mk(2.0 * rb, 1.0, 0.0);
     Dual sa = mk(4.0 * saa, 0.0, 1.0), sb = mk(4.0 * sbb, 0.0, 1.0);

@@ -12,7 +12,8 @@ struct Known {
   const char *name;
   int id;
 };
-const Known known[] = {{"lda_x", 1}, {"lda_c_vwn", 7}, {"lda_c_pw", 12}, {"gga_x_pbe", 101}, {"gga_c_pbe", 130}};
+const Known known[] = {{"lda_x", 1}, {"lda_c_vwn", 7}, {"lda_c_pw", 12}, {"gga_x_pbe", 101}, {"gga_c_pbe", 130},
+                       {"hyb_gga_xc_pbeh", 406}};  // PBE0: 0.75 gga_x_pbe + gga_c_pbe + 0.25 exact exchange
 
 int find_func(const std::string &name) {
   if (name.empty()) throw std::runtime_error("empty functional name\n");
@@ -38,7 +39,8 @@ void parse_xc_func(int &x_func, int &c_func, const std::string &xc) {
     x_func = find_func(xc);
 }
 
-double exact_exchange(int x_func) { return x_func == -1 ? 1.0 : 0.0; }
+// fraction of exact exchange (libxc xc_hyb_exx_coef; dftfuncs.cpp:134-160 of the reference)
+double exact_exchange(int x_func) { return x_func == -1 ? 1.0 : (x_func == 406 ? 0.25 : 0.0); }
 
 const char *xc_func_name(int id) {
   if (id == -1) return "HF";

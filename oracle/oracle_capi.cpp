@@ -244,7 +244,7 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
   o.lpad = lpad;
   o.method = method;
   parse_xc_func(o.x_func, o.c_func, o.method);
-  o.kfrac = (o.x_func == -1) ? 1.0 : 0.0;
+  o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
   o.ldft = ldft;
   o.mdft = mdft;
   o.symmetry = symmetry;
@@ -398,7 +398,7 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
   o.zexp = zexp;
   o.method = method;
   parse_xc_func(o.x_func, o.c_func, o.method);
-  o.kfrac = (o.x_func == -1) ? 1.0 : 0.0;
+  o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
   o.ldft = ldft;
   o.mdft = mdft;
   o.symmetry = symmetry;

@@ -109,7 +109,7 @@ void gga_c_pbe(double rho, double sigma, double &exc, double &vrho, double &vsig
 }
 }  // namespace
 
-bool xc_is_gga(int id) { return id == 101 || id == 130; }
+bool xc_is_gga(int id) { return id == 101 || id == 130 || id == 406; }
 
 void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
                     double *vsigma, double thr) {
@@ -126,6 +126,15 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
       case 12: lda_c_pw(r, e, v); break;
       case 101: gga_x_pbe(r, sigma[i], e, v, vs); break;
       case 130: gga_c_pbe(r, sigma[i], e, v, vs); break;
+      case 406: {  // hyb_gga_xc_pbeh (PBE0), DFT part
+        double e2, v2, vs2;
+        gga_x_pbe(r, sigma[i], e, v, vs);
+        gga_c_pbe(r, sigma[i], e2, v2, vs2);
+        e = 0.75 * e + e2;
+        v = 0.75 * v + v2;
+        vs = 0.75 * vs + vs2;
+        break;
+      }
       default: {
         std::ostringstream oss;
         oss << "Functional " << id << " not found!";
@@ -236,6 +245,15 @@ D3 eps_pbe_c(D3 rho, D3 rs, D3 z, D3 sig) {
 
 void xc_polarized(int id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho, double *vsigma,
                   double thr) {
+  if (id == 406) {  // hyb_gga_xc_pbeh (PBE0), DFT part: 0.75 gga_x_pbe + gga_c_pbe
+    Vec e(N), v(2 * N), vs(3 * N);
+    xc_polarized(101, N, rho, sigma, exc, vrho, vsigma, thr);
+    xc_polarized(130, N, rho, sigma, e.data(), v.data(), vs.data(), thr);
+    for (size_t i = 0; i < N; i++) exc[i] = 0.75 * exc[i] + e[i];
+    for (size_t i = 0; i < 2 * N; i++) vrho[i] = 0.75 * vrho[i] + v[i];
+    for (size_t i = 0; i < 3 * N; i++) vsigma[i] = 0.75 * vsigma[i] + vs[i];
+    return;
+  }
   for (size_t i = 0; i < N; i++) {
     exc[i] = 0.0;
     vrho[2 * i] = vrho[2 * i + 1] = 0.0;
@@ -309,6 +327,7 @@ static int find_func(const std::string &name) {
   if (!strcasecmp(name.c_str(), "lda_c_pw")) return 12;
   if (!strcasecmp(name.c_str(), "gga_x_pbe")) return 101;
   if (!strcasecmp(name.c_str(), "gga_c_pbe")) return 130;
+  if (!strcasecmp(name.c_str(), "hyb_gga_xc_pbeh")) return 406;
   std::ostringstream oss;
   oss << "\nError: functional " << name << " is not available in this build!\n";
   throw std::runtime_error(oss.str());

@@ -379,6 +379,7 @@ ATOMIC_LITERATURE = [
     ("Ne_HF", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="HF"), -128.54709811, 1e-7),
     ("He_LDA", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -2.834836, 1e-6),
     ("Ne_LDA", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -128.233481, 1e-6),
+    ("He_PBE0", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh"), -2.895178, 2e-6),
 ]
 
 

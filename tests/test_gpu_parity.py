@@ -146,7 +146,7 @@ def test_exchange_shards_sum_to_full(case, hf, nranks):
     assert common.relerr(acc, full) < 1e-12, name
 
 
-@pytest.mark.parametrize("funcs", [(1, 7), (1, 0), (101, 130), (101, 0), (0, 130), (1, 12)])
+@pytest.mark.parametrize("funcs", [(1, 7), (1, 0), (101, 130), (101, 0), (0, 130), (1, 12), (406, 0)])
 def test_xc_parity(case, hf, funcs):
     import common
     name, gb, ob, ldft, mdft = case
@@ -327,7 +327,7 @@ def _spin_densities(gb):
     return Pa, Pb
 
 
-@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (1, 12), (101, 0), (0, 130)])
+@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (1, 12), (101, 0), (0, 130), (406, 0)])
 def test_xc_polarized_parity(case, hf, funcs):
     import common
     name, gb, ob, ldft, mdft = case
@@ -381,6 +381,7 @@ OPEN_SHELL_CASES = [
     ("H_PBE", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="gga_x_pbe-gga_c_pbe", M=2), -0.499990, 2e-6),
     ("Li_UHF", "atomic", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=2), -7.432751, 2e-6),
     ("N_LSD", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=12, method="lda_x-lda_c_vwn", M=4), -54.136799, 5e-6),
+    ("H_PBE0", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh", M=2), None, None),
     ("H2+_like_HeH2+", "diatomic", dict(Z1=1, Z2=1, Rbond=2.0, lmmax=[6], nelem=3, nnodes=10, method="HF", M=3), None, None),
     ("OH_like_LiH+_PBE", "diatomic", dict(Z1=3, Z2=0, Rbond=3.0, lmmax=[4, 2], nelem=3, nnodes=8,
                                           method="gga_x_pbe-gga_c_pbe", M=2), None, None),
@@ -409,6 +410,8 @@ ATOMIC_SCF_CASES = [
     ("Be_HF", dict(Z=4, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF"), -14.573023168, 1e-7),
     ("Ne_HF", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="HF"), -128.54709811, 1e-7),
     ("Ne_LDA", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -128.233481, 2e-6),
+    # global hybrid: J + 0.25 K + XC in one Fock build (hyb_gga_xc_pbeh = PBE0)
+    ("He_PBE0", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh"), -2.895178, 2e-6),
 ]
 
 
@@ -428,6 +431,7 @@ def test_atomic_scf_energy_parity(hf, name, kw, lit, littol):
 # end-to-end SCF: converged total energies, GPU vs oracle on identical grids (north-star bar: 1e-8 Eh)
 # ---------------------------------------------------------------------------------------------------
 SCF_CASES = [
+    ("N2_PBE0_small", dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[4, 3], nelem=3, nnodes=8, method="hyb_gga_xc_pbeh"), None, None),
     # BASELINE config 3: diatomic H2 at R=1.4, HF, small (mu,nu) grid
     ("H2_HF", dict(Z1=1, Z2=1, Rbond=1.4, lmmax=[6], nelem=3, nnodes=10, method="HF"), -1.13362957, 2e-7),
     ("H2_LDA", dict(Z1=1, Z2=1, Rbond=1.4, lmmax=[4], nelem=2, nnodes=8, method="lda_x-lda_c_vwn"), None, None),
