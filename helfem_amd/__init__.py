@@ -253,8 +253,15 @@ class TwoDBasis(object):
                                           idx.ctypes.data_as(c_i64_p)))
         return [idx[ptr[i]:ptr[i + 1]].copy() for i in range(n.value)]
 
-    def compute_tei(self, exchange=True):
-        _check(lib().hfg_compute_tei(self.h, 1 if exchange else 0))
+    def compute_tei(self, exchange=True, device=False, ctx=None):
+        """TwoDBasis::compute_tei.  device=True builds the in-element tables on the GPU (hfg_compute_tei_dev): the
+        1 GB of primitive integrals at Nbf~4000 then never exists on the host"""
+        if device:
+            ctx = ctx or self.ctx or default_context()
+            self.ctx = ctx
+            _check(lib().hfg_compute_tei_dev(ctx.h, self.h, 1 if exchange else 0))
+        else:
+            _check(lib().hfg_compute_tei(self.h, 1 if exchange else 0))
         self._uploaded = None
 
     def upload(self, ldft=0, mdft=0, ctx=None):

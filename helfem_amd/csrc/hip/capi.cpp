@@ -24,6 +24,7 @@ void fock_finish_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dFc, const do
                      double *dF);
 void exchange_release(hfg_dev_tables *t);
 void exchange_lr_release(hfg_dev_tables *t);
+void compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis);
 void eig_release(hfg_ctx *ctx);
 void dc_release(hfg_ctx *ctx);
 void trd_release(hfg_ctx *ctx);
@@ -297,6 +298,14 @@ int hfg_compute_tei(hfg_basis *b, int exchange) {
   HFG_TRY
   if (b->kind) b->ab.compute_tei(exchange != 0);
   else b->b.compute_tei(exchange != 0);
+  HFG_CATCH
+}
+
+int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *b, int exchange) {
+  HFG_TRY
+  (void)exchange;  // the exchange-ordered copies are made on the device when the exchange kernels first need them
+  if (b->kind == 0) compute_tei_dev(ctx, b);
+  else b->ab.compute_tei(exchange != 0);  // the atomic tables are small: host
   HFG_CATCH
 }
 

@@ -88,6 +88,9 @@ struct hfg_basis {
   helfem::atomic::TwoDBasis ab;
   hfg_dev_tables *dev = nullptr;
   int dev_device = -1;
+  // primitive in-element integral tables built on the device (hip/tei_dev.hip) instead of host Mats
+  hfg::DevBuf<double> dev_tei;
+  bool tei_on_device = false;
 
   size_t Nbf() const { return kind ? ab.Nbf() : b.Nbf(); }
   size_t Ndummy() const { return kind ? ab.Nbf() : b.Ndummy(); }
@@ -95,7 +98,7 @@ struct hfg_basis {
   size_t Nang() const { return kind ? ab.Nang() : b.Nang(); }
   size_t Nel() const { return kind ? ab.Nel() : b.Nel(); }
   size_t max_Nprim() const { return kind ? ab.max_Nprim() : b.max_Nprim(); }
-  bool have_tei() const { return kind ? ab.have_tei : b.have_tei; }
+  bool have_tei() const { return tei_on_device || (kind ? ab.have_tei : b.have_tei); }
 };
 
 namespace hfg {

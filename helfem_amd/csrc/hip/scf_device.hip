@@ -29,6 +29,7 @@ void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                       const int64_t *blk_idx, double *dE, double *dC);
 void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
+void compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis);
 void fock_release(hfg_dev_tables *t);
 void exchange_release(hfg_dev_tables *t);
 void exchange_lr_release(hfg_dev_tables *t);
@@ -217,7 +218,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   if (verbose) printf("Computing two-electron integrals\n");
   t0 = wall();
   if (hb->kind) hb->ab.compute_tei(opt.kfrac != 0.0);
-  else hb->b.compute_tei(opt.kfrac != 0.0);
+  else compute_tei_dev(ctx, hb);  // in-element tables on the device (tei_dev.hip)
   if (hb->dev) {
     fock_release(hb->dev);
     exchange_release(hb->dev);

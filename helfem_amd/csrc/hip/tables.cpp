@@ -290,7 +290,14 @@ void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft) {
     const size_t pp = (size_t)p * p;
     const size_t blk = pp * pp;
     t->tei.resize((size_t)b.ntt * Ntab * E * blk);
+    if (basis->tei_on_device) {
+      if (basis->dev_tei.n < (size_t)b.ntt * Ntab * E * blk) throw std::logic_error("device tei buffer has the wrong size");
+      HFG_HIP_CHECK(hipMemcpyAsync(t->tei.p, basis->dev_tei.p, sizeof(double) * (size_t)b.ntt * Ntab * E * blk,
+                                   hipMemcpyDeviceToDevice, s));
+      HFG_HIP_CHECK(hipStreamSynchronize(s));
+    }
     std::vector<double> stage(blk);
+    if (!basis->tei_on_device)
     for (int tt = 0; tt < b.ntt; tt++)
       for (int tab = 0; tab < Ntab; tab++)
         for (int e = 0; e < E; e++) {

@@ -304,6 +304,123 @@ namespace {
 inline double clean(double v) { return std::isnormal(v) ? v : 0.0; }  // legendretable.cpp:83-89
 }
 
+void TwoDBasis::tei_element_tables(size_t iel, TeiElementTables &t) const {
+  const size_t nq = xq.size(), Nlm = lm_map.size();
+  const int ld = Lmax + 1;
+  const legendre_provider_t provider = get_legendre_provider();
+  const int Lm = Lmax, Mm = Mmax, lp = lpad;
+  auto legPQ = [provider, Lm, Mm, lp](double xi, double *P, double *Q) {
+    if (provider)
+      provider(Lm, Mm, lp, xi, P, Q);
+    else
+      legendre_PQ(Lm, Mm, xi, P, Q);
+  };
+  const double mumin0 = fem.element_begin(iel), mumax0 = fem.element_end(iel);
+  const double mumid0 = 0.5 * (mumax0 + mumin0), mulen0 = 0.5 * (mumax0 - mumin0);
+  LIPBasis poly = fem.get_basis(iel);
+  const size_t Ni = poly.nbf(), Np = Ni * Ni;
+  t.Ni = Ni;
+  t.Np = Np;
+  t.nq = nq;
+  t.Nlm = Nlm;
+  t.bb0.zeros(Np, nq);
+  t.bbs.zeros(Np, nq * nq);
+  t.wQ.assign(2 * Nlm * nq, 0.0);
+  t.wP.assign(2 * Nlm * nq * nq, 0.0);
+  Vec mu0(nq);
+  for (size_t q = 0; q < nq; q++) mu0[q] = mumid0 + mulen0 * xq[q];
+  Mat bf0 = poly.eval_dnf(xq, 0, mulen0);
+  const size_t tab = (size_t)ld * (Mmax + 1);
+  parallel_for(nq, [&](size_t isub) {
+    double mumin = (isub == 0) ? mumin0 : mu0[isub - 1];
+    double mumax = mu0[isub];
+    double mumid = 0.5 * (mumax + mumin), mulen = 0.5 * (mumax - mumin);
+    Vec xpoly(nq);
+    std::vector<double> Pt(tab), Qt(tab);
+    for (size_t q = 0; q < nq; q++) {
+      double mu = mumid + mulen * xq[q];
+      double ch = std::cosh(mu);
+      size_t s = isub * nq + q;
+      double w = wq[q] * mulen * std::sinh(mu);
+      xpoly[q] = (mu - mumid0) / mulen0;
+      legPQ(ch, Pt.data(), Qt.data());
+      for (size_t ilm = 0; ilm < Nlm; ilm++) {
+        double pl = clean(Pt[(size_t)lm_map[ilm].second * ld + lm_map[ilm].first]);
+        t.wP[(0 * Nlm + ilm) * nq * nq + s] = w * pl;
+        t.wP[(1 * Nlm + ilm) * nq * nq + s] = w * pl * ch * ch;
+      }
+    }
+    Mat bf = poly.eval_dnf(xpoly, 0, mulen0);
+    for (size_t q = 0; q < nq; q++)
+      for (size_t j = 0; j < Ni; j++)
+        for (size_t i = 0; i < Ni; i++) t.bbs(j * Ni + i, isub * nq + q) = bf(q, i) * bf(q, j);
+  }, provider ? 1 : 0);
+  std::vector<double> Pt(tab), Qt(tab);
+  for (size_t q = 0; q < nq; q++) {
+    double ch = std::cosh(mu0[q]);
+    double w = wq[q] * mulen0 * std::sinh(mu0[q]);
+    legPQ(ch, Pt.data(), Qt.data());
+    for (size_t ilm = 0; ilm < Nlm; ilm++) {
+      double ql = clean(Qt[(size_t)lm_map[ilm].second * ld + lm_map[ilm].first]);
+      t.wQ[(0 * Nlm + ilm) * nq + q] = w * ql;
+      t.wQ[(1 * Nlm + ilm) * nq + q] = w * ql * ch * ch;
+    }
+    for (size_t j = 0; j < Ni; j++)
+      for (size_t i = 0; i < Ni; i++) t.bb0(j * Ni + i, q) = bf0(q, i) * bf0(q, j);
+  }
+}
+
+void TwoDBasis::compute_disjoint() {
+  const size_t Ne = Nel(), Nlm = lm_map.size(), nq = xq.size();
+  const int ld = Lmax + 1;
+  const legendre_provider_t provider = get_legendre_provider();
+  const int Lm = Lmax, Mm = Mmax, lp = lpad;
+  disjoint_P0.assign(Ne * Nlm, Mat());
+  disjoint_P2.assign(Ne * Nlm, Mat());
+  disjoint_Q0.assign(Ne * Nlm, Mat());
+  disjoint_Q2.assign(Ne * Nlm, Mat());
+  const size_t tab = (size_t)ld * (Mmax + 1);
+  for (size_t iel = 0; iel < Ne; iel++) {
+    const double mumin0 = fem.element_begin(iel), mumax0 = fem.element_end(iel);
+    const double mumid0 = 0.5 * (mumax0 + mumin0), mulen0 = 0.5 * (mumax0 - mumin0);
+    LIPBasis poly = fem.get_basis(iel);
+    const size_t Ni = poly.nbf(), Np = Ni * Ni;
+    Mat bf0 = poly.eval_dnf(xq, 0, mulen0);
+    std::vector<double> Pm(nq * tab), Qm(nq * tab);
+    Vec wmain(nq), chmain(nq);
+    Mat bb0(Np, nq);
+    for (size_t q = 0; q < nq; q++) {
+      double mu = mumid0 + mulen0 * xq[q];
+      chmain[q] = std::cosh(mu);
+      wmain[q] = wq[q] * mulen0 * std::sinh(mu);
+      if (provider) provider(Lm, Mm, lp, chmain[q], &Pm[q * tab], &Qm[q * tab]);
+      else legendre_PQ(Lm, Mm, chmain[q], &Pm[q * tab], &Qm[q * tab]);
+      for (size_t j = 0; j < Ni; j++)
+        for (size_t i = 0; i < Ni; i++) bb0(j * Ni + i, q) = bf0(q, i) * bf0(q, j);
+    }
+    for (size_t ilm = 0; ilm < Nlm; ilm++) {
+      const size_t off = (size_t)lm_map[ilm].second * ld + lm_map[ilm].first;
+      Mat P0(Ni, Ni), P2(Ni, Ni), Q0(Ni, Ni), Q2(Ni, Ni);
+      for (size_t q = 0; q < nq; q++) {
+        double pl = clean(Pm[q * tab + off]), ql = clean(Qm[q * tab + off]);
+        double c2 = chmain[q] * chmain[q], w = wmain[q];
+        const double *b = &bb0.d[q * Np];
+        for (size_t k = 0; k < Np; k++) {
+          P0.d[k] += w * pl * b[k];
+          P2.d[k] += w * pl * c2 * b[k];
+          Q0.d[k] += w * ql * b[k];
+          Q2.d[k] += w * ql * c2 * b[k];
+        }
+      }
+      disjoint_P0[ilm * Ne + iel] = P0;
+      disjoint_P2[ilm * Ne + iel] = P2;
+      disjoint_Q0[ilm * Ne + iel] = Q0;
+      disjoint_Q2[ilm * Ne + iel] = Q2;
+    }
+  }
+  have_disjoint = true;
+}
+
 void TwoDBasis::compute_tei(bool exchange) {
   const size_t Ne = Nel();
   const size_t Nlm = lm_map.size();
@@ -447,6 +564,7 @@ void TwoDBasis::compute_tei(bool exchange) {
     });
   }
   have_tei = true;
+  have_disjoint = true;
 
   if (exchange) {
     prim_ktei00.assign(Ne * Nlm, Mat());

@@ -73,6 +73,21 @@ struct TwoDBasis {
   /// fill the disjoint_* and prim_tei* tables (basis.cpp:1166); exchange also fills prim_ktei*
   void compute_tei(bool exchange);
 
+  /// Per-element tables of compute_tei in a device-friendly form: everything the in-element integrals need that is
+  /// cheap on the host (quadrature points, LIP products, Legendre values); the O(Nlm nq p^4) sums are then done on
+  /// the GPU (hip/tei_dev.hip).  Arrays over points are contiguous per (L,|M|) channel.
+  struct TeiElementTables {
+    size_t Ni = 0, Np = 0, nq = 0, Nlm = 0;
+    Mat bb0;                 // Np x nq      products B_i B_j at the main points
+    Mat bbs;                 // Np x nq^2    products at the sub-interval points (point s = isub*nq + q)
+    std::vector<double> wQ;  // [2][Nlm][nq]    w_q sinh cosh^{2k} Q_L^M at the main points, k = 0,1
+    std::vector<double> wP;  // [2][Nlm][nq^2]  w_s sinh cosh^{2l} P_L^M at the sub-interval points, l = 0,1
+  };
+  void tei_element_tables(size_t iel, TeiElementTables &t) const;
+  /// the disjoint (cross-element) integrals only (the cheap part of compute_tei)
+  void compute_disjoint();
+  bool have_disjoint = false;
+
   /// radial functions / derivatives / weights / mu at the quadrature points of element iel
   Mat get_bf(size_t iel) const { return fem.eval_dnf(xq, 0, iel); }
   Mat get_df(size_t iel) const { return fem.eval_dnf(xq, 1, iel); }

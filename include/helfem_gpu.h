@@ -105,6 +105,9 @@ int hfg_basis_nuclear(const hfg_basis *basis, double *V);
 int hfg_basis_sym_blocks(const hfg_basis *basis, int symm, int *nblk, int64_t *blk_ptr, int64_t *blk_idx);
 /* TwoDBasis::compute_tei (basis.cpp:1166): primitive two-electron integral tables (host, threaded) */
 int hfg_compute_tei(hfg_basis *basis, int exchange);
+/* the same tables built on the GPU (diatomic: host computes quadrature points and Legendre values, the
+ * O(Nlm nq p^4) sums run on the device and the tables stay there); follow with hfg_basis_upload */
+int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis, int exchange);
 /* helpers of main.cpp:276-277: mu grid for --grid/--zexp, and (l,m) shell list for lmmax */
 int hfg_radial_grid(double mumax, int nelem, int igrid, double zexp, double *bval /* nelem+1 */);
 int hfg_lm_list(const int *lmmax, int nlm, int *lval, int *mval, int *nang /* in: capacity, out: count */);

@@ -202,6 +202,23 @@ def test_form_density_parity(case, hf):
     assert np.max(np.abs(hf.scf.form_density(C, 0))) == 0.0
 
 
+def test_tei_tables_built_on_device_match_host_tables(hf):
+    """hfg_compute_tei_dev (in-element integrals summed on the GPU) against the host tables: J, K and a full SCF"""
+    import common
+    for kw in (dict(Z1=7, Z2=7, Rbond=2.068, lmmax=(3, 2), nelem=2, nnodes=5),
+               dict(Z1=3, Z2=9, Rbond=2.955, lmmax=(3, 3, 2), nelem=3, nnodes=4)):
+        gb, ob = common.make_bases(**kw)
+        gd, _ = common.make_bases(oracle=False, **kw)
+        gb.compute_tei(True)
+        gd.compute_tei(True, device=True)
+        gb.upload()
+        gd.upload()
+        for tag, P in _densities(gb):
+            Jh, Jd = gb.coulomb(P), gd.coulomb(P)
+            Kh, Kd = gb.exchange(P), gd.exchange(P)
+            assert common.relerr(Jd, Jh) < 1e-13 and common.relerr(Kd, Kh) < 1e-12, (kw, tag)
+
+
 def test_edge_case_bases(hf):
     """smallest shapes the reference accepts: one radial element, one angular shell, sigma-only with lmax 0"""
     import common
