@@ -155,8 +155,11 @@ def main():
 
     # dominant kernel, measured live: all its launches of one eigensolve replayed back to back between two HIP
     # events on the launch stream (3 repetitions, the last is kept)
-    for _ in range(3):
-        ctx_gemv = ctx.measure_kernel(TRD_KERNEL)
+    # (rank 0 only: it always owns symmetry block 0; ranks beyond the number of blocks never ran the factorisation)
+    ctx_gemv = (0.0, 0)
+    if rank == 0:
+        for _ in range(3):
+            ctx_gemv = ctx.measure_kernel(TRD_KERNEL)
 
     if rank == 0:
         sizes = [len(b) for b in blocks]
