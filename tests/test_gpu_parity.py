@@ -219,6 +219,22 @@ def test_tei_tables_built_on_device_match_host_tables(hf):
             assert common.relerr(Jd, Jh) < 1e-13 and common.relerr(Kd, Kh) < 1e-12, (kw, tag)
 
 
+@pytest.mark.parametrize("env", [dict(HELFEM_TRD="twokernel"), dict(HELFEM_BT="column"),
+                                 dict(HELFEM_TRD="unblocked", HELFEM_BT="column")],
+                         ids=["two_launches_per_column", "column_backtransform", "unblocked_tridiagonalisation"])
+def test_fallback_variants(native_libs, env):
+    """the earlier kernel variants stay selectable (environment, read once per process) and stay correct"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "fallback_worker.py")], env=e, cwd=root, timeout=300,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert out.returncode == 0 and b"ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_edge_case_bases(hf):
     """smallest shapes the reference accepts: one radial element, one angular shell, sigma-only with lmax 0"""
     import common
