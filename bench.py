@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="n2_pbe_nbf4230")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--symmetry", type=int, default=1, help="0: one unsymmetrised eigenproblem; 1 (reference default): m blocks")
     args = ap.parse_args()
 
     import torch
@@ -102,7 +103,7 @@ def main():
     # one rank per GPU; HELFEM_BENCH_DEVICE pins every rank to one device (rehearsal of the N>1 path on a 1-GPU box
     # together with HELFEM_DIST_BACKEND=gloo)
     dev_index = int(os.environ.get("HELFEM_BENCH_DEVICE", local_rank))
-    step = hf.DeviceSCFStep(basis, w["x"], w["c"], ldft, mdft, w["nocc"], symmetry=1, device=dev_index, rank=rank,
+    step = hf.DeviceSCFStep(basis, w["x"], w["c"], ldft, mdft, w["nocc"], symmetry=args.symmetry, device=dev_index, rank=rank,
                             nranks=world)
     ctx = step.ctx
     S = basis.overlap()

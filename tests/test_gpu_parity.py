@@ -543,6 +543,19 @@ def test_eig_sym_hard_spectra(hf, name, A):
     assert np.max(np.abs(A @ C - C * E)) < 1e-12 * scale * max(np.sqrt(n), 10), name
 
 
+def test_eig_sym_2305_more_than_twelve_slabs(hf):
+    """n > 1536: the sweep's partial-slab sums leave their unrolled part (rolled tail loops), 19 x 19 tiles"""
+    rng = np.random.RandomState(8)
+    n = 2305
+    A = rng.uniform(-1, 1, (n, n))
+    A = A + A.T
+    E, C = hf.scf.eig_sym(A)
+    Eref = np.linalg.eigvalsh(A)
+    assert np.max(np.abs(E - Eref)) < 1e-10 * n
+    assert np.max(np.abs(C.T @ C - np.eye(n))) < 1e-10
+    assert np.max(np.abs(A @ C - C * E)) < 1e-9 * n
+
+
 def test_eig_sym_1400_dense(hf):
     rng = np.random.RandomState(7)
     n = 1400
