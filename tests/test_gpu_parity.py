@@ -235,6 +235,35 @@ def test_fallback_variants(native_libs, env):
     assert out.returncode == 0 and b"ok" in out.stdout, out.stdout.decode()[-2000:]
 
 
+def test_form_sinvh_cholesky_variant(case, hf):
+    """TwoDBasis::Sinvh(chol=true) -> utils::invh: Sinvh = D inv(chol(D S D)) per symmetry block (--diag 0)"""
+    import oracle_lib as orc
+    name, gb, ob, _, _ = case
+    S = gb.overlap()
+    blocks = gb.get_sym_idx(1)
+    X = hf.scf.form_Sinvh(S, True, blocks)
+    Xo = orc.form_Sinvh(S, True, blocks)
+    assert np.max(np.abs(X - Xo)) < 1e-9 * np.max(np.abs(Xo)), name
+    assert np.max(np.abs(X.T @ S @ X - np.eye(S.shape[0]))) < 1e-9
+    # the generalized eigenproblem does not care which half-inverse it gets
+    F = gb.kinetic() + gb.nuclear()
+    E1, _ = hf.scf.eig_gsym_sub(F, X, blocks)
+    E2, _ = hf.scf.eig_gsym_sub(F, hf.scf.form_Sinvh(S, False, blocks), blocks)
+    assert np.max(np.abs(E1 - E2)) < 1e-8 * max(1.0, np.max(np.abs(E2)))
+
+
+def test_form_sinvh_cholesky_large_block(hf):
+    rng = np.random.RandomState(4)
+    n = 333
+    A = rng.uniform(-1, 1, (n, n))
+    S = A @ A.T + 0.5 * n * np.eye(n)
+    X = hf.scf.form_Sinvh(S, True, [np.arange(n)])
+    assert np.max(np.abs(X.T @ S @ X - np.eye(n))) < 1e-10
+    assert np.max(np.abs(np.tril(X, -1))) == 0.0
+    with pytest.raises(RuntimeError):
+        hf.scf.form_Sinvh(-S, True, [np.arange(n)])
+
+
 def test_edge_case_bases(hf):
     """smallest shapes the reference accepts: one radial element, one angular shell, sigma-only with lmax 0"""
     import common
