@@ -26,6 +26,7 @@ void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, con
 void form_sinvh_dev(hfg_ctx *ctx, int N, const double *dS, bool chol, int nblk, const int64_t *blk_ptr,
                     const int64_t *blk_idx, double *dSinvh);
 void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc, double *dP);
+void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                       const int64_t *blk_idx, double *dE, double *dC);
 void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
@@ -52,6 +53,15 @@ __global__ void k_mask_blocks(double *__restrict__ F, int N, const int *__restri
   int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
   if (i >= N) return;
   if (blockid[i] != blockid[j]) F[(size_t)j * N + i] = 0.0;
+}
+// lambda of scf::ROHF_update in the natural-orbital basis (ascending occupations: virtual 0..Nv-1, core N-Nc..N-1):
+// the core-virtual blocks of -Delta, everything else zero
+__global__ void k_rohf_lambda(double *__restrict__ D, int N, int Nc, int Nv) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= N) return;
+  const bool ic = i >= N - Nc, iv = i < Nv, jc = j >= N - Nc, jv = j < Nv;
+  const size_t o = (size_t)j * N + i;
+  D[o] = ((ic && jv) || (iv && jc)) ? -D[o] : 0.0;
 }
 // two-stage deterministic reductions: partial[b] = sum / max over the block's grid-stride range
 __global__ __launch_bounds__(256) void k_dot_partial(size_t n, const double *__restrict__ x, const double *__restrict__ y,
@@ -144,9 +154,9 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   const int M = opt.multiplicity;
   if (M < 1 || (nel + M - 1) % 2 != 0 || M - 1 > nel) throw std::logic_error("Requested multiplicity not achievable.\n");
   const int nela = (nel + M - 1) / 2, nelb = nel - nela;
-  const bool restr = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
-  if (restr && nela != nelb)
-    throw std::logic_error("Restricted open-shell (ROHF) runs are not implemented in this build.\n");
+  const bool restr_req = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
+  const bool rohf = restr_req && nela != nelb;  // restricted open shell: unrestricted machinery + CUHF constraint
+  const bool restr = restr_req && !rohf;
   res.nela = nela;
   res.nelb = nelb;
 
@@ -208,6 +218,12 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   form_sinvh_dev(ctx, n, d.S.p, !opt.diag, (int)dsym.size(), ptr.data(), idx.data(), d.Sinvh.p);
   HFG_HIP_CHECK(hipStreamSynchronize(s));
   if (verbose) printf("Half-inverse formed in %.6f\n", wall() - t0);
+  DevBuf<double> Sh, Pvec, A2N, ShPv, occ;
+  if (rohf) {  // partner of Sinvh: Sh^T Sinvh = 1 (S^{1/2} for the symmetric half-inverse)
+    for (DevBuf<double> *b : {&Sh, &Pvec, &A2N, &ShPv}) b->resize(NN);
+    occ.resize(N);
+    gemm_dev(ctx, false, false, n, n, n, 1.0, d.S.p, n, d.Sinvh.p, n, 0.0, Sh.p, n);
+  }
   if (verbose) printf("Guess orbitals from core Hamiltonian\n");
   eig_gsym_sub_dev(ctx, n, d.H0.p, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), d.Ea.p, d.Ca.p);
   if (!restr) {
@@ -286,6 +302,25 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       if (opt.kfrac != 0.0) d.axpby(1.0, sp ? d.Kb.p : d.Ka.p, 1.0, F, NN);
       if (dft) d.axpby(1.0, sp ? d.XCb.p : d.XCa.p, 1.0, F, NN);
       if (symm) hipLaunchKernelGGL(k_mask_blocks, dim3((n + 255) / 256, n), dim3(256), 0, s, F, n, d.blockid.p);
+    }
+
+    if (rohf) {
+      // scf::ROHF_update (scf_helpers.cpp:470-523) with every product on the matrix cores
+      gemm_dev(ctx, false, false, n, n, n, 1.0, d.P.p, n, Sh.p, n, 0.0, d.T1.p, n);
+      gemm_dev(ctx, true, false, n, n, n, 1.0, Sh.p, n, d.T1.p, n, 0.0, d.T2.p, n);  // P in the orthonormal basis
+      eig_sym_dev(ctx, n, d.T2.p, occ.p, Pvec.p);                                    // natural orbitals, ascending
+      gemm_dev(ctx, false, false, n, n, n, 1.0, d.Sinvh.p, n, Pvec.p, n, 0.0, A2N.p, n);
+      gemm_dev(ctx, false, false, n, n, n, 1.0, Sh.p, n, Pvec.p, n, 0.0, ShPv.p, n);
+      d.axpby(0.5, d.Fa.p, 0.0, d.T1.p, NN);
+      d.axpby(-0.5, d.Fb.p, 1.0, d.T1.p, NN);  // Delta
+      gemm_dev(ctx, false, false, n, n, n, 1.0, d.T1.p, n, A2N.p, n, 0.0, d.T2.p, n);
+      gemm_dev(ctx, true, false, n, n, n, 1.0, A2N.p, n, d.T2.p, n, 0.0, d.T1.p, n);  // Delta in the NO basis
+      const int Nc = std::min(nela, nelb), Nv = n - std::max(nela, nelb);
+      hipLaunchKernelGGL(k_rohf_lambda, dim3((n + 255) / 256, n), dim3(256), 0, s, d.T1.p, n, Nc, Nv);
+      gemm_dev(ctx, false, false, n, n, n, 1.0, ShPv.p, n, d.T1.p, n, 0.0, d.T2.p, n);
+      gemm_dev(ctx, false, true, n, n, n, 1.0, d.T2.p, n, ShPv.p, n, 0.0, d.T1.p, n);  // lambda in the AO basis
+      d.axpby(1.0, d.T1.p, 1.0, d.Fa.p, NN);
+      d.axpby(-1.0, d.T1.p, 1.0, d.Fb.p, NN);
     }
 
     // DIIS: store (F, err) in a ring slot, new row of B, slot 5 = max |err|

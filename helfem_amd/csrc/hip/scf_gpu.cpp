@@ -83,6 +83,12 @@ struct GPUBackend : public helfem::scf::Backend {
                        X.memptr()));
     return X;
   }
+  void eig_sym(Vec &E, Mat &C, const Mat &A) override {
+    size_t n = A.n_rows;
+    E.assign(n, 0.0);
+    C.zeros(n, n);
+    chk(hfg_eig_sym(ctx, (int64_t)n, A.memptr(), E.data(), C.memptr()));
+  }
   Mat gemm(const Mat &A, bool tA, const Mat &B, bool tB) override {
     size_t m = tA ? A.n_cols : A.n_rows, k = tA ? A.n_rows : A.n_cols, n = tB ? B.n_rows : B.n_cols;
     Mat C(m, n);
@@ -191,7 +197,8 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
                      int symmetry, int multiplicity, int maxit, double convthr, int verbose, double *out) {
   try {
     helfem::scf::Options o;
-    o.multiplicity = multiplicity;
+    o.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
+    if (multiplicity < 0) o.restricted = 1;
     o.Z1 = Z1;
     o.Z2 = Z2;
     o.Rbond = Rbond;
@@ -242,7 +249,8 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
                    double convthr, int verbose, double *out) {
   try {
     helfem::scf::AtomicOptions a;
-    a.common.multiplicity = multiplicity;
+    a.common.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;
+    if (multiplicity < 0) a.common.restricted = 1;
     a.Z = Z;
     a.Q = Q;
     a.lmax = lmax;

@@ -101,6 +101,31 @@ struct Problem {
   std::function<void()> compute_tei_and_prepare;
 };
 
+// scf::ROHF_update (src/general/scf_helpers.cpp:470-523; Tsuchimochi & Scuseria, J. Chem. Phys. 134, 064101):
+// natural orbitals of the total density, lambda = -Delta on the core-virtual blocks, Fa += lambda, Fb -= lambda.
+// Sh is the partner of Sinvh (Sh^T Sinvh = 1; S Sinvh, which is S^{1/2} for the symmetric half-inverse).
+void rohf_update(Backend &be, Mat &Fa, Mat &Fb, const Mat &P, const Mat &Sh, const Mat &Sinvh, size_t nocca, size_t noccb) {
+  const size_t N = P.n_rows;
+  Mat Porth = be.gemm(be.gemm(Sh, true, P, false), false, Sh, false);
+  Vec occ;
+  Mat Pvec;
+  be.eig_sym(occ, Pvec, Porth);  // ascending occupations: virtual, active, core
+  Mat A2N = be.gemm(Sinvh, false, Pvec, false);
+  Mat ShPv = be.gemm(Sh, false, Pvec, false);
+  Mat Delta = 0.5 * (Fa - Fb);
+  Mat Dno = be.gemm(be.gemm(A2N, true, Delta, false), false, A2N, false);
+  const size_t Nc = std::min(nocca, noccb), Na = std::max(nocca, noccb) - Nc, Nv = N - Na - Nc;
+  Mat lam(N, N);
+  for (size_t c = N - Nc; c < N; c++)
+    for (size_t v = 0; v < Nv; v++) {
+      lam(c, v) = -Dno(c, v);
+      lam(v, c) = -Dno(v, c);
+    }
+  Mat lamAO = be.gemm(be.gemm(ShPv, false, lam, false), false, ShPv, true);
+  Fa += lamAO;
+  Fb -= lamAO;
+}
+
 Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   const bool verbose = opt.verbose;
   const bool dft = (opt.x_func > 0 || opt.c_func > 0);
@@ -109,9 +134,9 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   const int M = opt.multiplicity;
   if (M < 1 || (nel + M - 1) % 2 != 0 || M - 1 > nel) throw std::logic_error("Requested multiplicity not achievable.\n");
   const size_t nela = (nel + M - 1) / 2, nelb = nel - nela;
-  bool restr = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
-  if (restr && nela != nelb)
-    throw std::logic_error("Restricted open-shell (ROHF) runs are not implemented in this build.\n");
+  const bool restr_req = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
+  const bool rohf = restr_req && nela != nelb;  // restricted open shell: unrestricted machinery + CUHF constraint
+  const bool restr = restr_req && !rohf;
   res.nela = (int)nela;
   res.nelb = (int)nelb;
   const int symm = pb.symm;
@@ -122,6 +147,8 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   Mat Sinvh(be.Sinvh(S, !opt.diag, dsym));
   if (verbose) printf("Half-inverse formed in %.6f\n", wall() - t0);
 
+  Mat Sh;
+  if (rohf) Sh = be.gemm(S, false, Sinvh, false);
   // core guess (main.cpp:655-660 with point nuclei == T+Vnuc)
   Vec Ea, Eb;
   Mat Ca, Cb;
@@ -197,6 +224,7 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
       if (Kb.n_rows == Fb.n_rows) Fb += Kb;
       if (dft) Fb += XCb;
       if (symm) Fb = enforce_sym(Fb, dsym);
+      if (rohf) rohf_update(be, Fa, Fb, P, Sh, Sinvh, nela, nelb);  // main.cpp:903-904
     }
 
     res.Etot = res.Ekin + res.Epot + res.Ecoul + res.Exx + res.Exc + res.Enucr;

@@ -4,7 +4,7 @@
 // of the reference driver (/root/reference/src/diatomic/main.cpp:402-1009):
 //   S,T,Vnuc -> Sinvh -> guess (core Hamiltonian, --iguess 0) -> compute_tei ->
 //   loop { P = C_occ C_occ^T; J; K; XC; F; E; DIIS; eig_gsym_sub } -> energy table.
-// Restricted open-shell (ROHF) runs, external fields, finite nuclei, checkpoints and the SAP/GSZ/TF
+// External fields, finite nuclei, checkpoints and the SAP/GSZ/TF
 // guesses are outside the hot-path scope and are rejected loudly.
 #pragma once
 #include "atomic_basis.h"
@@ -33,6 +33,8 @@ struct Backend {
   virtual Mat Sinvh(const Mat &S, bool chol, const std::vector<std::vector<size_t> > &sym) = 0;
   /// C = op(A) op(B)
   virtual Mat gemm(const Mat &A, bool tA, const Mat &B, bool tB) = 0;
+  /// arma::eig_sym of a dense symmetric matrix, eigenvalues ascending (natural orbitals of ROHF_update)
+  virtual void eig_sym(Vec &E, Mat &C, const Mat &A) = 0;
 };
 
 struct Options {
@@ -54,7 +56,8 @@ struct Options {
   double dftthr = 1e-12;
   int symmetry = 1;
   int multiplicity = 1;   // --M: spin multiplicity 2S+1; nela - nelb = M - 1
-  int restricted = -1;    // --restricted: -1 auto (restricted iff M == 1), 0 unrestricted, 1 restricted (M == 1 only)
+  int restricted = -1;    // --restricted: -1 auto (restricted iff M == 1), 0 unrestricted, 1 restricted; with M > 1 that
+                          // is the constrained-UHF form of ROHF (scf::ROHF_update, scf_helpers.cpp:470)
   int diisorder = 5;
   bool verbose = true;
 };

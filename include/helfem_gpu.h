@@ -188,7 +188,8 @@ int hfg_gemm_dev(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int
                  int64_t lda, const double *dB, int64_t ldb, double *dC, int64_t ldc);
 
 /* ---- SCF driver, the loop of src/diatomic/main.cpp:780-995: restricted closed shell (multiplicity 1) or
- * unrestricted (multiplicity = 2S+1 > 1: nela - nelb = multiplicity - 1, --M of main.cpp:100) --------- */
+ * unrestricted (multiplicity = 2S+1 > 1: nela - nelb = multiplicity - 1, --M of main.cpp:100); a NEGATIVE
+ * multiplicity selects the restricted open-shell run of `--restricted 1` (scf::ROHF_update, main.cpp:903) --------- */
 /* out[0..7] = Etot, Ekin, Epot, Ecoul, Exx, Exc, Enucr, iterations(+0.5 if converged); out[8..11] =
  * seconds of the last iteration's J, K, XC and diagonalisation steps (the reference's Timer prints). */
 int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmmax, int nlm, int nelem, int nnodes,

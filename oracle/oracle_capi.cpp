@@ -65,6 +65,7 @@ struct OracleBackend : public helfem::scf::Backend {
     return oracle::form_Sinvh(S, chol, sym);
   }
   Mat gemm(const Mat &A, bool tA, const Mat &B, bool tB) override { return helfem::matmul(A, tA, B, tB); }
+  void eig_sym(Vec &E, Mat &C, const Mat &A) override { oracle::eig_sym(E, C, A); }
 };
 }  // namespace
 
@@ -230,7 +231,8 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
                      int symmetry, int multiplicity, int maxit, double convthr, int verbose, double *out) {
   ORC_TRY
   helfem::scf::Options o;
-  o.multiplicity = multiplicity;
+  o.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
+  if (multiplicity < 0) o.restricted = 1;
   o.Z1 = Z1;
   o.Z2 = Z2;
   o.Rbond = Rbond;
@@ -384,7 +386,8 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
                    double convthr, int verbose, double *out) {
   ORC_TRY
   helfem::scf::AtomicOptions a;
-  a.common.multiplicity = multiplicity;
+  a.common.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
+  if (multiplicity < 0) a.common.restricted = 1;
   a.Z = Z;
   a.Q = Q;
   a.lmax = lmax;

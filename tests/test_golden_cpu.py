@@ -477,6 +477,9 @@ OPEN_SHELL_LITERATURE = [
     ("H_UHF", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=2), -0.5, 1e-9),
     ("Li_UHF", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=2), -7.432751, 1e-6),
     ("N_UHF", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=15, method="HF", M=4), -54.404548, 1e-6),
+    # restricted open shell (M < 0): numerical ROHF limits
+    ("Li_ROHF", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=-2), -7.4327269, 1e-6),
+    ("N_ROHF", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=15, method="HF", M=-4), -54.400934, 1e-6),
 ]
 
 
