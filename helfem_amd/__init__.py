@@ -485,17 +485,17 @@ def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0
 
 
 def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
-               symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1):
-    """Restricted closed-shell (M=1) or unrestricted (M=2S+1>1) atomic SCF with every per-iteration step on the GPU
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1, maverage=False):
+    """Restricted closed-shell (M=1), unrestricted (M=2S+1>1) or restricted open-shell (M<0) atomic SCF with every per-iteration step on the GPU
     (the loop of src/atomic/main.cpp:760-1005; flags as in main.cpp:66-100)."""
     ctx = ctx or default_context()
     L = lib()
     L.hfg_scf_atomic.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int,
-                                ctypes.c_double, ctypes.c_char_p] + [ctypes.c_int] * 5 + [ctypes.c_double,
+                                ctypes.c_double, ctypes.c_char_p] + [ctypes.c_int] * 6 + [ctypes.c_double,
                                 ctypes.c_int, c_double_p]
     out = np.zeros(12)
     _check(L.hfg_scf_atomic(ctx.h, Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft,
-                            mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
+                            mdft, symmetry, M, 1 if maverage else 0, maxit, convthr, verbose, _p(out)))
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])

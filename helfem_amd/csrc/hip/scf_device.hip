@@ -54,6 +54,16 @@ __global__ void k_mask_blocks(double *__restrict__ F, int N, const int *__restri
   if (i >= N) return;
   if (blockid[i] != blockid[j]) F[(size_t)j * N + i] = 0.0;
 }
+// scf::fock_symmetry_average (scf_helpers.cpp:263-284) for one group: the diagonal blocks F(idx_c, idx_c), c < ng, are
+// replaced by their mean; idx holds the ng index lists of length nn back to back
+__global__ void k_fock_average(double *__restrict__ F, int N, const int *__restrict__ idx, int ng, int nn) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= nn) return;
+  double m = 0.0;
+  for (int c = 0; c < ng; c++) m += F[(size_t)idx[c * nn + j] * N + idx[c * nn + i]];
+  m /= (double)ng;
+  for (int c = 0; c < ng; c++) F[(size_t)idx[c * nn + j] * N + idx[c * nn + i]] = m;
+}
 // lambda of scf::ROHF_update in the natural-orbital basis (ascending occupations: virtual 0..Nv-1, core N-Nc..N-1):
 // the core-virtual blocks of -Delta, everything else zero
 __global__ void k_rohf_lambda(double *__restrict__ D, int N, int Nc, int Nv) {
@@ -145,7 +155,8 @@ struct DevSCF {
 
 /// the shared part of both programs, everything on the device; `basis` already holds the host tables of S, T, V
 helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::scf::Options &opt, int nel, double Enucr,
-                                    int symm, const std::vector<std::vector<size_t> > &dsym, int ldft, int mdft) {
+                                    int symm, const std::vector<std::vector<size_t> > &dsym, int ldft, int mdft,
+                                    const std::vector<std::vector<std::vector<size_t> > > &avg_idx) {
   using helfem::Mat;
   helfem::scf::Result res;
   res.Enucr = Enucr;
@@ -214,6 +225,14 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     d.histE[k].resize(nspin * NN);
   }
 
+  std::unique_ptr<DevBuf<int>[]> avgdev(new DevBuf<int>[avg_idx.size() + 1]);
+  for (size_t gi = 0; gi < avg_idx.size(); gi++) {
+    std::vector<int> flat;
+    for (const auto &l : avg_idx[gi])
+      for (size_t v : l) flat.push_back((int)v);
+    avgdev[gi].upload(flat, s);
+  }
+  HFG_HIP_CHECK(hipStreamSynchronize(s));
   double t0 = wall();
   form_sinvh_dev(ctx, n, d.S.p, !opt.diag, (int)dsym.size(), ptr.data(), idx.data(), d.Sinvh.p);
   HFG_HIP_CHECK(hipStreamSynchronize(s));
@@ -301,6 +320,11 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       d.axpby(1.0, d.J.p, 1.0, F, NN);
       if (opt.kfrac != 0.0) d.axpby(1.0, sp ? d.Kb.p : d.Ka.p, 1.0, F, NN);
       if (dft) d.axpby(1.0, sp ? d.XCb.p : d.XCa.p, 1.0, F, NN);
+      for (size_t gi = 0; gi < avg_idx.size(); gi++) {
+        if (avg_idx[gi].empty()) continue;
+        const int ng = (int)avg_idx[gi].size(), nn = (int)avg_idx[gi][0].size();
+        hipLaunchKernelGGL(k_fock_average, dim3((nn + 255) / 256, nn), dim3(256), 0, s, F, n, avgdev[gi].p, ng, nn);
+      }
       if (symm) hipLaunchKernelGGL(k_mask_blocks, dim3((n + 255) / 256, n), dim3(256), 0, s, F, n, d.blockid.p);
     }
 

@@ -101,7 +101,9 @@ struct GPUBackend : public helfem::scf::Backend {
 
 namespace hfg {
 helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::scf::Options &opt, int nel, double Enucr,
-                                    int symm, const std::vector<std::vector<size_t> > &dsym, int ldft, int mdft);
+                                    int symm, const std::vector<std::vector<size_t> > &dsym, int ldft, int mdft,
+                                    const std::vector<std::vector<std::vector<size_t> > > &avg_idx =
+                                        std::vector<std::vector<std::vector<size_t> > >());
 }
 
 namespace {
@@ -177,7 +179,9 @@ helfem::scf::Result run_atomic_device(hfg_ctx *ctx, const helfem::scf::AtomicOpt
       if (mdft < 2 * a.mmax) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
     } else
       ldft = mdft = 0;
-    r = hfg::scf_device_loop(ctx, hb, opt, nel, 0.0, opt.symmetry, hb->ab.get_sym_idx(opt.symmetry), ldft, mdft);
+    std::vector<std::vector<std::vector<size_t> > > avg;
+    if (a.maverage) avg = helfem::scf::atomic_average_groups(hb->ab);
+    r = hfg::scf_device_loop(ctx, hb, opt, nel, 0.0, opt.symmetry, hb->ab.get_sym_idx(opt.symmetry), ldft, mdft, avg);
   } catch (...) {
     hfg_basis_destroy(hb);
     throw;
@@ -245,10 +249,11 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
 }
 
 int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax,
-                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity, int maxit,
-                   double convthr, int verbose, double *out) {
+                   int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity,
+                   int maverage, int maxit, double convthr, int verbose, double *out) {
   try {
     helfem::scf::AtomicOptions a;
+    a.maverage = maverage != 0;
     a.common.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;
     if (multiplicity < 0) a.common.restricted = 1;
     a.Z = Z;

@@ -99,7 +99,27 @@ struct Problem {
   int symm = 1;
   int nel = 0;
   std::function<void()> compute_tei_and_prepare;
+  // --maverage (atomic): groups of equally sized index lists whose diagonal blocks of F are averaged
+  std::vector<std::vector<std::vector<size_t> > > avg_idx;
 };
+
+// scf::fock_symmetry_average (src/general/scf_helpers.cpp:263-284)
+Mat fock_symmetry_average(const Mat &Fin, const std::vector<std::vector<std::vector<size_t> > > &sym_idx) {
+  Mat Fout(Fin);
+  for (const auto &grp : sym_idx) {
+    if (grp.empty()) continue;
+    const size_t nn = grp[0].size();
+    Mat Fmean(nn, nn);
+    for (const auto &idx : grp)
+      for (size_t j = 0; j < nn; j++)
+        for (size_t i = 0; i < nn; i++) Fmean(i, j) += Fin(idx[i], idx[j]);
+    for (double &v : Fmean.d) v /= (double)grp.size();
+    for (const auto &idx : grp)
+      for (size_t j = 0; j < nn; j++)
+        for (size_t i = 0; i < nn; i++) Fout(idx[i], idx[j]) = Fmean(i, j);
+  }
+  return Fout;
+}
 
 // scf::ROHF_update (src/general/scf_helpers.cpp:470-523; Tsuchimochi & Scuseria, J. Chem. Phys. 134, 064101):
 // natural orbitals of the total density, lambda = -Delta on the core-virtual blocks, Fa += lambda, Fb -= lambda.
@@ -218,11 +238,13 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
     Fa = H0 + J;
     if (Ka.n_rows == Fa.n_rows) Fa += Ka;
     if (dft) Fa += XCa;
+    if (!pb.avg_idx.empty()) Fa = fock_symmetry_average(Fa, pb.avg_idx);  // atomic/main.cpp:839-842
     if (symm) Fa = enforce_sym(Fa, dsym);
     if (!restr) {
       Fb = H0 + J;
       if (Kb.n_rows == Fb.n_rows) Fb += Kb;
       if (dft) Fb += XCb;
+      if (!pb.avg_idx.empty()) Fb = fock_symmetry_average(Fb, pb.avg_idx);
       if (symm) Fb = enforce_sym(Fb, dsym);
       if (rohf) rohf_update(be, Fa, Fb, P, Sh, Sinvh, nela, nelb);  // main.cpp:903-904
     }
@@ -359,6 +381,17 @@ Result run_diatomic(const Options &opt, Backend &be) {
   return scf_loop(opt, be, pb, res);
 }
 
+// index lists of atomic/main.cpp:308-312: for every l the functions of the shells (l,m), all m
+std::vector<std::vector<std::vector<size_t> > > atomic_average_groups(const atomic::TwoDBasis &basis) {
+  int lmax = 0;
+  for (int l : basis.lval) lmax = std::max(lmax, l);
+  std::vector<std::vector<std::vector<size_t> > > grp(lmax + 1);
+  for (int l = 0; l <= lmax; l++)
+    for (size_t a = 0; a < basis.Nang(); a++)
+      if (basis.lval[a] == l) grp[l].push_back(basis.lm_indices(l, basis.mval[a]));
+  return grp;
+}
+
 Result run_atomic(const AtomicOptions &aopt, Backend &be) {
   const Options &opt = aopt.common;
   Result res;
@@ -392,6 +425,7 @@ Result run_atomic(const AtomicOptions &aopt, Backend &be) {
   }
   pb.symm = opt.symmetry;
   pb.dsym = basis.get_sym_idx(pb.symm);
+  if (aopt.maverage) pb.avg_idx = atomic_average_groups(basis);
   pb.nel = nel;
   pb.S = basis.overlap();
   pb.T = basis.kinetic();

@@ -80,8 +80,10 @@ struct AtomicOptions {
   Options common;
   int Z = 2, Q = 0;
   int lmax = 0, mmax = 0;
+  bool maverage = false;  // --maverage: average the Fock matrices over m for every l (scf::fock_symmetry_average)
 };
 
+std::vector<std::vector<std::vector<size_t> > > atomic_average_groups(const atomic::TwoDBasis &basis);
 Result run_diatomic(const Options &opt, Backend &be);
 /// src/atomic/main.cpp:100-1010, restricted closed shell, point nucleus, core guess
 Result run_atomic(const AtomicOptions &opt, Backend &be);

@@ -208,7 +208,8 @@ int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launche
 /* Atomic SCF, restricted closed shell or unrestricted (driver loop of src/atomic/main.cpp:760-1005); out as for hfg_scf_diatomic */
 int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax,
                    int igrid, double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity,
-                   int maxit, double convthr, int verbose, double *out /* 12 */);
+                   int maverage /* --maverage: scf::fock_symmetry_average over m */, int maxit, double convthr,
+                   int verbose, double *out /* 12 */);
 
 /* Replays every launch of the named kernel of the last eigensolve back to back between two HIP events on the
  * context's stream (the roofline leg of bench.py).  Supported: "k_trdb_gemv". */

@@ -382,10 +382,11 @@ int orc_atomic_prim_tei(void *h, int L, int iel, double *out, int64_t *n) {
 
 /// Restricted closed-shell atomic SCF on the CPU oracle; out as for orc_scf_diatomic
 int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax, int igrid,
-                   double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity, int maxit,
-                   double convthr, int verbose, double *out) {
+                   double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity, int maverage,
+                   int maxit, double convthr, int verbose, double *out) {
   ORC_TRY
   helfem::scf::AtomicOptions a;
+  a.maverage = maverage != 0;
   a.common.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
   if (multiplicity < 0) a.common.restricted = 1;
   a.Z = Z;

@@ -51,7 +51,7 @@ def lib():
         L.orc_atomic_radial_integral.argtypes = [ctypes.c_void_p, ctypes.c_int, c_double_p]
         L.orc_atomic_prim_tei.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_double_p, c_i64_p]
         L.orc_scf_atomic.argtypes = [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
-                                                          ctypes.c_char_p] + [ctypes.c_int] * 5 + [
+                                                          ctypes.c_char_p] + [ctypes.c_int] * 6 + [
                                                               ctypes.c_double, ctypes.c_int, c_double_p]
         for name in ("orc_basis_destroy", "orc_basis_dims", "orc_compute_tei", "orc_coulomb", "orc_exchange",
                      "orc_grid_overlap", "orc_grid_kinetic"):
@@ -238,10 +238,10 @@ def xc_polarized(func_id, rho, sigma, thr=1e-12):
 
 
 def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
-               symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1):
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1, maverage=False):
     out = np.zeros(8)
     _check(lib().orc_scf_atomic(Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft, mdft,
-                                symmetry, M, maxit, convthr, verbose, _p(out)))
+                                symmetry, M, 1 if maverage else 0, maxit, convthr, verbose, _p(out)))
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])
