@@ -276,9 +276,11 @@ __global__ void k_coulomb_bra(const double *__restrict__ Jaux, int A, int E, int
 // -------------------------------------------------------------------------------------------------
 // X1 radial contraction of the density: D0[Q][x][y] = sum_ij B_i(q) Pc[x][y][e][j][i] B_j(q),
 //    D1[Q][x][y] = sum_ij B'_i(q) Pc[..][j][i] B_j(q)            (replaces Pv = P conj(bf), dftgrid.cpp:62)
+//    (meta-GGA: D2[Q][x][y] = sum_ij B'_i Pc B'_j for the kinetic energy density)
 __global__ void k_xc_density_radial(const double *__restrict__ Pc, const double *__restrict__ B,
                                     const double *__restrict__ dB, int A, int E, int p, int nq, int do_grad,
-                                    int rank, int nranks, double *__restrict__ D0, double *__restrict__ D1) {
+                                    int do_tau, int rank, int nranks, double *__restrict__ D0, double *__restrict__ D1,
+                                    double *__restrict__ D2) {
   extern __shared__ double sh[];  // P[pp]
   int xy = blockIdx.x, e = blockIdx.y;
   int pp = p * p;
@@ -289,7 +291,7 @@ __global__ void k_xc_density_radial(const double *__restrict__ Pc, const double 
     if ((e * nq + q) % nranks != rank) continue;  // radial quadrature points are the multi-GPU shards of XC
     const double *b = B + ((size_t)e * nq + q) * p;
     const double *db = dB + ((size_t)e * nq + q) * p;
-    double d0 = 0.0, d1 = 0.0;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
     for (int j = 0; j < p; j++) {
       double s0 = 0.0, s1 = 0.0;
       for (int i = 0; i < p; i++) {
@@ -299,49 +301,62 @@ __global__ void k_xc_density_radial(const double *__restrict__ Pc, const double 
       }
       d0 += s0 * b[j];
       d1 += s1 * b[j];
+      d2 += s1 * db[j];
     }
     size_t Q = (size_t)e * nq + q;
     D0[Q * AA + xy] = d0;
     if (do_grad) D1[Q * AA + xy] = d1;
+    if (do_tau) D2[Q * AA + xy] = d2;
   }
 }
 
 // X2 theta contraction per (m-group pair): V[k][Q][ga][gb][i],
 //    k=0: sum Theta_a D0_ab Theta_b ; k=1: sum dTheta_a D0_ab Theta_b ; k=2: sum Theta_a D1_ab Theta_b
+//    meta-GGA: k=3: sum Theta_a D2_ab Theta_b ; k=4: sum dTheta_a D0_ab dTheta_b
 __global__ void k_xc_density_theta(const double *__restrict__ D0, const double *__restrict__ D1,
-                                   const double *__restrict__ Th, const double *__restrict__ dTh, int A, int nth,
-                                   int G, const int *__restrict__ grp_off, const int *__restrict__ grp_shell,
-                                   int do_grad, size_t NQ, int rank, int nranks, double *__restrict__ V) {
-  extern __shared__ double sh[];  // d0[na*nb], d1[na*nb]
+                                   const double *__restrict__ D2, const double *__restrict__ Th,
+                                   const double *__restrict__ dTh, int A, int nth, int G,
+                                   const int *__restrict__ grp_off, const int *__restrict__ grp_shell, int do_grad,
+                                   int do_tau, size_t NQ, int rank, int nranks, double *__restrict__ V) {
+  extern __shared__ double sh[];  // d0[na*nb], d1[na*nb], d2[na*nb]
   size_t Q = blockIdx.x;
   if ((int)(Q % nranks) != rank) return;
   int ga = blockIdx.y / G, gb = blockIdx.y % G;
   int a0 = grp_off[ga], na = grp_off[ga + 1] - a0;
   int b0 = grp_off[gb], nb = grp_off[gb + 1] - b0;
-  double *d0 = sh, *d1 = sh + na * nb;
+  double *d0 = sh, *d1 = sh + na * nb, *d2 = sh + 2 * na * nb;
   size_t AA = (size_t)A * A;
   for (int t = threadIdx.x; t < na * nb; t += blockDim.x) {
     int ia = t / nb, ib = t % nb;
     int a = grp_shell[a0 + ia], b = grp_shell[b0 + ib];
     d0[t] = D0[Q * AA + (size_t)a * A + b];
     d1[t] = do_grad ? D1[Q * AA + (size_t)a * A + b] : 0.0;
+    d2[t] = do_tau ? D2[Q * AA + (size_t)a * A + b] : 0.0;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nth; i += blockDim.x) {
-    double r = 0.0, s = 0.0, u = 0.0;
+    double r = 0.0, s = 0.0, u = 0.0, k3 = 0.0, k4 = 0.0;
     for (int ia = 0; ia < na; ia++) {
       int a = grp_shell[a0 + ia];
-      double s0 = 0.0, s1 = 0.0;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       for (int ib = 0; ib < nb; ib++) {
         double tb = Th[(size_t)grp_shell[b0 + ib] * nth + i];
         s0 += d0[ia * nb + ib] * tb;
         s1 += d1[ia * nb + ib] * tb;
+        if (do_tau) {
+          s2 += d2[ia * nb + ib] * tb;
+          s3 += d0[ia * nb + ib] * dTh[(size_t)grp_shell[b0 + ib] * nth + i];
+        }
       }
       double ta = Th[(size_t)a * nth + i];
       r += ta * s0;
       if (do_grad) {
         s += dTh[(size_t)a * nth + i] * s0;
         u += ta * s1;
+      }
+      if (do_tau) {
+        k3 += ta * s2;
+        k4 += dTh[(size_t)a * nth + i] * s3;
       }
     }
     size_t o = ((Q * G + ga) * G + gb) * nth + i;
@@ -350,6 +365,10 @@ __global__ void k_xc_density_theta(const double *__restrict__ D0, const double *
     if (do_grad) {
       V[stride + o] = s;
       V[2 * stride + o] = u;
+    }
+    if (do_tau) {
+      V[3 * stride + o] = k3;
+      V[4 * stride + o] = k4;
     }
   }
 }
@@ -364,24 +383,26 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
                           const double *__restrict__ rad_sh, const double *__restrict__ th_s,
                           const double *__restrict__ th_w, const int *__restrict__ grp_m,
                           const double *__restrict__ cosd, const double *__restrict__ sind, int Dmax, int G, int nth,
-                          int nphi, double Rh, int geom, int x_func, int c_func, int do_grad, double thr, size_t NQ,
-                          int rank, int nranks, double *__restrict__ Fo, double *__restrict__ partial /* [2][NQ] */) {
-  extern __shared__ double sh[];  // pot[4][nth*nphi], red[2*nwave]
+                          int nphi, double Rh, int geom, int x_func, int c_func, int do_grad, int do_tau, double thr,
+                          size_t NQ, int rank, int nranks, double *__restrict__ Fo,
+                          double *__restrict__ partial /* [3][NQ] */) {
+  extern __shared__ double sh[];  // pot[5][nth*nphi], red[3*nwave]
   size_t Q = blockIdx.x;
   if ((int)(Q % nranks) != rank) {
     if (threadIdx.x == 0) {
       partial[Q] = 0.0;
       partial[NQ + Q] = 0.0;
+      partial[2 * NQ + Q] = 0.0;
     }
     return;
   }
   int ng = nth * nphi;
-  double *p0 = sh, *p1 = sh + ng, *p2 = sh + 2 * ng, *p3 = sh + 3 * ng;
-  double *red = sh + 4 * ng;
+  double *p0 = sh, *p1 = sh + ng, *p2 = sh + 2 * ng, *p3 = sh + 3 * ng, *p4 = sh + 4 * ng;
+  double *red = sh + 5 * ng;
   double shm = rad_sh[Q], wr = rad_w[Q];
   double dphi = 2.0 * HFG_PI / nphi;
   size_t stride = NQ * G * G * nth;
-  double nel = 0.0, exc_sum = 0.0;
+  double nel = 0.0, exc_sum = 0.0, kin_sum = 0.0;
   for (int pt = threadIdx.x; pt < ng; pt += blockDim.x) {
     int i = pt / nphi, j = pt % nphi;
     double sth = th_s[i];
@@ -399,7 +420,7 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
       hphi = shm * sth;
       w = th_w[i] * dphi * wr * shm * shm;
     }
-    double rho = 0.0, gmu = 0.0, gnu = 0.0, gphi = 0.0;
+    double rho = 0.0, gmu = 0.0, gnu = 0.0, gphi = 0.0, tau = 0.0;
     for (int ga = 0; ga < G; ga++)
       for (int gb = 0; gb < G; gb++) {
         int D = grp_m[ga] - grp_m[gb];
@@ -407,6 +428,9 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
         size_t o = ((Q * G + ga) * G + gb) * nth + i;
         double vr = V[o];
         rho += cd * vr;
+        if (do_tau)  // tau = 1/2 sum_c Re[(P conj d_c bf) . d_c bf] / h_c^2   (dftgrid.cpp:90-112)
+          tau += 0.5 * cd * (V[3 * stride + o] / (hmu * hmu) + V[4 * stride + o] / (hnu * hnu) +
+                             (double)(grp_m[ga] * grp_m[gb]) * vr / (hphi * hphi));
         if (do_grad) {
           double sd = sind[(size_t)(D + Dmax) * nphi + j];
           gnu += cd * V[stride + o];
@@ -421,13 +445,21 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
       gphi *= 2.0 / hphi;
       sigma = gmu * gmu + gnu * gnu + gphi * gphi;
     }
-    double exc = 0.0, vrho = 0.0, vsig = 0.0;
+    double exc = 0.0, vrho = 0.0, vsig = 0.0, vtau = 0.0;
     if (rho >= thr && rho > 0.0) {
-      if (x_func > 0) xc::eval_add(x_func, rho, sigma, exc, vrho, vsig);
-      if (c_func > 0) xc::eval_add(c_func, rho, sigma, exc, vrho, vsig);
+      if (x_func > 0) {
+        if (xc::is_mgga(x_func)) xc::eval_add_mgga(x_func, rho, sigma, tau, exc, vrho, vsig, vtau);
+        else xc::eval_add(x_func, rho, sigma, exc, vrho, vsig);
+      }
+      if (c_func > 0) {
+        if (xc::is_mgga(c_func)) xc::eval_add_mgga(c_func, rho, sigma, tau, exc, vrho, vsig, vtau);
+        else xc::eval_add(c_func, rho, sigma, exc, vrho, vsig);
+      }
     }
     nel += w * rho;
     exc_sum += w * exc * rho;
+    kin_sum += w * tau;
+    if (do_tau) p4[pt] = 0.5 * w * vtau;  // vt of dftgrid.cpp:534-535
     p0[pt] = w * vrho;
     if (do_grad) {
       double f = 2.0 * w * vsig;
@@ -441,20 +473,24 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
   for (int o = 32; o > 0; o >>= 1) {
     nel += __shfl_down(nel, o, 64);
     exc_sum += __shfl_down(exc_sum, o, 64);
+    kin_sum += __shfl_down(kin_sum, o, 64);
   }
   if (lane == 0) {
     red[wave] = nel;
     red[nwave + wave] = exc_sum;
+    red[2 * nwave + wave] = kin_sum;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, c2 = 0.0;
     for (int w = 0; w < nwave; w++) {
       a += red[w];
       b += red[nwave + w];
+      c2 += red[2 * nwave + w];
     }
     partial[Q] = a;
     partial[NQ + Q] = b;
+    partial[2 * NQ + Q] = c2;
   }
   // phi transforms
   int nout = G * G * nth;
@@ -465,7 +501,7 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
     int D = grp_m[ga] - grp_m[gb];
     const double *cd = cosd + (size_t)(D + Dmax) * nphi;
     const double *sd = sind + (size_t)(D + Dmax) * nphi;
-    double fa = 0.0, fs = 0.0, fb = 0.0;
+    double fa = 0.0, fs = 0.0, fb = 0.0, ft = 0.0;
     double mga = grp_m[ga];
     for (int j = 0; j < nphi; j++) {
       int pt = i * nphi + j;
@@ -475,8 +511,25 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
         fs += p2[pt] * cd[j];
         fb += p1[pt] * cd[j];
       }
+      if (do_tau) ft += p4[pt] * cd[j];
     }
     size_t o = ((Q * G + ga) * G + gb) * nth + i;
+    if (do_tau) {
+      // the three tau terms of eval_Fxc (dftgrid.cpp:533-540) share the phi sum; the scale factors depend on
+      // theta only.  Halves as for the LDA term: the radial stage adds the (x,y) and (y,x) blocks.
+      double sth = th_s[i], hmu, hnu, hphi;
+      if (geom == 0) {
+        hmu = hnu = Rh * sqrt(shm * shm + sth * sth);
+        hphi = Rh * shm * sth;
+      } else {
+        hmu = 1.0;
+        hnu = shm;
+        hphi = shm * sth;
+      }
+      fa += 0.5 * mga * (double)grp_m[gb] * ft / (hphi * hphi);
+      Fo[3 * stride + o] = 0.5 * ft / (hmu * hmu);
+      Fo[4 * stride + o] = 0.5 * ft / (hnu * hnu);
+    }
     Fo[o] = fa;
     if (do_grad) {
       Fo[stride + o] = fs;
@@ -499,6 +552,7 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
     if (threadIdx.x == 0) {
       partial[Q] = 0.0;
       partial[NQ + Q] = 0.0;
+      partial[2 * NQ + Q] = 0.0;
     }
     return;
   }
@@ -591,6 +645,7 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
     }
     partial[Q] = a;
     partial[NQ + Q] = b;
+    partial[2 * NQ + Q] = 0.0;
   }
   int nout = G * G * nth;
   for (int t = threadIdx.x; t < 2 * nout; t += blockDim.x) {
@@ -624,11 +679,13 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
 }
 
 // X4 theta expansion: GA[Q][a][b] = sum_i Theta_a Theta_b Fo0 + dTheta_a Theta_b Fo1 ; GB[Q][a][b] = sum_i Theta_a Theta_b Fo2
+//    meta-GGA: GA += sum_i dTheta_a dTheta_b Fo4 ; GC[Q][a][b] = sum_i Theta_a Theta_b Fo3
 __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__restrict__ Th,
                                 const double *__restrict__ dTh, int A, int nth, int G,
                                 const int *__restrict__ grp_off, const int *__restrict__ grp_shell, int do_grad,
-                                size_t NQ, int rank, int nranks, double *__restrict__ GA, double *__restrict__ GB) {
-  extern __shared__ double sh[];  // f0[nth], f1[nth], f2[nth]
+                                int do_tau, size_t NQ, int rank, int nranks, double *__restrict__ GA,
+                                double *__restrict__ GB, double *__restrict__ GC) {
+  extern __shared__ double sh[];  // f0[nth], f1[nth], f2[nth], f3[nth], f4[nth]
   size_t Q = blockIdx.x;
   if ((int)(Q % nranks) != rank) return;
   int ga = blockIdx.y / G, gb = blockIdx.y % G;
@@ -636,45 +693,56 @@ __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__r
   int b0 = grp_off[gb], nb = grp_off[gb + 1] - b0;
   size_t stride = NQ * G * G * nth;
   size_t o = ((Q * G + ga) * G + gb) * nth;
-  double *f0 = sh, *f1 = sh + nth, *f2 = sh + 2 * nth;
+  double *f0 = sh, *f1 = sh + nth, *f2 = sh + 2 * nth, *f3 = sh + 3 * nth, *f4 = sh + 4 * nth;
   for (int i = threadIdx.x; i < nth; i += blockDim.x) {
     f0[i] = Fo[o + i];
     f1[i] = do_grad ? Fo[stride + o + i] : 0.0;
     f2[i] = do_grad ? Fo[2 * stride + o + i] : 0.0;
+    f3[i] = do_tau ? Fo[3 * stride + o + i] : 0.0;
+    f4[i] = do_tau ? Fo[4 * stride + o + i] : 0.0;
   }
   __syncthreads();
   size_t AA = (size_t)A * A;
   for (int t = threadIdx.x; t < na * nb; t += blockDim.x) {
     int a = grp_shell[a0 + t / nb], b = grp_shell[b0 + t % nb];
     const double *ta = Th + (size_t)a * nth, *tb = Th + (size_t)b * nth, *da = dTh + (size_t)a * nth;
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const double *dbb = dTh + (size_t)b * nth;
     for (int i = 0; i < nth; i++) {
       double tbi = tb[i];
       s0 += (ta[i] * f0[i] + da[i] * f1[i]) * tbi;
       s1 += ta[i] * f2[i] * tbi;
+      if (do_tau) {
+        s0 += da[i] * dbb[i] * f4[i];
+        s2 += ta[i] * tbi * f3[i];
+      }
     }
     GA[Q * AA + (size_t)a * A + b] = s0;
     if (do_grad) GB[Q * AA + (size_t)a * A + b] = s1;
+    if (do_tau) GC[Q * AA + (size_t)a * A + b] = s2;
   }
 }
 
 // X5 radial expansion into the compact Fock blocks:
 //    Hc[x][y][e][n'][n] = sum_q B_n B_n' (GA_xy + GA_yx) + B'_n B_n' GB_xy + B_n B'_n' GB_yx
+//    meta-GGA: + B'_n B'_n' (GC_xy + GC_yx)
 __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__restrict__ GB,
-                                 const double *__restrict__ B, const double *__restrict__ dB, int A, int E, int p,
-                                 int nq, int do_grad, int rank, int nranks, double *__restrict__ Hc) {
-  extern __shared__ double sh[];  // gs[nq], g1[nq], g2[nq]
+                                 const double *__restrict__ GC, const double *__restrict__ B,
+                                 const double *__restrict__ dB, int A, int E, int p, int nq, int do_grad, int do_tau,
+                                 int rank, int nranks, double *__restrict__ Hc) {
+  extern __shared__ double sh[];  // gs[nq], g1[nq], g2[nq], g3[nq]
   int xy = blockIdx.x, e = blockIdx.y;
   int x = xy / A, y = xy % A;
   int yx = y * A + x;
   size_t AA = (size_t)A * A;
-  double *gs = sh, *g1 = sh + nq, *g2 = sh + 2 * nq;
+  double *gs = sh, *g1 = sh + nq, *g2 = sh + 2 * nq, *g3 = sh + 3 * nq;
   for (int q = threadIdx.x; q < nq; q += blockDim.x) {
     size_t Q = (size_t)e * nq + q;
     bool own = ((int)(Q % nranks) == rank);
     gs[q] = own ? GA[Q * AA + xy] + GA[Q * AA + yx] : 0.0;
     g1[q] = (own && do_grad) ? GB[Q * AA + xy] : 0.0;
     g2[q] = (own && do_grad) ? GB[Q * AA + yx] : 0.0;
+    g3[q] = (own && do_tau) ? GC[Q * AA + xy] + GC[Q * AA + yx] : 0.0;
   }
   __syncthreads();
   int pp = p * p;
@@ -684,7 +752,7 @@ __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__
     for (int q = 0; q < nq; q++) {
       const double *b = B + ((size_t)e * nq + q) * p;
       const double *db = dB + ((size_t)e * nq + q) * p;
-      acc += b[n] * b[m] * gs[q] + db[n] * b[m] * g1[q] + b[n] * db[m] * g2[q];
+      acc += b[n] * b[m] * gs[q] + db[n] * b[m] * g1[q] + b[n] * db[m] * g2[q] + db[n] * db[m] * g3[q];
     }
     Hc[((size_t)xy * E + e) * pp + t] = acc;
   }
@@ -692,14 +760,15 @@ __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__
 
 __global__ void k_xc_sum_partials(const double *__restrict__ partial, size_t NQ, double *__restrict__ scal) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double nel = 0.0, exc = 0.0;
+    double nel = 0.0, exc = 0.0, kin = 0.0;
     for (size_t q = 0; q < NQ; q++) {
       nel += partial[q];
       exc += partial[NQ + q];
+      kin += partial[2 * NQ + q];
     }
     scal[0] = exc;  // Exc
     scal[1] = nel;  // Nel
-    scal[2] = 0.0;  // Ekin (tau only integrated for meta-GGAs)
+    scal[2] = kin;  // Ekin = integral of tau (zero unless a meta-GGA asked for tau; dftgrid.cpp:227-240)
   }
 }
 
@@ -710,7 +779,7 @@ static int round_up64(int n) { return ((n + 63) / 64) * 64; }
 
 struct FockAux {
   DevBuf<int> pure_shell, pure_n, lmpos;
-  DevBuf<double> Pc, Jc, Pc2, Jc2, Paux, Y, Jaux, D0, D1, V, Fo, GA, GB, partial, scal;
+  DevBuf<double> Pc, Jc, Pc2, Jc2, Paux, Y, Jaux, D0, D1, D2, V, Fo, GA, GB, GC, partial, scal;
 };
 
 static std::map<hfg_dev_tables *, FockAux *> g_aux;
@@ -820,32 +889,40 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   const int A = t->A, E = t->E, p = t->p, nq = t->nq, G = t->G, nth = t->ntheta, nphi = t->nphi;
   const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
   int do_grad = ((x_func > 0 && xc::is_gga(x_func)) || (c_func > 0 && xc::is_gga(c_func))) ? 1 : 0;
+  int do_tau = ((x_func > 0 && xc::is_mgga(x_func)) || (c_func > 0 && xc::is_mgga(c_func))) ? 1 : 0;
   a.D0.resize(NQ * AA);
   a.D1.resize(NQ * AA);
   a.GA.resize(NQ * AA);
   a.GB.resize(NQ * AA);
+  if (do_tau) {
+    a.D2.resize(NQ * AA);
+    a.GC.resize(NQ * AA);
+  }
   const size_t nv = NQ * G * G * nth;
-  a.V.resize(3 * nv);
-  a.Fo.resize(3 * nv);
-  a.partial.resize(2 * NQ);
+  a.V.resize(5 * nv);
+  a.Fo.resize(5 * nv);
+  a.partial.resize(3 * NQ);
   int maxgrp = 0;
   for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
 
   hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(std::min(256, round_up64(nq))), p * p * sizeof(double),
-                     ctx->stream, dPc, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank, ctx->shard_n, a.D0.p, a.D1.p);
+                     ctx->stream, dPc, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau, ctx->shard_rank, ctx->shard_n, a.D0.p,
+                     a.D1.p, a.D2.p);
   hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
-                     2 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, t->Th.p, t->dTh.p, A, nth, G,
-                     t->grp_off.p, t->grp_shell.p, do_grad, NQ, ctx->shard_rank, ctx->shard_n, a.V.p);
-  size_t shb = (size_t)(4 * nth * nphi + 2 * 4) * sizeof(double);
+                     3 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, a.D2.p, t->Th.p, t->dTh.p, A, nth, G,
+                     t->grp_off.p, t->grp_shell.p, do_grad, do_tau, NQ, ctx->shard_rank, ctx->shard_n, a.V.p);
+  size_t shb = (size_t)(5 * nth * nphi + 3 * 4) * sizeof(double);
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   hipLaunchKernelGGL(k_xc_grid, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
-                     x_func, c_func, do_grad, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
-  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 3 * nth * sizeof(double), ctx->stream,
-                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p);
-  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 3 * nq * sizeof(double),
-                     ctx->stream, a.GA.p, a.GB.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank, ctx->shard_n, dHc);
+                     x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
+  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 5 * nth * sizeof(double), ctx->stream,
+                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, NQ,
+                     ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
+  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 4 * nq * sizeof(double),
+                     ctx->stream, a.GA.p, a.GB.p, a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
+                     ctx->shard_rank, ctx->shard_n, dHc);
   hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
   HFG_HIP_CHECK(hipGetLastError());
 }
@@ -871,6 +948,8 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
   if (!t->have_xc) throw std::runtime_error("XC grid tables were not uploaded (hfg_basis_upload with ldft,mdft > 0)\n");
   if ((x_func > 0 && !xc::is_supported(x_func)) || (c_func > 0 && !xc::is_supported(c_func)))
     throw std::runtime_error("Functional not found!");
+  if ((x_func > 0 && xc::is_mgga(x_func)) || (c_func > 0 && xc::is_mgga(c_func)))
+    throw std::runtime_error("meta-GGAs are implemented for spin-restricted runs only\n");
   FockAux &a = aux_for(ctx, basis);
   const int A = t->A, E = t->E, p = t->p, nq = t->nq, G = t->G, nth = t->ntheta, nphi = t->nphi;
   const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
@@ -882,16 +961,17 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
   const size_t nv = NQ * G * G * nth;
   a.V.resize(6 * nv);
   a.Fo.resize(6 * nv);
-  a.partial.resize(2 * NQ);
+  a.partial.resize(3 * NQ);
   int maxgrp = 0;
   for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
   for (int sp = 0; sp < 2; sp++) {
     hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(std::min(256, round_up64(nq))), p * p * sizeof(double),
-                       ctx->stream, sp ? dPcb : dPca, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank,
-                       ctx->shard_n, a.D0.p, a.D1.p);
+                       ctx->stream, sp ? dPcb : dPca, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, 0, ctx->shard_rank,
+                       ctx->shard_n, a.D0.p, a.D1.p, (double *)nullptr);
     hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
-                       2 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, t->Th.p, t->dTh.p, A, nth, G,
-                       t->grp_off.p, t->grp_shell.p, do_grad, NQ, ctx->shard_rank, ctx->shard_n, a.V.p + (size_t)sp * 3 * nv);
+                       3 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, (const double *)nullptr, t->Th.p, t->dTh.p,
+                       A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, 0, NQ, ctx->shard_rank, ctx->shard_n,
+                       a.V.p + (size_t)sp * 3 * nv);
   }
   size_t shb = (size_t)(8 * nth * nphi + 2 * 4) * sizeof(double);
   if (shb > 160 * 1024) throw std::runtime_error("XC angular grid too large for the polarised grid kernel's LDS tile");
@@ -901,12 +981,12 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
                      x_func, c_func, do_grad, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
   for (int sp = 0; sp < 2; sp++) {
-    hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 3 * nth * sizeof(double), ctx->stream,
+    hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 5 * nth * sizeof(double), ctx->stream,
                        a.Fo.p + (size_t)sp * 3 * nv, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad,
-                       NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p);
-    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 3 * nq * sizeof(double),
-                       ctx->stream, a.GA.p, a.GB.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, ctx->shard_rank,
-                       ctx->shard_n, sp ? dHcb : dHca);
+                       0, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, (double *)nullptr);
+    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 4 * nq * sizeof(double),
+                       ctx->stream, a.GA.p, a.GB.p, (const double *)nullptr, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, 0,
+                       ctx->shard_rank, ctx->shard_n, sp ? dHcb : dHca);
   }
   hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
   HFG_HIP_CHECK(hipGetLastError());

@@ -115,9 +115,9 @@ __host__ __device__ inline Dual eps_gga_c_pbe(Dual rho, Dual sigma) {
   return ec + H;
 }
 
-__host__ __device__ inline bool is_gga(int id) { return id == 101 || id == 130 || id == 406; }
+__host__ __device__ inline bool is_gga(int id) { return id == 101 || id == 130 || id == 406 || id == 202 || id == 231; }
 __host__ __device__ inline bool is_supported(int id) {
-  return id == 1 || id == 7 || id == 12 || id == 101 || id == 130 || id == 406;
+  return id == 1 || id == 7 || id == 12 || id == 101 || id == 130 || id == 406 || id == 202 || id == 231;
 }
 
 /// adds functional id's exc (per particle), vrho, vsigma at one point; rho >= threshold assumed
@@ -294,6 +294,78 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
   vsaa += en.s;
   vsab += 2.0 * en.s;
   vsbb += en.s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// meta-GGA (tau-dependent), spin-unpolarised: TPSS exchange (libxc id 202) and correlation (231).  The T3 slots
+// (a, b, s) carry the derivatives with respect to (rho, sigma, tau) here.
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ inline T3 tmaxv(T3 x, T3 y) { return (x.v >= y.v) ? x : y; }
+
+__host__ __device__ inline T3 mg_eps_tpss_x(T3 rho, T3 sig, T3 tau) {
+  const double b = 0.40, c = 1.59096, e = 1.537, kappa = 0.804, mu = 0.21951, muge = 10.0 / 81.0;
+  const double c32 = 9.570780000627305;  // (3 pi^2)^{2/3}
+  T3 exu = (-0.75 * cbrt(3.0 / HFG_PI)) * tcbrt(rho);
+  T3 rho23 = tpow23(rho);
+  T3 pp = sig / ((4.0 * c32) * rho * rho * rho23);
+  T3 tauw = sig / (8.0 * rho);
+  T3 tt = tmaxv(tau, tauw);
+  T3 z = tauw / tt;
+  T3 tunif = (0.3 * c32) * rho * rho23;
+  T3 alpha = (tt - tauw) / tunif;
+  T3 qb = (9.0 / 20.0) * (alpha - 1.0) / tsqrt(1.0 + b * alpha * (alpha - 1.0)) + (2.0 / 3.0) * pp;
+  T3 z2 = z * z;
+  T3 opz2 = 1.0 + z2;
+  T3 num = (muge + c * z2 / (opz2 * opz2)) * pp + (146.0 / 2025.0) * qb * qb -
+           (73.0 / 405.0) * qb * tsqrt(0.5 * (9.0 / 25.0) * z2 + 0.5 * pp * pp) + (muge * muge / kappa) * pp * pp +
+           (2.0 * sqrt(e) * muge * 9.0 / 25.0) * z2 + (e * mu) * pp * pp * pp;
+  T3 den = 1.0 + sqrt(e) * pp;
+  T3 x = num / (den * den);
+  T3 F = 1.0 + kappa - kappa * kappa / (kappa + x);
+  return exu * F;
+}
+
+__host__ __device__ inline T3 mg_eps_pbe_c_fullpol(T3 n, T3 sig) {
+  const double beta = 0.06672455060314922;
+  const double gamma = (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI);
+  const double B = beta / gamma;
+  T3 rs = tcbrt((3.0 / (4.0 * HFG_PI)) / n);
+  T3 ec = pol_pw_G(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+  const double phi = 0.7937005259840998, phi3 = 0.5;  // 2^{-1/3}
+  T3 kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
+  T3 ks2 = (4.0 / HFG_PI) * kf;
+  T3 t2 = sig / ((4.0 * phi * phi) * ks2 * n * n);
+  T3 Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
+  T3 At2 = Aa * t2;
+  return ec + (gamma * phi3) * tlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+}
+
+__host__ __device__ inline T3 mg_eps_tpss_c(T3 rho, T3 sig, T3 tau) {
+  const double d = 2.8, C0 = 0.53;
+  T3 rs = tcbrt((3.0 / (4.0 * HFG_PI)) / rho);
+  T3 epbe = pol_eps_pbe_c(rho, rs, t3(0.0), sig);
+  T3 esig = mg_eps_pbe_c_fullpol(0.5 * rho, 0.25 * sig);
+  T3 etil = tmaxv(esig, epbe);
+  T3 tauw = sig / (8.0 * rho);
+  T3 tt = tmaxv(tau, tauw);
+  T3 z = tauw / tt;
+  T3 z2 = z * z;
+  T3 rev = epbe * (1.0 + C0 * z2) - (1.0 + C0) * z2 * etil;
+  return rev * (1.0 + d * rev * z2 * z);
+}
+
+__host__ __device__ inline bool is_mgga(int id) { return id == 202 || id == 231; }
+
+/// adds a meta-GGA's exc, vrho, vsigma, vtau at one point (rho >= threshold assumed)
+__host__ __device__ inline void eval_add_mgga(int id, double rho, double sigma, double tau, double &exc, double &vrho,
+                                              double &vsigma, double &vtau) {
+  T3 r = t3(rho, 1.0, 0.0, 0.0), s = t3(fmax(sigma, 1e-40), 0.0, 1.0, 0.0), t = t3(fmax(tau, 1e-40), 0.0, 0.0, 1.0);
+  T3 e = (id == 202) ? mg_eps_tpss_x(r, s, t) : mg_eps_tpss_c(r, s, t);
+  T3 en = r * e;
+  exc += e.v;
+  vrho += en.a;
+  vsigma += en.b;
+  vtau += en.s;
 }
 
 }  // namespace xc

@@ -13,7 +13,7 @@ struct Known {
   int id;
 };
 const Known known[] = {{"lda_x", 1}, {"lda_c_vwn", 7}, {"lda_c_pw", 12}, {"gga_x_pbe", 101}, {"gga_c_pbe", 130},
-                       {"hyb_gga_xc_pbeh", 406}};  // PBE0: 0.75 gga_x_pbe + gga_c_pbe + 0.25 exact exchange
+                       {"hyb_gga_xc_pbeh", 406}, {"mgga_x_tpss", 202}, {"mgga_c_tpss", 231}};  // PBE0: 0.75 gga_x_pbe + gga_c_pbe + 0.25 exact exchange
 
 int find_func(const std::string &name) {
   if (name.empty()) throw std::runtime_error("empty functional name\n");

@@ -73,6 +73,10 @@ void atomic_eval_Fxc_pol(const helfem::atomic::TwoDBasis &b, int lang, int mang,
 // ids follow libxc: 1 = lda_x, 7 = lda_c_vwn (VWN5), 12 = lda_c_pw, 101 = gga_x_pbe, 130 = gga_c_pbe
 // exc: energy per particle; vrho = d(rho exc)/d rho; vsigma = d(rho exc)/d sigma
 bool xc_is_gga(int func_id);
+bool xc_is_mgga(int func_id);
+/// meta-GGA (tau-dependent), spin-unpolarised: 202 = mgga_x_tpss, 231 = mgga_c_tpss; vtau = d(rho exc)/d tau
+void xc_unpolarized_mgga(int func_id, size_t N, const double *rho, const double *sigma, const double *tau, double *exc,
+                         double *vrho, double *vsigma, double *vtau, double dens_threshold);
 void xc_unpolarized(int func_id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
                     double *vsigma, double dens_threshold);
 /// spin-polarised: rho[2N] = (a,b) per point, sigma[3N] = (aa,ab,bb) per point; exc[N] per particle of the total

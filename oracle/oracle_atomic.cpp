@@ -218,26 +218,29 @@ void atomic_eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_f
                      double &Nel, double &Ekin, double thr) {
   AtomicGridWorker grid(b, lang, mang);
   grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  grid.do_tau = (x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func));
   H.zeros(b.Nbf(), b.Nbf());
-  double exc = 0.0, nel = 0.0;
+  double exc = 0.0, nel = 0.0, ekin = 0.0;
   for (size_t iel = 0; iel < b.Nel(); iel++)
     for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
       grid.compute_bf(iel, irad);
       grid.update_density(P);
       nel += grid.compute_Nel();
+      ekin += grid.compute_Ekin();
       grid.compute_xc(x_func, c_func, thr);
       exc += grid.eval_Exc();
       grid.eval_Fxc(H);
     }
   Exc = exc;
   Nel = nel;
-  Ekin = 0.0;
+  Ekin = ekin;
 }
 
 void atomic_eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa, const Mat &Pb,
                          Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin, double thr) {
   AtomicGridWorker grid(b, lang, mang);
   grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  grid.do_tau = (x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func));
   Ha.zeros(b.Nbf(), b.Nbf());
   Hb.zeros(b.Nbf(), b.Nbf());
   double exc = 0.0, nel = 0.0;

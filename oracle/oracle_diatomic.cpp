@@ -291,9 +291,10 @@ void eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, co
               double &Nel, double &Ekin, double thr, long q_begin, long q_end, int shard_rank, int shard_n) {
   Mat H(b.Ndummy(), b.Ndummy());
   Mat P(b.expand_boundaries(P0));
-  double exc = 0.0, nel = 0.0;
+  double exc = 0.0, nel = 0.0, ekin = 0.0;
   GridWorker grid(b, lang, mang);
   grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  grid.do_tau = (x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func));
   long q = 0;
   for (size_t iel = 0; iel < b.Nel(); iel++)
     for (size_t irad = 0; irad < (size_t)b.nquad(); irad++, q++) {
@@ -302,13 +303,14 @@ void eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, co
       grid.compute_bf(iel, irad);
       grid.update_density(P);
       for (size_t ip = 0; ip < grid.Ng; ip++) nel += grid.wtot[ip] * grid.rho[ip];
+      ekin += grid.compute_Ekin();
       grid.compute_xc(x_func, c_func, thr);
       for (size_t ip = 0; ip < grid.Ng; ip++) exc += grid.wtot[ip] * grid.exc[ip] * grid.rho[ip];
       grid.eval_Fxc(H);
     }
   Exc = exc;
   Nel = nel;
-  Ekin = 0.0;  // only meta-GGAs integrate tau (dftgrid.cpp:227-240)
+  Ekin = ekin;  // only meta-GGAs integrate tau (dftgrid.cpp:227-240)
   Hout = b.remove_boundaries(H);
 }
 
@@ -319,6 +321,7 @@ void eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int c_func
   double exc = 0.0, nel = 0.0;
   GridWorker grid(b, lang, mang);
   grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
+  grid.do_tau = (x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func));
   for (size_t iel = 0; iel < b.Nel(); iel++)
     for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
       grid.compute_bf(iel, irad);

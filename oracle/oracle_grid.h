@@ -16,6 +16,8 @@ typedef std::complex<double> cplx;
 
 struct DenseGrid {
   bool do_grad = false, do_gga = false, polarized = false;
+  bool do_tau = false, do_mgga_t = false;  // kinetic energy density (restricted runs only)
+  Vec tau, vtau;
   std::vector<size_t> bf_ind;
   size_t ne = 0, Ng = 0;
   std::vector<cplx> bf, bf_rho, bf_theta, bf_phi;  // ne x Ng column-major
@@ -70,6 +72,30 @@ struct DenseGrid {
         double gr = grho[ip], gt = grho[Ng + ip], gp = grho[2 * Ng + ip];
         sigma[ip] = gr * gr + gt * gt + gp * gp;
       }
+    if (do_tau) {  // tau = 1/2 sum_c Re[(P conj(d_c bf)) . d_c bf] / h_c^2   (dftgrid.cpp:90-112)
+      tau.assign(Ng, 0.0);
+      const std::vector<cplx> *dbf[3] = {&bf_rho, &bf_theta, &bf_phi};
+      const Vec *sc[3] = {&scale_r, &scale_theta, &scale_phi};
+      std::vector<cplx> Pv(ne);
+      for (int c = 0; c < 3; c++)
+        for (size_t ip = 0; ip < Ng; ip++) {
+          const cplx *f = &(*dbf[c])[ip * ne];
+          for (size_t i = 0; i < ne; i++) Pv[i] = 0;
+          for (size_t j = 0; j < ne; j++) {
+            cplx cb = std::conj(f[j]);
+            for (size_t i = 0; i < ne; i++) Pv[i] += P(i, j) * cb;
+          }
+          cplx k(0);
+          for (size_t i = 0; i < ne; i++) k += Pv[i] * f[i];
+          tau[ip] += 0.5 * k.real() / ((*sc[c])[ip] * (*sc[c])[ip]);
+        }
+    }
+  }
+  double compute_Ekin() const {
+    double e = 0.0;
+    if (do_tau && !polarized)
+      for (size_t ip = 0; ip < Ng; ip++) e += wtot[ip] * tau[ip];
+    return e;
   }
 
   void update_density(const Mat &Padummy, const Mat &Pbdummy) {
@@ -108,11 +134,19 @@ struct DenseGrid {
     vxc.assign(nr * Ng, 0.0);
     vsigma.assign(ns * Ng, 0.0);
     do_gga = false;
+    do_mgga_t = false;
+    vtau.assign(Ng, 0.0);
     Vec e(Ng), v(nr * Ng), vs(ns * Ng);
     for (int id : {x_func, c_func}) {
       if (id <= 0) continue;
       do_gga = do_gga || xc_is_gga(id);
-      if (polarized)
+      if (xc_is_mgga(id)) {
+        if (polarized) throw std::logic_error("meta-GGAs are implemented for spin-restricted runs only\n");
+        Vec vt(Ng);
+        xc_unpolarized_mgga(id, Ng, rho.data(), sigma.data(), tau.data(), e.data(), v.data(), vs.data(), vt.data(), thr);
+        for (size_t i = 0; i < Ng; i++) vtau[i] += vt[i];
+        do_mgga_t = true;
+      } else if (polarized)
         xc_polarized(id, Ng, rho.data(), do_grad ? sigma.data() : nullptr, e.data(), v.data(), vs.data(), thr);
       else
         xc_unpolarized(id, Ng, rho.data(), do_grad ? sigma.data() : nullptr, e.data(), v.data(), vs.data(), thr);
@@ -161,6 +195,18 @@ struct DenseGrid {
         gr[2 * Ng + ip] = grho[2 * Ng + ip] * 2.0 * wtot[ip] * vsigma[ip] / scale_phi[ip];
       }
       increment_gga(H, gr);
+    }
+    if (do_mgga_t) {  // dftgrid.cpp:533-540
+      Vec v0(Ng), v1(Ng), v2(Ng);
+      for (size_t ip = 0; ip < Ng; ip++) {
+        double vt = 0.5 * wtot[ip] * vtau[ip];
+        v0[ip] = vt / (scale_r[ip] * scale_r[ip]);
+        v1[ip] = vt / (scale_theta[ip] * scale_theta[ip]);
+        v2[ip] = vt / (scale_phi[ip] * scale_phi[ip]);
+      }
+      increment_lda(H, v0, bf_rho);
+      increment_lda(H, v1, bf_theta);
+      increment_lda(H, v2, bf_phi);
     }
     scatter_add(Hdummy, H);
   }

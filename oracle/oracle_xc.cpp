@@ -109,7 +109,7 @@ void gga_c_pbe(double rho, double sigma, double &exc, double &vrho, double &vsig
 }
 }  // namespace
 
-bool xc_is_gga(int id) { return id == 101 || id == 130 || id == 406; }
+bool xc_is_gga(int id) { return id == 101 || id == 130 || id == 406 || id == 202 || id == 231; }  // needs the gradient
 
 void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
                     double *vsigma, double thr) {
@@ -318,6 +318,82 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// meta-GGA: TPSS exchange and correlation, spin-unpolarised (libxc mgga_x_tpss = 202, mgga_c_tpss = 231;
+// Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401).  Variables of the D3 type here: (rho, sigma, tau).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+inline D3 Dmax(D3 a, D3 b) { return (a.v >= b.v) ? a : b; }
+
+D3 eps_tpss_x(D3 rho, D3 sig, D3 tau) {
+  const double b = 0.40, c = 1.59096, e = 1.537, kappa = 0.804, mu = 0.21951, muge = 10.0 / 81.0;
+  D3 exu = (-0.75 * cbrt(3.0 / PI)) * Dcbrt(rho);
+  D3 rho83 = rho * rho * Dpow23(rho);
+  D3 pp = sig / ((4.0 * pow(3.0 * PI * PI, 2.0 / 3.0)) * rho83);  // p = s^2
+  D3 tauw = sig / (8.0 * rho);
+  D3 tt = Dmax(tau, tauw);                                         // tau >= tau_W
+  D3 z = tauw / tt;
+  D3 tunif = (0.3 * pow(3.0 * PI * PI, 2.0 / 3.0)) * rho * Dpow23(rho);
+  D3 alpha = (tt - tauw) / tunif;
+  D3 qb = (9.0 / 20.0) * (alpha - 1.0) / Dsqrt(1.0 + b * alpha * (alpha - 1.0)) + (2.0 / 3.0) * pp;
+  D3 z2 = z * z;
+  D3 opz2 = 1.0 + z2;
+  D3 num = (muge + c * z2 / (opz2 * opz2)) * pp + (146.0 / 2025.0) * qb * qb -
+           (73.0 / 405.0) * qb * Dsqrt(0.5 * (9.0 / 25.0) * z2 + 0.5 * pp * pp) + (muge * muge / kappa) * pp * pp +
+           (2.0 * sqrt(e) * muge * 9.0 / 25.0) * z2 + (e * mu) * pp * pp * pp;
+  D3 den = 1.0 + sqrt(e) * pp;
+  D3 x = num / (den * den);
+  D3 F = 1.0 + kappa - kappa * kappa / (kappa + x);
+  return exu * F;
+}
+
+// PBE correlation of a fully spin-polarised density n (zeta = 1), gradient invariant sig
+D3 eps_pbe_c_fullpol(D3 n, D3 sig) {
+  const double beta = 0.06672455060314922, gamma = (1.0 - log(2.0)) / (PI * PI), B = beta / gamma;
+  D3 rs = Dcbrt((3.0 / (4.0 * PI)) / n);
+  D3 ec = pw_G(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);  // pw_mod, ferromagnetic set
+  const double phi = cbrt(0.5), phi3 = 0.5;                                 // ((1+1)^{2/3} + 0)/2 = 2^{-1/3}
+  D3 kf = Dcbrt((3.0 * PI * PI) * n);
+  D3 ks2 = (4.0 / PI) * kf;
+  D3 t2 = sig / ((4.0 * phi * phi) * ks2 * n * n);
+  D3 A = B / (Dexp(-ec / (gamma * phi3)) - 1.0);
+  D3 At2 = A * t2;
+  return ec + (gamma * phi3) * Dlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+}
+
+D3 eps_tpss_c(D3 rho, D3 sig, D3 tau) {
+  const double d = 2.8, C0 = 0.53;
+  D3 rs = Dcbrt((3.0 / (4.0 * PI)) / rho);
+  D3 epbe = eps_pbe_c(rho, rs, C(0.0), sig);
+  D3 esig = eps_pbe_c_fullpol(0.5 * rho, 0.25 * sig);  // each spin channel on its own
+  D3 etil = Dmax(esig, epbe);
+  D3 tauw = sig / (8.0 * rho);
+  D3 tt = Dmax(tau, tauw);
+  D3 z = tauw / tt;
+  D3 z2 = z * z;
+  D3 rev = epbe * (1.0 + C0 * z2) - (1.0 + C0) * z2 * etil;
+  return rev * (1.0 + d * rev * z2 * z);
+}
+}  // namespace
+
+bool xc_is_mgga(int id) { return id == 202 || id == 231; }
+
+void xc_unpolarized_mgga(int id, size_t N, const double *rho, const double *sigma, const double *tau, double *exc,
+                         double *vrho, double *vsigma, double *vtau, double thr) {
+  for (size_t i = 0; i < N; i++) {
+    exc[i] = vrho[i] = vsigma[i] = vtau[i] = 0.0;
+    double r = rho[i];
+    if (!(r >= thr) || r <= 0.0) continue;
+    D3 R = var(r, 0), S = var(std::max(sigma[i], 1e-40), 1), T = var(std::max(tau[i], 1e-40), 2);
+    D3 e = (id == 202) ? eps_tpss_x(R, S, T) : eps_tpss_c(R, S, T);
+    D3 en = R * e;
+    exc[i] = e.v;
+    vrho[i] = en.d[0];
+    vsigma[i] = en.d[1];
+    vtau[i] = en.d[2];
+  }
+}
+
 static int find_func(const std::string &name) {
   if (isdigit(name[0])) return atoi(name.c_str());
   if (!strcasecmp(name.c_str(), "none")) return 0;
@@ -328,6 +404,8 @@ static int find_func(const std::string &name) {
   if (!strcasecmp(name.c_str(), "gga_x_pbe")) return 101;
   if (!strcasecmp(name.c_str(), "gga_c_pbe")) return 130;
   if (!strcasecmp(name.c_str(), "hyb_gga_xc_pbeh")) return 406;
+  if (!strcasecmp(name.c_str(), "mgga_x_tpss")) return 202;
+  if (!strcasecmp(name.c_str(), "mgga_c_tpss")) return 231;
   std::ostringstream oss;
   oss << "\nError: functional " << name << " is not available in this build!\n";
   throw std::runtime_error(oss.str());

@@ -380,6 +380,8 @@ ATOMIC_LITERATURE = [
     ("He_LDA", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -2.834836, 1e-6),
     ("Ne_LDA", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -128.233481, 1e-6),
     ("He_PBE0", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh"), -2.895178, 2e-6),
+    ("He_TPSS", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="mgga_x_tpss-mgga_c_tpss"), -2.9097, 1e-4),
+    ("Be_TPSS", dict(Z=4, lmax=0, mmax=0, nelem=5, nnodes=15, method="mgga_x_tpss-mgga_c_tpss"), -14.6717, 2e-4),
 ]
 
 

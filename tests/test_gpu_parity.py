@@ -146,7 +146,8 @@ def test_exchange_shards_sum_to_full(case, hf, nranks):
     assert common.relerr(acc, full) < 1e-12, name
 
 
-@pytest.mark.parametrize("funcs", [(1, 7), (1, 0), (101, 130), (101, 0), (0, 130), (1, 12), (406, 0)])
+@pytest.mark.parametrize("funcs", [(1, 7), (1, 0), (101, 130), (101, 0), (0, 130), (1, 12), (406, 0), (202, 231), (202, 0),
+                                   (0, 231), (202, 130)])
 def test_xc_parity(case, hf, funcs):
     import common
     name, gb, ob, ldft, mdft = case
@@ -156,11 +157,15 @@ def test_xc_parity(case, hf, funcs):
         if tag == "general":
             # a general random P is not positive on the grid: scale it down onto a positive block-diagonal part
             P = 0.05 * P + list(_densities(gb))[1][1]
-        H, Exc, Nel, _ = grid.eval_Fxc(x, c, P)
-        Ho, Exco, Nelo, _ = ob.eval_Fxc(ldft, mdft, x, c, P)
+        H, Exc, Nel, Ekin = grid.eval_Fxc(x, c, P)
+        Ho, Exco, Nelo, Ekino = ob.eval_Fxc(ldft, mdft, x, c, P)
         assert abs(Nel - Nelo) < 1e-11 * max(1.0, abs(Nelo)), (name, tag, Nel, Nelo)
         assert abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco)), (name, tag, Exc, Exco)
         assert common.relerr(H, Ho) < 1e-10, (name, tag, funcs, common.relerr(H, Ho))
+        # meta-GGAs also integrate the kinetic energy density (DFTGrid::eval_Fxc returns it as Ekin)
+        assert abs(Ekin - Ekino) < 1e-10 * max(1.0, abs(Ekino)), (name, tag, Ekin, Ekino)
+        if x in (202,) or c in (231,):
+            assert Ekino > 0.0
 
 
 def test_eig_gsym_sub_parity(case, hf):
@@ -363,7 +368,7 @@ def test_atomic_exchange_parity(acase):
         assert common.relerr(K, Ko) < 1e-12, (name, tag, common.relerr(K, Ko))
 
 
-@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (101, 0), (0, 130), (1, 12)])
+@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (101, 0), (0, 130), (1, 12), (202, 231)])
 def test_atomic_xc_parity(acase, hf, funcs):
     import common
     name, gb, ob, ldft, mdft = acase
@@ -483,6 +488,9 @@ ATOMIC_SCF_CASES = [
     ("Ne_LDA", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -128.233481, 2e-6),
     # global hybrid: J + 0.25 K + XC in one Fock build (hyb_gga_xc_pbeh = PBE0)
     ("He_PBE0", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh"), -2.895178, 2e-6),
+    # meta-GGA (tau): TPSS, total energies of Staroverov et al., PRB 69, 075102, Table (4 decimals)
+    ("He_TPSS", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="mgga_x_tpss-mgga_c_tpss"), -2.9097, 1e-4),
+    ("Ne_TPSS", dict(Z=10, lmax=1, mmax=1, nelem=4, nnodes=12, method="mgga_x_tpss-mgga_c_tpss"), -128.9811, 2e-4),
 ]
 
 
@@ -502,6 +510,7 @@ def test_atomic_scf_energy_parity(hf, name, kw, lit, littol):
 # end-to-end SCF: converged total energies, GPU vs oracle on identical grids (north-star bar: 1e-8 Eh)
 # ---------------------------------------------------------------------------------------------------
 SCF_CASES = [
+    ("N2_TPSS_small", dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[4, 3], nelem=3, nnodes=8, method="mgga_x_tpss-mgga_c_tpss"), None, None),
     ("N2_PBE0_small", dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[4, 3], nelem=3, nnodes=8, method="hyb_gga_xc_pbeh"), None, None),
     # BASELINE config 3: diatomic H2 at R=1.4, HF, small (mu,nu) grid
     ("H2_HF", dict(Z1=1, Z2=1, Rbond=1.4, lmmax=[6], nelem=3, nnodes=10, method="HF"), -1.13362957, 2e-7),
