@@ -70,6 +70,12 @@ def lib():
         L.hfg_theta_lm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double]
         L.hfg_legendre_PQ.restype = None
         L.hfg_legendre_PQ.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, c_double_p, c_double_p]
+        for nm in ("hfg_bessel_il", "hfg_bessel_kl"):
+            getattr(L, nm).restype = ctypes.c_double
+            getattr(L, nm).argtypes = [ctypes.c_double, ctypes.c_int]
+        L.hfg_erfc_phi.restype = ctypes.c_double
+        L.hfg_erfc_phi.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double]
+        L.hfg_compute_rs_tei.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
         L.hfg_chebyshev_rule.restype = None
         L.hfg_chebyshev_rule.argtypes = [ctypes.c_int, c_double_p, c_double_p]
         L.hfg_lobatto_nodes.restype = None
@@ -320,6 +326,24 @@ class AtomicTwoDBasis(TwoDBasis):
         _check(lib().hfg_basis_dims(self.h, *[ctypes.byref(x) for x in dims]))
         self._Nbf, self._Ndummy, self._Nrad, self._Nang, self._Nel = [x.value for x in dims]
 
+    def compute_yukawa(self, lam):
+        """TwoDBasis::compute_yukawa (src/atomic/TwoDBasis.cpp:741): tables of exp(-lambda r12)/r12 (host)"""
+        _check(lib().hfg_compute_rs_tei(self.h, 1, float(lam)))
+        self._uploaded = None
+
+    def compute_erfc(self, mu):
+        """TwoDBasis::compute_erfc (src/atomic/TwoDBasis.cpp:780): tables of erfc(mu r12)/r12 (host)"""
+        _check(lib().hfg_compute_rs_tei(self.h, 2, float(mu)))
+        self._uploaded = None
+
+    def rs_exchange(self, P):
+        """TwoDBasis::rs_exchange (src/atomic/TwoDBasis.cpp:1142) on the GPU"""
+        ctx = self._ensure()
+        P = _f(P)
+        K = np.zeros_like(P, order="F")
+        _check(lib().hfg_rs_exchange(ctx.h, self.h, _p(P), _p(K)))
+        return K
+
 
 class DFTGrid(object):
     """diatomic::dftgrid::DFTGrid (dftgrid.cpp:760)."""
@@ -444,6 +468,18 @@ def legendre_PQ(Lmax, Mmax, xi):
     Q = np.zeros((Mmax + 1, Lmax + 1))
     lib().hfg_legendre_PQ(int(Lmax), int(Mmax), float(xi), _p(P), _p(Q))
     return P.T.copy(), Q.T.copy()
+
+
+def bessel_il(x, L):
+    return lib().hfg_bessel_il(float(x), int(L))
+
+
+def bessel_kl(x, L):
+    return lib().hfg_bessel_kl(float(x), int(L))
+
+
+def erfc_phi(n, Xi, xi):
+    return lib().hfg_erfc_phi(int(n), float(Xi), float(xi))
 
 
 def theta_lm(l, m, cth):

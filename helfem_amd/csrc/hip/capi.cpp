@@ -13,7 +13,7 @@ void set_error(const std::string &msg) { g_err = msg; }
 void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr);
-void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false);
 void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
                      double *dHa, double *dHb, double *dScal, double thr);
 void fock_release(hfg_dev_tables *t);
@@ -248,6 +248,11 @@ int hfg_basis_destroy(hfg_basis *b) {
     exchange_lr_release(b->dev);
     delete b->dev;
   }
+  if (b->dev_rs) {
+    exchange_release(b->dev_rs);
+    exchange_lr_release(b->dev_rs);
+    delete b->dev_rs;
+  }
   delete b;
   HFG_CATCH
 }
@@ -301,6 +306,15 @@ int hfg_compute_tei(hfg_basis *b, int exchange) {
   HFG_CATCH
 }
 
+int hfg_compute_rs_tei(hfg_basis *b, int rs_kind, double omega) {
+  HFG_TRY
+  if (b->kind == 0) throw std::logic_error("Range separated functionals are not supported.\n");  // diatomic/main.cpp:393
+  if (rs_kind == 1) b->ab.compute_yukawa(omega);
+  else if (rs_kind == 2) b->ab.compute_erfc(omega);
+  else throw std::logic_error("unknown range-separation kernel (1 = Yukawa, 2 = erfc)\n");
+  HFG_CATCH
+}
+
 int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *b, int exchange) {
   HFG_TRY
   (void)exchange;  // the exchange-ordered copies are made on the device when the exchange kernels first need them
@@ -341,6 +355,9 @@ double hfg_modified_gaunt_coefficient(int lj, int mj, int L, int M, int li, int 
 }
 void hfg_legendre_PQ(int Lmax, int Mmax, double xi, double *P, double *Q) { helfem::legendre_PQ(Lmax, Mmax, xi, P, Q); }
 double hfg_theta_lm(int l, int m, double cth) { return helfem::theta_lm(l, m, cth); }
+double hfg_bessel_il(double x, int L) { return helfem::bessel_il(x, L); }
+double hfg_bessel_kl(double x, int L) { return helfem::bessel_kl(x, L); }
+double hfg_erfc_phi(int n, double Xi, double xi) { return helfem::erfc_Phi(n, Xi, xi); }
 void hfg_chebyshev_rule(int n, double *x, double *w) {
   helfem::Vec xv, wv;
   helfem::chebyshev_rule(n, xv, wv);
@@ -360,6 +377,13 @@ int hfg_basis_upload(hfg_ctx *ctx, hfg_basis *b, int ldft, int mdft) {
     exchange_lr_release(b->dev);
   }
   upload_tables(ctx, b, ldft, mdft);
+  if (b->dev_rs) {
+    exchange_release(b->dev_rs);
+    exchange_lr_release(b->dev_rs);
+    delete b->dev_rs;
+    b->dev_rs = nullptr;
+  }
+  if (b->kind == 1 && b->ab.rs_kind) upload_rs_tables(ctx, b);
   HFG_CATCH
 }
 
@@ -370,6 +394,10 @@ int hfg_coulomb_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, double *dJ) {
 }
 int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, double *dK) {
   HFG_TRY exchange_dev(ctx, b, dP, dK);
+  HFG_CATCH
+}
+int hfg_rs_exchange_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, double *dK) {
+  HFG_TRY exchange_dev(ctx, b, dP, dK, true);
   HFG_CATCH
 }
 int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *dP, double *dH, double *dScal,
@@ -437,6 +465,16 @@ int hfg_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dK = st.alloc(N * N);
   exchange_dev(ctx, b, dP, dK);
+  st.down(K, dK, N * N);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_rs_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
+  HFG_TRY
+  size_t N = b->Nbf();
+  Stage st(ctx);
+  double *dP = st.up(P, N * N), *dK = st.alloc(N * N);
+  exchange_dev(ctx, b, dP, dK, true);
   st.down(K, dK, N * N);
   st.sync();
   HFG_CATCH

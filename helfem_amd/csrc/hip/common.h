@@ -87,6 +87,7 @@ struct hfg_basis {
   helfem::diatomic::TwoDBasis b;
   helfem::atomic::TwoDBasis ab;
   hfg_dev_tables *dev = nullptr;
+  hfg_dev_tables *dev_rs = nullptr;  // range-separated exchange kernel (atomic), see tables.h
   int dev_device = -1;
   // primitive in-element integral tables built on the device (hip/tei_dev.hip) instead of host Mats
   hfg::DevBuf<double> dev_tei;

@@ -109,7 +109,7 @@ __global__ void k_ex_R(const double *__restrict__ U, int R, int A, int nchan, co
 // EXc/EXd: radial stage for output block (j,k), element pair (iel,jel)
 __global__ void k_ex_radial(const double *__restrict__ Rm, const int *__restrict__ couple,
                             const double *__restrict__ tei, const double *__restrict__ disj, int R, int E, int p,
-                            int Nlm, int ntt, double *__restrict__ Kc /* [A][E][E][p*p] */) {
+                            int Nlm, int ntt, int pair_tei, double *__restrict__ Kc /* [A][E][E][p*p] */) {
   extern __shared__ double sh[];  // T[p*p]
   int k = blockIdx.x;
   int iel = blockIdx.y / E, jel = blockIdx.y % E;
@@ -126,12 +126,14 @@ __global__ void k_ex_radial(const double *__restrict__ Rm, const int *__restrict
     if (!couple[k * Nlm + ilm]) continue;
     const double *R00 = Rm + (((size_t)k * Nlm + ilm) * ntt) * RR;
     const double *R02 = R00 + RR, *R20 = R00 + 2 * RR, *R22 = R00 + 3 * RR;  // only read when ntt == 4
-    if (iel == jel) {
+    if (iel == jel || pair_tei) {
       // Ksub(a,b) = sum_{i',l'} tei[(i' a),(b l')] R(i',l') :  ktei(b*p+a, l'*p+i') = tei(a*p+i', l'*p+b)
+      // pair_tei (erfc kernel, TwoDBasis.cpp:1262): every element pair has its own block, rows in iel, columns in jel
       if (inrange) {
         double s = 0.0;
         for (int tt = 0; tt < ntt; tt++) {
-          const double *T = tei + (((size_t)tt * Nlm + ilm) * E + iel) * (size_t)pp * pp;
+          const double *T = pair_tei ? tei + ((((size_t)tt * Nlm + ilm) * E + iel) * E + jel) * (size_t)pp * pp
+                                     : tei + (((size_t)tt * Nlm + ilm) * E + iel) * (size_t)pp * pp;
           const double *Rt = R00 + (size_t)tt * RR;
           for (int lp = 0; lp < p; lp++) {
             int gl = jfirst + lp;
@@ -225,8 +227,7 @@ void exchange_release(hfg_dev_tables *t) {
   }
 }
 
-static ExAux &exaux_for(hfg_ctx *ctx, hfg_basis *basis) {
-  hfg_dev_tables *t = basis->dev;
+static ExAux &exaux_for(hfg_ctx *ctx, hfg_dev_tables *t) {
   auto it = g_ex.find(t);
   if (it != g_ex.end()) return *it->second;
   ExAux *a = new ExAux();
@@ -270,20 +271,21 @@ static ExAux &exaux_for(hfg_ctx *ctx, hfg_basis *basis) {
   return *a;
 }
 
-bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, double *dK);
 
-void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK) {
-  if (!basis->dev || !basis->dev->have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
+// rs: the range-separated kernel of TwoDBasis::rs_exchange (src/atomic/TwoDBasis.cpp:1142) through basis->dev_rs
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs) {
+  hfg_dev_tables *t = rs ? basis->dev_rs : basis->dev;
+  if (!t || !t->have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
   if (basis->dev_device != ctx->device) throw std::logic_error("basis tables live on a different device\n");
-  hfg_dev_tables *t = basis->dev;
   ProfScope ps(ctx, "exchange");
   // fast path for the low-rank densities of SCF runs (exchange_lr.hip); HELFEM_EXCHANGE=general forces the
   // general kernels below, which take any symmetric P
   {
     const char *mode = getenv("HELFEM_EXCHANGE");
-    if (!(mode && std::string(mode) == "general") && exchange_lowrank_dev(ctx, basis, dP, dK)) return;
+    if (!(mode && std::string(mode) == "general") && exchange_lowrank_dev(ctx, t, dP, dK)) return;
   }
-  ExAux &a = exaux_for(ctx, basis);
+  ExAux &a = exaux_for(ctx, t);
   hipStream_t s = ctx->stream;
   const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, Nlm = t->Ntab, ntt = t->ntt;
   const size_t RR = (size_t)R * R;
@@ -310,7 +312,7 @@ void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK) 
                        a.chan_fac.p, t->shell_m.p, a.c0tab.p, a.c2tab.p, a.Lp1, Nlm, ntt, a.Rm.p, a.couple.p);
     int bs = std::max(64, ((p * p + 63) / 64) * 64);
     hipLaunchKernelGGL(k_ex_radial, dim3(A, E * E), dim3(bs), p * p * sizeof(double), s, a.Rm.p, a.couple.p, t->tei.p,
-                       t->disj.p, R, E, p, Nlm, ntt, a.Kc.p);
+                       t->disj.p, R, E, p, Nlm, ntt, t->pair_tei, a.Kc.p);
     hipLaunchKernelGGL(k_ex_assemble, dim3(A, R), dim3(128), 0, s, a.Kc.p, R, E, p, Nd, j, a.Kd.p);
   }
   hipLaunchKernelGGL(k_remove, dim3((N + 255) / 256, N), dim3(256), 0, s, a.Kd.p, N, Nd, a.pure_idx.p, dK);

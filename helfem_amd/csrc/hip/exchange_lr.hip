@@ -470,8 +470,8 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
 
 /// K from P through the low-rank factors.  Returns false (nothing written) when P is not reproduced by at most
 /// EXL_RMAX factors; the caller then runs the general kernels.
-bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK) {
-  hfg_dev_tables *t = basis->dev;
+bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, double *dK) {
+  if (t->pair_tei) return false;  // erfc kernel: no factorisation over elements, general kernels (exchange.hip)
   const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, NLM = t->NLM, Ntab = t->Ntab, ntt = t->ntt;
   if (N > 1024 * EXL_QMAX) return false;
   ExLRAux &a = exlr_for(ctx, t);

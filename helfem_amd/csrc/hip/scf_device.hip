@@ -18,7 +18,7 @@ namespace hfg {
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
-void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false);
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr);
 void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
@@ -30,6 +30,7 @@ void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                       const int64_t *blk_idx, double *dE, double *dC);
 void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
+void upload_rs_tables(hfg_ctx *ctx, hfg_basis *basis);
 void compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis);
 void fock_release(hfg_dev_tables *t);
 void exchange_release(hfg_dev_tables *t);
@@ -208,9 +209,12 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     for (DevBuf<double> *b : {&d.Cb, &d.Pb, &d.Fb}) b->resize(NN);
     d.Eb.resize(N);
   }
-  if (opt.kfrac != 0.0) {
+  const bool anyK = (opt.kfrac != 0.0 || opt.kshort != 0.0);
+  DevBuf<double> Krs;  // short-range exact exchange of the range-separated hybrids (atomic/main.cpp:768-769)
+  if (anyK) {
     d.Ka.resize(NN);
     if (!restr) d.Kb.resize(NN);
+    if (opt.omega != 0.0) Krs.resize(NN);
   }
   if (dft) {
     d.XCa.resize(NN);
@@ -254,12 +258,24 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   t0 = wall();
   if (hb->kind) hb->ab.compute_tei(opt.kfrac != 0.0);
   else compute_tei_dev(ctx, hb);  // in-element tables on the device (tei_dev.hip)
+  if (opt.omega != 0.0) {  // atomic/main.cpp:709-712
+    if (!hb->kind) throw std::logic_error("Range separated functionals are not supported.\n");
+    if (opt.rs_kind == 1) hb->ab.compute_yukawa(opt.omega);
+    else hb->ab.compute_erfc(opt.omega);
+  }
   if (hb->dev) {
     fock_release(hb->dev);
     exchange_release(hb->dev);
     exchange_lr_release(hb->dev);
   }
   upload_tables(ctx, hb, ldft, mdft);
+  if (hb->dev_rs) {
+    exchange_release(hb->dev_rs);
+    exchange_lr_release(hb->dev_rs);
+    delete hb->dev_rs;
+    hb->dev_rs = nullptr;
+  }
+  if (opt.omega != 0.0) upload_rs_tables(ctx, hb);
   if (verbose) printf("Done in %.6f\n", wall() - t0);
 
   std::vector<std::vector<double> > B;  // DIIS inner products of the stored errors, indexed by ring slot
@@ -283,15 +299,22 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
     res.tJ = wall() - tJ0;
     double tK0 = wall();
-    if (opt.kfrac != 0.0) {
-      exchange_dev(ctx, hb, d.Pa.p, d.Ka.p);
-      d.axpby(0.0, d.Ka.p, opt.kfrac, d.Ka.p, NN);  // Ka *= kfrac
-      if (!restr) {
-        if (nelb) {
-          exchange_dev(ctx, hb, d.Pb.p, d.Kb.p);
-          d.axpby(0.0, d.Kb.p, opt.kfrac, d.Kb.p, NN);
+    if (anyK) {
+      auto buildK = [&](const double *Ps, double *K) {  // K = kfrac K[1/r12] + kshort K[screened kernel]
+        if (opt.kfrac != 0.0) {
+          exchange_dev(ctx, hb, Ps, K);
+          d.axpby(0.0, K, opt.kfrac, K, NN);
         } else
-          HFG_HIP_CHECK(hipMemsetAsync(d.Kb.p, 0, sizeof(double) * NN, s));
+          HFG_HIP_CHECK(hipMemsetAsync(K, 0, sizeof(double) * NN, s));
+        if (opt.omega != 0.0) {
+          exchange_dev(ctx, hb, Ps, Krs.p, true);
+          d.axpby(opt.kshort, Krs.p, 1.0, K, NN);
+        }
+      };
+      buildK(d.Pa.p, d.Ka.p);
+      if (!restr) {
+        if (nelb) buildK(d.Pb.p, d.Kb.p);
+        else HFG_HIP_CHECK(hipMemsetAsync(d.Kb.p, 0, sizeof(double) * NN, s));
       }
       if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
     }
@@ -308,7 +331,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     d.dot(d.P.p, d.T.p, NN, 0);
     d.dot(d.P.p, d.V.p, NN, 1);
     d.dot(d.P.p, d.J.p, NN, 2);
-    if (opt.kfrac != 0.0) {
+    if (anyK) {
       d.dot(d.Pa.p, d.Ka.p, NN, 3);
       if (!restr) d.dot(d.Pb.p, d.Kb.p, NN, 4);
     }
@@ -318,7 +341,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       double *F = sp ? d.Fb.p : d.Fa.p;
       HFG_HIP_CHECK(hipMemcpyAsync(F, d.H0.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
       d.axpby(1.0, d.J.p, 1.0, F, NN);
-      if (opt.kfrac != 0.0) d.axpby(1.0, sp ? d.Kb.p : d.Ka.p, 1.0, F, NN);
+      if (anyK) d.axpby(1.0, sp ? d.Kb.p : d.Ka.p, 1.0, F, NN);
       if (dft) d.axpby(1.0, sp ? d.XCb.p : d.XCa.p, 1.0, F, NN);
       for (size_t gi = 0; gi < avg_idx.size(); gi++) {
         if (avg_idx[gi].empty()) continue;
@@ -378,12 +401,12 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     res.Epot = d.hres[1];
     res.Ecoul = 0.5 * d.hres[2];
     res.Exx = 0.0;
-    if (opt.kfrac != 0.0) res.Exx = restr ? d.hres[3] : 0.5 * d.hres[3] + 0.5 * d.hres[4];
+    if (anyK) res.Exx = restr ? d.hres[3] : 0.5 * d.hres[3] + 0.5 * d.hres[4];
     const double diiserr = d.hres[5];
     for (size_t k = 0; k < slots.size(); k++) B[slot][slots[k]] = B[slots[k]][slot] = d.hres[8 + k];
     if (verbose) {
       printf("Coulomb energy %.10e % .6f\n", res.Ecoul, res.tJ);
-      if (opt.kfrac != 0.0) printf("Exchange energy %.10e % .6f\n", res.Exx, res.tK);
+      if (anyK) printf("Exchange energy %.10e % .6f\n", res.Exx, res.tK);
     }
     res.Etot = res.Ekin + res.Epot + res.Ecoul + res.Exx + res.Exc + res.Enucr;
     const double dE = res.Etot - Eold;

@@ -56,6 +56,11 @@ struct GPUBackend : public helfem::scf::Backend {
     chk(hfg_exchange(ctx, hb, P.memptr(), K.memptr()));
     return K;
   }
+  Mat rs_exchange(const Mat &P) override {
+    Mat K(P.n_rows, P.n_cols);
+    chk(hfg_rs_exchange(ctx, hb, P.memptr(), K.memptr()));
+    return K;
+  }
   void eval_Fxc(int x, int c, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin, double thr) override {
     H.zeros(P.n_rows, P.n_cols);
     chk(hfg_xc_fock(ctx, hb, x, c, P.memptr(), H.memptr(), &Exc, &Nel, &Ekin, thr));
@@ -216,7 +221,12 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
     o.lpad = lpad;
     o.method = method;
     helfem::parse_xc_func(o.x_func, o.c_func, o.method);
-    o.kfrac = helfem::exact_exchange(o.x_func);
+    helfem::range_separation(o.x_func, o.omega, o.kfrac, o.kshort);
+    {
+      bool erf, yuk;
+      helfem::is_range_separated(o.x_func, erf, yuk);
+      o.rs_kind = yuk ? 1 : (erf ? 2 : 0);
+    }
     o.ldft = ldft;
     o.mdft = mdft;
     o.symmetry = symmetry;
@@ -269,7 +279,12 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
     o.zexp = zexp;
     o.method = method;
     helfem::parse_xc_func(o.x_func, o.c_func, o.method);
-    o.kfrac = helfem::exact_exchange(o.x_func);
+    helfem::range_separation(o.x_func, o.omega, o.kfrac, o.kshort);
+    {
+      bool erf, yuk;
+      helfem::is_range_separated(o.x_func, erf, yuk);
+      o.rs_kind = yuk ? 1 : (erf ? 2 : 0);
+    }
     o.ldft = ldft;
     o.mdft = mdft;
     o.symmetry = symmetry;

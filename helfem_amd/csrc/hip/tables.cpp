@@ -19,6 +19,8 @@ struct BasisView {
   std::vector<int> lm_tab;
   std::vector<double> LM_fac;
   int Ntab = 0, ntt = 4, ndt = 4, Lp1 = 0;
+  int rs_kind = 0, pair_tei = 0;
+  std::function<const helfem::Mat &(int, int, int)> tei_pair;  // (tab, e, f), pair_tei only
   std::function<void(int, int, int &, int &)> Lrange;  // (x,y) -> Lmin,Lmax
   std::function<double(int, int, int)> c0, c2;         // (x,y,L)
   std::function<const helfem::Mat &(int, int, int)> disj, tei;  // (type, tab, e)
@@ -38,8 +40,10 @@ struct BasisView {
   }
 };
 
-BasisView view_of(const hfg_basis *basis) {
+BasisView view_of(const hfg_basis *basis, bool rs = false) {
   BasisView v;
+  if (rs && (basis->kind == 0 || basis->ab.rs_kind == 0))
+    throw std::logic_error("Primitive teis have not been computed!\n");
   if (basis->kind == 0) {
     const helfem::diatomic::TwoDBasis *b = &basis->b;
     v.geom = 0;
@@ -138,10 +142,29 @@ BasisView view_of(const hfg_basis *basis) {
     v.df = [b](int e) { return b->get_df(e); };
     v.wrad = [b](int e) { return b->get_wrad(e); };
     v.rcoord = [b](int e) { return b->get_r(e); };
+    if (rs) {
+      // TwoDBasis.cpp:1240: Lfac = 4 pi lambda (Yukawa) or 4 pi mu/(2L+1) (erfc)
+      v.rs_kind = b->rs_kind;
+      const double lam = b->rs_lambda;
+      for (size_t i = 0; i < v.LM_map.size(); i++)
+        v.LM_fac[i] = (b->rs_kind == 1) ? 4.0 * M_PI * lam : 4.0 * M_PI * lam / (2 * v.LM_map[i].first + 1);
+      if (b->rs_kind == 1) {
+        v.disj = [b, E](int t, int tab, int e) -> const helfem::Mat & {
+          return (t == 0 ? b->disjoint_iL : b->disjoint_kL)[tab * E + e];
+        };
+        v.tei = [b, E](int, int tab, int e) -> const helfem::Mat & { return b->rs_tei[tab * E + e]; };
+      } else {
+        v.pair_tei = 1;
+        v.ndt = 0;
+        v.tei_pair = [b, E](int tab, int e, int f) -> const helfem::Mat & { return b->rs_tei[((size_t)tab * E + e) * E + f]; };
+      }
+    }
   }
   return v;
 }
 }  // namespace
+
+static void fill_tables(hfg_ctx *ctx, hfg_basis *basis, const BasisView &b, hfg_dev_tables *t, int ldft, int mdft);
 
 void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft) {
   if (!basis->have_tei()) throw std::logic_error("Primitive teis have not been computed!\n");
@@ -151,7 +174,25 @@ void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft) {
   hfg_dev_tables *t = new hfg_dev_tables();
   basis->dev = t;
   basis->dev_device = ctx->device;
+  fill_tables(ctx, basis, b, t, ldft, mdft);
+}
+
+void upload_rs_tables(hfg_ctx *ctx, hfg_basis *basis) {
+  const BasisView b = view_of(basis, true);
+  HFG_HIP_CHECK(hipSetDevice(ctx->device));
+  if (basis->dev_rs) delete basis->dev_rs;
+  hfg_dev_tables *t = new hfg_dev_tables();
+  basis->dev_rs = t;
+  if (basis->dev && basis->dev_device != ctx->device) throw std::logic_error("basis tables live on a different device\n");
+  basis->dev_device = ctx->device;
+  fill_tables(ctx, basis, b, t, 0, 0);
+}
+
+static void fill_tables(hfg_ctx *ctx, hfg_basis *basis, const BasisView &b, hfg_dev_tables *t, int ldft, int mdft) {
   hipStream_t s = ctx->stream;
+  const bool use_dev_tei = basis->tei_on_device && !b.rs_kind;
+  t->rs_kind = b.rs_kind;
+  t->pair_tei = b.pair_tei;
 
   const int A = t->A = b.A;
   const int R = t->R = b.R;
@@ -269,7 +310,7 @@ void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft) {
   const int Ntab = b.Ntab;
   {
     const size_t pp = (size_t)p * p;
-    std::vector<double> disj((size_t)b.ndt * Ntab * E * pp, 0.0);
+    std::vector<double> disj(std::max<size_t>((size_t)b.ndt * Ntab * E * pp, 1), 0.0);
     for (int tt = 0; tt < b.ndt; tt++)
       for (int tab = 0; tab < Ntab; tab++)
         for (int e = 0; e < E; e++) {
@@ -289,32 +330,35 @@ void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft) {
   {
     const size_t pp = (size_t)p * p;
     const size_t blk = pp * pp;
-    t->tei.resize((size_t)b.ntt * Ntab * E * blk);
-    if (basis->tei_on_device) {
+    const int nper = b.pair_tei ? E * E : E;  // blocks per (type, slot)
+    t->tei.resize((size_t)b.ntt * Ntab * nper * blk);
+    if (use_dev_tei) {
       if (basis->dev_tei.n < (size_t)b.ntt * Ntab * E * blk) throw std::logic_error("device tei buffer has the wrong size");
       HFG_HIP_CHECK(hipMemcpyAsync(t->tei.p, basis->dev_tei.p, sizeof(double) * (size_t)b.ntt * Ntab * E * blk,
                                    hipMemcpyDeviceToDevice, s));
       HFG_HIP_CHECK(hipStreamSynchronize(s));
     }
     std::vector<double> stage(blk);
-    if (!basis->tei_on_device)
+    if (!use_dev_tei)
     for (int tt = 0; tt < b.ntt; tt++)
       for (int tab = 0; tab < Ntab; tab++)
-        for (int e = 0; e < E; e++) {
-          const helfem::Mat &m = b.tei(tt, tab, e);
-          const int lo = b.lo(e);
-          const size_t Ni = (size_t)std::lround(std::sqrt((double)m.n_rows));
-          if (Ni * Ni != m.n_rows || (int)Ni + lo > p) throw std::logic_error("unexpected primitive tei block size");
-          double *dst = t->tei.p + (((size_t)tt * Ntab + tab) * E + e) * blk;
-          if ((int)Ni == p) {
+        for (int eb = 0; eb < nper; eb++) {
+          const int e = b.pair_tei ? eb / E : eb, f = b.pair_tei ? eb % E : eb;
+          const helfem::Mat &m = b.pair_tei ? b.tei_pair(tab, e, f) : b.tei(tt, tab, e);
+          const int lo = b.lo(e), lof = b.lo(f);  // rows: primitives of e, columns: primitives of f
+          const size_t Ni = (size_t)std::lround(std::sqrt((double)m.n_rows)), Nf = (size_t)std::lround(std::sqrt((double)m.n_cols));
+          if (Ni * Ni != m.n_rows || Nf * Nf != m.n_cols || (int)Ni + lo > p || (int)Nf + lof > p)
+            throw std::logic_error("unexpected primitive tei block size");
+          double *dst = t->tei.p + (((size_t)tt * Ntab + tab) * nper + eb) * blk;
+          if ((int)Ni == p && (int)Nf == p) {
             HFG_HIP_CHECK(hipMemcpyAsync(dst, m.memptr(), blk * sizeof(double), hipMemcpyHostToDevice, s));
           } else {
             std::fill(stage.begin(), stage.end(), 0.0);
-            for (size_t cj = 0; cj < Ni; cj++)
-              for (size_t ci = 0; ci < Ni; ci++)
+            for (size_t cj = 0; cj < Nf; cj++)
+              for (size_t ci = 0; ci < Nf; ci++)
                 for (size_t rj = 0; rj < Ni; rj++)
                   for (size_t ri = 0; ri < Ni; ri++)
-                    stage[((cj + lo) * p + (ci + lo)) * pp + (rj + lo) * p + (ri + lo)] = m(rj * Ni + ri, cj * Ni + ci);
+                    stage[((cj + lof) * p + (ci + lof)) * pp + (rj + lo) * p + (ri + lo)] = m(rj * Ni + ri, cj * Nf + ci);
             HFG_HIP_CHECK(hipMemcpyAsync(dst, stage.data(), blk * sizeof(double), hipMemcpyHostToDevice, s));
             HFG_HIP_CHECK(hipStreamSynchronize(s));
           }

@@ -32,6 +32,14 @@ struct hfg_dev_tables {
   int Lp1 = 0;         // size of the L axis of c0tab/c2tab
   double Rhalf = 0.0;
   bool have_tei = false, have_xc = false;
+  // Range-separated exchange of the atomic program (TwoDBasis::rs_exchange, src/atomic/TwoDBasis.cpp:1142): a second
+  // table set (hfg_basis::dev_rs) with the same couplings whose radial slots hold the screened kernel.  Yukawa
+  // (rs_kind 1): P0 := int i_L(lambda r), Q0 := int k_L(lambda r), tei00 := in-element integral, LMfac = 4 pi lambda.
+  // erfc (rs_kind 2): the kernel does not factorise over elements -- pair_tei = 1, no disjoint tables, and
+  // tei[tab][e][f][c][r] holds one p^2 x p^2 block per ELEMENT PAIR (rows: primitives of e, columns: primitives of f),
+  // LMfac = 4 pi mu/(2L+1).
+  int rs_kind = 0;
+  int pair_tei = 0;
 
   hfg::DevBuf<int> shell_l, shell_m, shell_off, shell_skip;
   // couplings by pair (x*A+y): entries [pair_off, pair_off+1)
@@ -66,4 +74,6 @@ struct hfg_dev_tables {
 namespace hfg {
 /// build (or rebuild) the device tables of basis on the context's device
 void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
+/// build (or rebuild) basis->dev_rs from the host tables of compute_yukawa / compute_erfc
+void upload_rs_tables(hfg_ctx *ctx, hfg_basis *basis);
 }  // namespace hfg

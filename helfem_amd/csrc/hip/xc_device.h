@@ -60,10 +60,61 @@ __host__ __device__ inline Dual datan(Dual a) {
   return mk(atan(a.v), a.dr * f, a.ds * f);
 }
 
+__host__ __device__ inline Dual derf(Dual a) {
+  double f = 1.1283791670955126 * exp(-a.v * a.v);  // 2/sqrt(pi)
+  return mk(erf(a.v), a.dr * f, a.ds * f);
+}
+
 #define HFG_PI 3.14159265358979323846
 
 // energy per particle of each functional as a Dual in (rho, sigma)
 __host__ __device__ inline Dual eps_lda_x(Dual rho) { return (-0.75 * cbrt(3.0 / HFG_PI)) * dcbrt(rho); }
+
+// Short-range LDA exchange of the range-separated hybrids: eps_x^sr = eps_x^LDA(rho) F(a), a = omega/(2 k_F).
+// erfc(omega r)/r (libxc lda_x_erf; Toulouse, Savin, Flad, Int. J. Quantum Chem. 100, 1047 (2004), eq 18-19):
+//   F = 1 - (8/3) a [sqrt(pi) erf(1/(2a)) + (2a - 4a^3) exp(-1/(4a^2)) - 3a + 4a^3]
+// exp(-omega r)/r (libxc lda_x_yukawa; Savin, Flad, Int. J. Quantum Chem. 56, 327 (1995)):
+//   F = 1 - (8/3) a [atan(1/a) + a/4 - (a/4)(a^2 + 3) ln(1 + 1/a^2)]
+// Both closed forms cancel like a^4 for large a (low density); there the expansions in 1/a^2 are summed:
+//   erf: sum_k (-1)^{k+1} 2/(4^k k! (2k+1)(k+1)(k+2)) a^{-2k},  Yukawa: sum_k (-1)^{k+1} 2/((2k+1)(k+1)(k+2)) a^{-2k}.
+__host__ __device__ inline Dual att_erf(Dual a) {
+  if (a.v > 0.75) {
+    Dual u = 1.0 / (a * a), t = mk(1.0), sum = mk(0.0);
+    for (int k = 1; k <= 24; k++) {
+      t = t * u * (-0.25 / k);
+      sum = sum - t * (2.0 / ((2.0 * k + 1.0) * (k + 1.0) * (k + 2.0)));
+    }
+    return sum;
+  }
+  Dual a2 = a * a;
+  Dual e = dexp(-0.25 / a2);
+  return 1.0 - (8.0 / 3.0) * a * (1.7724538509055159 * derf(0.5 / a) + (2.0 * a - 4.0 * a2 * a) * e - 3.0 * a + 4.0 * a2 * a);
+}
+__host__ __device__ inline Dual att_yukawa(Dual a) {
+  if (a.v > 2.0) {
+    Dual u = 1.0 / (a * a), t = mk(-1.0), sum = mk(0.0);
+    for (int k = 1; k <= 40; k++) {
+      t = -1.0 * t * u;
+      sum = sum + t * (2.0 / ((2.0 * k + 1.0) * (k + 1.0) * (k + 2.0)));
+    }
+    return sum;
+  }
+  Dual a2 = a * a;
+  return 1.0 - (8.0 / 3.0) * a * (datan(1.0 / a) + 0.25 * a - 0.25 * a * (a2 + 3.0) * dlog(1.0 + 1.0 / a2));
+}
+/// kind 1: Yukawa, 2: erfc
+__host__ __device__ inline Dual eps_lda_x_sr(Dual rho, double omega, int kind) {
+  Dual kf = dcbrt((3.0 * HFG_PI * HFG_PI) * rho);
+  Dual a = (0.5 * omega) / kf;
+  return eps_lda_x(rho) * (kind == 1 ? att_yukawa(a) : att_erf(a));
+}
+// hyb_lda_xc_cam_lda0 (libxc id 178; Mosquera, Borca, Ratner, Schatz, J. Phys. Chem. A 120, 1605 (2016)): omega = 1/3,
+// exact exchange alpha = 1/2 over the full range plus beta = -1/4 of the short range (1/4 at short, 1/2 at long range);
+// DFT part (1 - alpha) lda_x - beta lda_x_erf + lda_c_pw_mod
+#define HFG_CAM_LDA0_OMEGA (1.0 / 3.0)
+__host__ __device__ inline Dual eps_cam_lda0_x(Dual rho) {
+  return 0.5 * eps_lda_x(rho) + 0.25 * eps_lda_x_sr(rho, HFG_CAM_LDA0_OMEGA, 2);
+}
 
 __host__ __device__ inline Dual eps_lda_c_vwn(Dual rho) {
   const double A = 0.0310907, b = 3.72744, c = 12.9352, x0 = -0.10498;
@@ -117,7 +168,8 @@ __host__ __device__ inline Dual eps_gga_c_pbe(Dual rho, Dual sigma) {
 
 __host__ __device__ inline bool is_gga(int id) { return id == 101 || id == 130 || id == 406 || id == 202 || id == 231; }
 __host__ __device__ inline bool is_supported(int id) {
-  return id == 1 || id == 7 || id == 12 || id == 101 || id == 130 || id == 406 || id == 202 || id == 231;
+  return id == 1 || id == 7 || id == 12 || id == 13 || id == 101 || id == 130 || id == 406 || id == 202 || id == 231 ||
+         id == 546 || id == 641 || id == 178;
 }
 
 /// adds functional id's exc (per particle), vrho, vsigma at one point; rho >= threshold assumed
@@ -128,6 +180,10 @@ __host__ __device__ inline void eval_add(int id, double rho, double sigma, doubl
     case 1: e = eps_lda_x(r); break;
     case 7: e = eps_lda_c_vwn(r); break;
     case 12: e = eps_lda_c_pw(r); break;
+    case 13: e = eps_pw92(dcbrt(3.0 / (4.0 * HFG_PI) / r), true); break;  // lda_c_pw_mod
+    case 546: e = eps_lda_x_sr(r, 0.3, 2); break;                          // lda_x_erf, libxc default omega
+    case 641: e = eps_lda_x_sr(r, 0.3, 1); break;                          // lda_x_yukawa, libxc default omega
+    case 178: e = eps_cam_lda0_x(r) + eps_pw92(dcbrt(3.0 / (4.0 * HFG_PI) / r), true); break;  // hyb_lda_xc_cam_lda0, DFT part
     case 101: e = eps_gga_x_pbe(r, s); break;
     case 130: e = eps_gga_c_pbe(r, s); break;
     case 406: e = 0.75 * eps_gga_x_pbe(r, s) + eps_gga_c_pbe(r, s); break;  // hyb_gga_xc_pbeh (PBE0), DFT part
@@ -263,11 +319,22 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
     eval_add_pol(130, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
     return;
   }
-  if (id == 1 || id == 101) {
+  if (id == 178) {  // hyb_lda_xc_cam_lda0, DFT part: spin-scaled exchange mixture + lda_c_pw_mod
+    eval_add_pol(-178, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+    eval_add_pol(13, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+    return;
+  }
+  if (id == 1 || id == 101 || id == 546 || id == 641 || id == -178) {
     Dual a = mk(2.0 * ra, 1.0, 0.0), b = mk(2.0 * rb, 1.0, 0.0);
     Dual sa = mk(4.0 * saa, 0.0, 1.0), sb = mk(4.0 * sbb, 0.0, 1.0);
-    Dual ea = (id == 1) ? eps_lda_x(a) : eps_gga_x_pbe(a, sa);
-    Dual eb = (id == 1) ? eps_lda_x(b) : eps_gga_x_pbe(b, sb);
+    Dual ea, eb;
+    switch (id) {
+      case 1: ea = eps_lda_x(a); eb = eps_lda_x(b); break;
+      case 546: ea = eps_lda_x_sr(a, 0.3, 2); eb = eps_lda_x_sr(b, 0.3, 2); break;
+      case 641: ea = eps_lda_x_sr(a, 0.3, 1); eb = eps_lda_x_sr(b, 0.3, 1); break;
+      case -178: ea = eps_cam_lda0_x(a); eb = eps_cam_lda0_x(b); break;
+      default: ea = eps_gga_x_pbe(a, sa); eb = eps_gga_x_pbe(b, sb); break;
+    }
     Dual na = a * ea, nb = b * eb;  // energy per volume of the doubled densities
     exc += 0.5 * (na.v + nb.v) / rt;
     va += na.dr;          // d/d ra [ (1/2) n(2 ra) ] = n'(2 ra)
@@ -284,6 +351,7 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
   switch (id) {
     case 7: e = pol_eps_vwn(rs, z); break;
     case 12: e = pol_eps_pw(rs, z, false); break;
+    case 13: e = pol_eps_pw(rs, z, true); break;
     case 130: e = pol_eps_pbe_c(n, rs, z, st); break;
     default: return;
   }

@@ -196,13 +196,18 @@ Mat TwoDBasis::nuclear() const {
   return place_diag(*this, std::vector<Mat>(Nang(), (-(double)Z) * Vrad));
 }
 
-Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly, int L) {
+// quadrature::twoe_inner_integral + twoe_integral / yukawa_integral (libhelfem/src/quadrature.cpp:22-169) for a kernel
+// g(r<, r>) = fsmallbig(r<, r>) whose r> dependence is fbig(r>): the inner integral up to each outer quadrature point
+// is built segment by segment (each segment with a fresh rule, scaled by the kernel at its upper end) and carried
+// to the next point with the ratio fbig(r_ip)/fbig(r_ip-1).
+static Mat twoe_integral_kernel(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly,
+                                const std::function<double(double, double)> &fsmallbig,
+                                const std::function<double(double)> &fbig) {
   const size_t nq = xq.size();
   const double rmid0 = 0.5 * (rmax + rmin), rlen0 = 0.5 * (rmax - rmin);
   const size_t Ni = poly.nbf(), Np = Ni * Ni;
   Vec r0(nq);
   for (size_t q = 0; q < nq; q++) r0[q] = rmid0 + rlen0 * xq[q];
-  // inner(q,(kl)) = r_q^{-L-1} int_{rmin}^{r_q} r^L B_k B_l dr, built segment by segment (quadrature.cpp:22-83)
   Mat inner(Np, nq);
   for (size_t ip = 0; ip < nq; ip++) {
     double a = (ip == 0) ? rmin : r0[ip - 1], bnd = r0[ip];
@@ -210,7 +215,7 @@ Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const 
     Vec xpoly(nq), wp(nq);
     for (size_t q = 0; q < nq; q++) {
       double r = rmid + rlen * xq[q];
-      wp[q] = wq[q] * std::pow(r / bnd, (double)L) / bnd * rlen;
+      wp[q] = wq[q] * fsmallbig(r, bnd) * rlen;
       xpoly[q] = (r - rmid0) / rlen0;
     }
     Mat bf = poly.eval_dnf(xpoly, 0, rlen0);
@@ -219,7 +224,7 @@ Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const 
       for (size_t l = 0; l < Ni; l++)
         for (size_t k = 0; k < Ni; k++) col[l * Ni + k] += wp[q] * bf(q, k) * bf(q, l);
     if (ip > 0) {
-      double ratio = std::pow(r0[ip], -(double)L - 1.0) / std::pow(r0[ip - 1], -(double)L - 1.0);
+      double ratio = fbig(r0[ip]) / fbig(r0[ip - 1]);
       const double *prev = &inner.d[(ip - 1) * Np];
       for (size_t k = 0; k < Np; k++) col[k] += prev[k] * ratio;
     }
@@ -237,6 +242,20 @@ Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const 
     }
   }
   return ints + ints.t();
+}
+
+Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly, int L) {
+  // r_<^L / r_>^{L+1}: inner(q,(kl)) = r_q^{-L-1} int_{rmin}^{r_q} r^L B_k B_l dr
+  return twoe_integral_kernel(
+      rmin, rmax, xq, wq, poly, [L](double r, double R) { return std::pow(r / R, (double)L) / R; },
+      [L](double r) { return std::pow(r, -(double)L - 1.0); });
+}
+
+Mat yukawa_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly, int L, double lambda) {
+  return twoe_integral_kernel(
+      rmin, rmax, xq, wq, poly,
+      [L, lambda](double r, double R) { return bessel_il(r * lambda, L) * bessel_kl(R * lambda, L); },
+      [L, lambda](double r) { return bessel_kl(r * lambda, L); });
 }
 
 void TwoDBasis::compute_tei(bool exchange) {
@@ -265,5 +284,83 @@ void TwoDBasis::compute_tei(bool exchange) {
   }
 }
 
+Mat TwoDBasis::bessel_il_integral(int L, double lambda, size_t iel) const {
+  return fem.matrix_element(iel, 0, 0, xq, wq, [L, lambda](double r) { return bessel_il(r * lambda, L); });
+}
+
+Mat TwoDBasis::bessel_kl_integral(int L, double lambda, size_t iel) const {
+  return fem.matrix_element(iel, 0, 0, xq, wq, [L, lambda](double r) { return bessel_kl(r * lambda, L); });
+}
+
+Mat TwoDBasis::erfc_integral(int L, double mu, size_t iel, size_t kel) const {
+  // RadialBasis.cpp:502-558 + quadrature.cpp:171-222.  The kernel has a cusp at r = r', so the in-element integral
+  // uses nq sub-intervals (each with its own nq-point rule) for the second coordinate; distinct elements use one.
+  const size_t nq = xq.size();
+  const size_t Nint = (iel == kel) ? nq : 1;
+  Vec xk(nq * Nint), wk(nq * Nint);
+  for (size_t ii = 0; ii < Nint; ii++) {
+    double istart = ii * 2.0 / Nint - 1.0, iend = (ii + 1) * 2.0 / Nint - 1.0;
+    double imid = 0.5 * (iend + istart), ilen = 0.5 * (iend - istart);
+    for (size_t q = 0; q < nq; q++) {
+      xk[ii * nq + q] = imid + xq[q] * ilen;
+      wk[ii * nq + q] = wq[q] * ilen;
+    }
+  }
+  Mat ibf = fem.eval_dnf(xq, 0, iel), kbf = fem.eval_dnf(xk, 0, kel);
+  const double rleni = fem.scaling_factor(iel), rlenk = fem.scaling_factor(kel);
+  Vec ri = fem.eval_coord(xq, iel), rk = fem.eval_coord(xk, kel);
+  const size_t Ni = ibf.n_cols, Nk = kbf.n_cols, nqi = nq, nqk = nq * Nint;
+  // Green's function and weighted product functions
+  Mat Fn(nqi, nqk);
+  for (size_t k = 0; k < nqk; k++)
+    for (size_t i = 0; i < nqi; i++) Fn(i, k) = erfc_Phi(L, mu * ri[i], mu * rk[k]);
+  Mat pij(nqi, Ni * Ni), pkl(nqk, Nk * Nk);
+  for (size_t fi = 0; fi < Ni; fi++)
+    for (size_t fj = 0; fj < Ni; fj++)
+      for (size_t q = 0; q < nqi; q++) pij(q, fi * Ni + fj) = ibf(q, fi) * ibf(q, fj) * wq[q] * rleni;
+  for (size_t fi = 0; fi < Nk; fi++)
+    for (size_t fj = 0; fj < Nk; fj++)
+      for (size_t q = 0; q < nqk; q++) pkl(q, fi * Nk + fj) = kbf(q, fi) * kbf(q, fj) * wk[q] * rlenk;
+  Mat tei = matmul(pij, true, matmul(Fn, false, pkl, false), false);
+  if (iel == kel) tei = 0.5 * (tei + tei.t());
+  return tei;
+}
+
+void TwoDBasis::compute_yukawa(double lambda) {
+  // TwoDBasis.cpp:741-778
+  rs_kind = 1;
+  rs_lambda = lambda;
+  const size_t Ne = Nel(), NL = (size_t)N_L();
+  disjoint_iL.assign(Ne * NL, Mat());
+  disjoint_kL.assign(Ne * NL, Mat());
+  rs_tei.assign(Ne * NL, Mat());
+  rs_ktei.assign(Ne * NL, Mat());
+  parallel_for(Ne * NL, [&](size_t idx) {
+    const size_t L = idx / Ne, iel = idx % Ne;
+    disjoint_iL[idx] = bessel_il_integral((int)L, lambda, iel);
+    disjoint_kL[idx] = bessel_kl_integral((int)L, lambda, iel);
+    rs_tei[idx] = yukawa_integral(fem.element_begin(iel), fem.element_end(iel), xq, wq, fem.get_basis(iel), (int)L, lambda);
+    size_t Ni = fem.nprim(iel);
+    rs_ktei[idx] = diatomic::exchange_tei(rs_tei[idx], Ni, Ni, Ni, Ni);
+  });
+}
+
+void TwoDBasis::compute_erfc(double mu) {
+  // TwoDBasis.cpp:780-815
+  rs_kind = 2;
+  rs_lambda = mu;
+  const size_t Ne = Nel(), NL = (size_t)N_L();
+  disjoint_iL.clear();
+  disjoint_kL.clear();
+  rs_tei.assign(Ne * Ne * NL, Mat());
+  rs_ktei.assign(Ne * Ne * NL, Mat());
+  parallel_for(Ne * Ne * NL, [&](size_t idx) {
+    const size_t L = idx / (Ne * Ne), iel = (idx / Ne) % Ne, kel = idx % Ne;
+    rs_tei[idx] = erfc_integral((int)L, mu, iel, kel);
+    rs_ktei[idx] = diatomic::exchange_tei(rs_tei[idx], fem.nprim(iel), fem.nprim(iel), fem.nprim(kel), fem.nprim(kel));
+  });
+}
+
 }  // namespace atomic
 }  // namespace helfem
+

@@ -4,8 +4,11 @@
 // helfem::atomic::basis::RadialBasis (libhelfem/src/RadialBasis.cpp:190 radial_integral, :484 twoe_integral,
 // :649/:676 get_bf/get_df) with libhelfem/src/quadrature.cpp:22-130 (in-element two-electron integrals).
 //
-// Point nucleus at the origin only (finite nuclei, off-centre charges, confinement, range separation are
-// outside this round's scope and rejected by the driver).
+// Range-separated exchange tables: :741-778 compute_yukawa, :780-815 compute_erfc with RadialBasis.cpp:201-209
+// bessel_il/kl_integral, :491 yukawa_integral, :502-558 erfc_integral and libhelfem/src/quadrature.cpp:128-222.
+//
+// Point nucleus at the origin only (finite nuclei, off-centre charges, confinement are outside this round's scope
+// and rejected by the driver).
 //
 // B(r)/r near the origin: the reference switches to a Taylor series of order nprim-1 below a numerically
 // chosen cutoff (RadialBasis.cpp:59-133, 575-631).  For LIPs whose first function is dropped, B_i(r)/r is a
@@ -24,6 +27,9 @@ void angular_basis(int lmax, int mmax, IVec &lval, IVec &mval);
 /// In-element two-electron integral table of one radial element, int int B_i(r1)B_j(r1) r_<^L/r_>^{L+1} B_k(r2)B_l(r2),
 /// (ij) x (kl), without the 4 pi/(2L+1) factor (quadrature::twoe_integral, libhelfem/src/quadrature.cpp:22-130)
 Mat twoe_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly, int L);
+/// Same with the Yukawa kernel i_L(lambda r<) k_L(lambda r>), without the 4 pi lambda factor
+/// (quadrature::yukawa_integral, libhelfem/src/quadrature.cpp:128-169)
+Mat yukawa_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, const LIPBasis &poly, int L, double lambda);
 
 struct TwoDBasis {
   int Z = 0;
@@ -36,6 +42,15 @@ struct TwoDBasis {
   std::vector<Mat> disjoint_L, disjoint_m1L;  // [L*Nel+iel]
   std::vector<Mat> prim_tei, prim_ktei;      // [L*Nel+iel]
   bool have_tei = false, have_ktei = false;
+
+  // range-separated exchange (TwoDBasis.cpp:741-815).  rs_kind 1: Yukawa, exp(-lambda r12)/r12 -- disjoint_iL/kL and
+  // the in-element tables rs_tei[L*Nel+iel]; rs_kind 2: erfc(mu r12)/r12 -- no factorisation, one table per element
+  // pair rs_tei[(L*Nel+iel)*Nel+kel] ((ij) x (kl), i,j in iel, k,l in kel).  rs_ktei: the exchange-ordered copies
+  // (utils::exchange_tei) the reference stores; kept for the oracle only.
+  int rs_kind = 0;
+  double rs_lambda = 0.0;
+  std::vector<Mat> disjoint_iL, disjoint_kL;  // [L*Nel+iel]
+  std::vector<Mat> rs_tei, rs_ktei;
 
   TwoDBasis() {}
   TwoDBasis(int Z, int nnodes, int n_quad, const Vec &bval, const IVec &lval, const IVec &mval);
@@ -66,6 +81,13 @@ struct TwoDBasis {
   Mat kinetic() const;
   Mat nuclear() const;
   void compute_tei(bool exchange);
+  /// int B_i B_j f(r) dr over element iel   (RadialBasis::bessel_il_integral / bessel_kl_integral)
+  Mat bessel_il_integral(int L, double lambda, size_t iel) const;
+  Mat bessel_kl_integral(int L, double lambda, size_t iel) const;
+  /// int int B_i(r)B_j(r) Phi_L(mu r, mu r') B_k(r')B_l(r') dr dr', i,j in iel, k,l in kel   (RadialBasis::erfc_integral)
+  Mat erfc_integral(int L, double mu, size_t iel, size_t kel) const;
+  void compute_yukawa(double lambda);
+  void compute_erfc(double mu);
 };
 
 }  // namespace atomic

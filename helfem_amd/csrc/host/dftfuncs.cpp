@@ -12,8 +12,11 @@ struct Known {
   const char *name;
   int id;
 };
-const Known known[] = {{"lda_x", 1}, {"lda_c_vwn", 7}, {"lda_c_pw", 12}, {"gga_x_pbe", 101}, {"gga_c_pbe", 130},
-                       {"hyb_gga_xc_pbeh", 406}, {"mgga_x_tpss", 202}, {"mgga_c_tpss", 231}};  // PBE0: 0.75 gga_x_pbe + gga_c_pbe + 0.25 exact exchange
+const Known known[] = {{"lda_x", 1}, {"lda_c_vwn", 7}, {"lda_c_pw", 12}, {"lda_c_pw_mod", 13}, {"gga_x_pbe", 101},
+                       {"gga_c_pbe", 130},
+                       {"hyb_gga_xc_pbeh", 406},  // PBE0: 0.75 gga_x_pbe + gga_c_pbe + 0.25 exact exchange
+                       {"mgga_x_tpss", 202}, {"mgga_c_tpss", 231}, {"lda_x_erf", 546}, {"lda_x_yukawa", 641},
+                       {"hyb_lda_xc_cam_lda0", 178}};  // CAM-LDA0: erfc range separation, omega = 1/3
 
 int find_func(const std::string &name) {
   if (name.empty()) throw std::runtime_error("empty functional name\n");
@@ -40,7 +43,24 @@ void parse_xc_func(int &x_func, int &c_func, const std::string &xc) {
 }
 
 // fraction of exact exchange (libxc xc_hyb_exx_coef; dftfuncs.cpp:134-160 of the reference)
-double exact_exchange(int x_func) { return x_func == -1 ? 1.0 : (x_func == 406 ? 0.25 : 0.0); }
+double exact_exchange(int x_func) { return x_func == -1 ? 1.0 : (x_func == 406 ? 0.25 : (x_func == 178 ? 0.5 : 0.0)); }
+
+// libxc's xc_hyb_cam_coef / hyb_type of the range-separated hybrids available here (dftfuncs.cpp:464-570 of the
+// reference): K = alpha K[1/r12] + beta K[screened kernel]
+void range_separation(int x_func, double &omega, double &alpha, double &beta) {
+  omega = 0.0;
+  alpha = exact_exchange(x_func);
+  beta = 0.0;
+  if (x_func == 178) {  // hyb_lda_xc_cam_lda0
+    omega = 1.0 / 3.0;
+    alpha = 0.5;
+    beta = -0.25;
+  }
+}
+void is_range_separated(int x_func, bool &erf, bool &yukawa) {
+  erf = (x_func == 178);
+  yukawa = false;
+}
 
 const char *xc_func_name(int id) {
   if (id == -1) return "HF";

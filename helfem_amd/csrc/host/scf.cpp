@@ -208,11 +208,18 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
 
     Mat Ka, Kb;
     res.Exx = 0.0;
-    if (opt.kfrac != 0.0) {
+    if (opt.kfrac != 0.0 || opt.kshort != 0.0) {
       t0 = wall();
-      Ka = opt.kfrac * be.exchange(Pa);
+      // atomic/main.cpp:763-780: full-range and short-range exact exchange
+      auto buildK = [&](const Mat &Ps) {
+        Mat K(Nb, Nb);
+        if (opt.kfrac != 0.0) K += opt.kfrac * be.exchange(Ps);
+        if (opt.omega != 0.0) K += opt.kshort * be.rs_exchange(Ps);
+        return K;
+      };
+      Ka = buildK(Pa);
       if (!restr) {
-        if (nelb) Kb = opt.kfrac * be.exchange(Pb);
+        if (nelb) Kb = buildK(Pb);
         else Kb.zeros(Nb, Nb);
       }
       res.tK = wall() - t0;
@@ -332,6 +339,7 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
 }  // namespace
 
 Result run_diatomic(const Options &opt, Backend &be) {
+  if (opt.omega != 0.0) throw std::logic_error("Range separated functionals are not supported.\n");  // diatomic/main.cpp:393
   Result res;
   const bool verbose = opt.verbose;
   Problem pb;
@@ -430,8 +438,17 @@ Result run_atomic(const AtomicOptions &aopt, Backend &be) {
   pb.S = basis.overlap();
   pb.T = basis.kinetic();
   pb.Vnuc = basis.nuclear();
+  if (verbose && opt.omega != 0.0) {  // atomic/main.cpp:363-370
+    printf("\nUsing range-separated exchange with range-separation constant omega = % .3f.\n", opt.omega);
+    printf("Using % .3f %% short-range and % .3f %% long-range exchange.\n", (opt.kfrac + opt.kshort) * 100, opt.kfrac * 100);
+    printf("Range separation is done with the %s kernel.\n", opt.rs_kind == 1 ? "Yukawa" : "error function");
+  }
   pb.compute_tei_and_prepare = [&]() {
     basis.compute_tei(opt.kfrac != 0.0);
+    if (opt.omega != 0.0) {  // atomic/main.cpp:709-712
+      if (opt.rs_kind == 1) basis.compute_yukawa(opt.omega);
+      else basis.compute_erfc(opt.omega);
+    }
     be.prepare_atomic(basis, opt.kfrac != 0.0, ldft, mdft);
   };
   return scf_loop(opt, be, pb, res);

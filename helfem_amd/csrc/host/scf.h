@@ -23,6 +23,8 @@ struct Backend {
   virtual void prepare_atomic(const atomic::TwoDBasis &basis, bool exchange, int ldft, int mdft) = 0;
   virtual Mat coulomb(const Mat &P) = 0;
   virtual Mat exchange(const Mat &P) = 0;
+  /// atomic::basis::TwoDBasis::rs_exchange (src/atomic/TwoDBasis.cpp:1142), tables of compute_yukawa / compute_erfc
+  virtual Mat rs_exchange(const Mat &P) = 0;
   virtual void eval_Fxc(int x_func, int c_func, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin,
                         double thr) = 0;
   /// unrestricted: both spin matrices
@@ -52,6 +54,10 @@ struct Options {
   std::string method = "HF";
   int x_func = -1, c_func = 0;  // filled by the caller from method
   double kfrac = 1.0;
+  // range-separated hybrids (atomic/main.cpp:358-372): K = kfrac K[1/r12] + kshort K[screened], omega != 0 switches the
+  // second term on; rs_kind 1 Yukawa, 2 erfc.  Filled by the caller from the functional (range_separation()).
+  double kshort = 0.0, omega = 0.0;
+  int rs_kind = 0;
   int ldft = 0, mdft = 0;
   double dftthr = 1e-12;
   int symmetry = 1;

@@ -1,6 +1,8 @@
 #include "special.h"
 #include "fem.h"
+#include <cfloat>
 #include <cmath>
+#include <stdexcept>
 #include <cstdlib>
 #include <algorithm>
 
@@ -282,6 +284,149 @@ void legendre_PQ(int Lmax, int Mmax, double xi, double *P, double *Q) {
   }
   for (int M = 0; M <= Mmax; M++)
     for (int L = M; L <= Lmax; L++) Q[M * ld + L] = (double)q[M][L];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Radial kernels of the range-separated exchange (atomic program)
+// -------------------------------------------------------------------------------------------------
+double bessel_il(double x, int L) {
+  x = fabs(x);
+  if (L < 0) throw std::logic_error("bessel_il: negative order");
+  if (x == 0.0) return L == 0 ? 1.0 : 0.0;
+  if (x > 30.0 && x > 4.0 * L) {
+    // upward recurrence i_{n+1} = i_{n-1} - (2n+1)/x i_n, harmless for x >> n
+    double im = sinh(x) / x;
+    if (L == 0) return im;
+    double ic = (x * cosh(x) - sinh(x)) / (x * x);
+    for (int n = 1; n < L; n++) {
+      double ip = im - (2 * n + 1) / x * ic;
+      im = ic;
+      ic = ip;
+    }
+    return ic;
+  }
+  // ascending series: x^L/(2L+1)!! sum_k (x^2/2)^k / (k! (2L+3)(2L+5)...(2L+2k+1)), all terms positive
+  double pref = 1.0;
+  for (int n = 1; n <= L; n++) pref *= x / (2 * n + 1);
+  const double h = 0.5 * x * x;
+  double term = 1.0, sum = 1.0;
+  for (int k = 1; k < 2000; k++) {
+    term *= h / ((double)k * (2 * L + 2 * k + 1));
+    sum += term;
+    if (term < 1e-18 * sum) break;
+  }
+  return pref * sum;
+}
+
+double bessel_kl(double x, int L) {
+  if (L < 0) throw std::logic_error("bessel_kl: negative order");
+  // k_0 = e^{-x}/x, k_1 = e^{-x}(1 + 1/x)/x, k_{n+1} = k_{n-1} + (2n+1)/x k_n  (dominant solution: upward is stable)
+  const double ex = exp(-x);
+  double km = ex / x;
+  if (L == 0) return km;
+  double kc = ex * (1.0 + 1.0 / x) / x;
+  for (int n = 1; n < L; n++) {
+    double kp = km + (2 * n + 1) / x * kc;
+    km = kc;
+    kc = kp;
+  }
+  return kc;
+}
+
+namespace {
+int g_erfc_binomial_mode = 0;
+
+double factorial_d(int n) {
+  double f = 1.0;
+  for (int i = 2; i <= n; i++) f *= i;
+  return f;
+}
+double double_factorial_d(int n) {
+  double f = 1.0;
+  for (int i = n; i > 1; i -= 2) f *= i;
+  return f;
+}
+// binomial coefficient with any integer upper argument: C(n,m) = n (n-1) ... (n-m+1) / m!
+double gen_binomial(int n, int m) {
+  if (m < 0) return 0.0;
+  double c = 1.0;
+  for (int i = 0; i < m; i++) c = c * (n - i) / (i + 1);
+  return std::round(c);
+}
+// the helper of erfc_expn.cpp:46-70, kept only for the test hook
+double ref_binomial(int n, int m) {
+  if (n == -1) return (m % 2) ? -1.0 : 1.0;
+  if (n == 0) return m == 0 ? 1.0 : 0.0;
+  if (m == 0) return 1.0;
+  if (m == 1) return n;
+  if (n > 0 && m > 0 && m > n) return 0.0;
+  if (n < 0) return ref_binomial(n + m - 1, m) * ((m % 2) ? -1.0 : 1.0);
+  return gen_binomial(n, m);
+}
+
+// eq 22
+double erfc_F(int n, double Xi, double xi) {
+  const double ep = exp(-(Xi + xi) * (Xi + xi)), em = exp(-(Xi - xi) * (Xi - xi));
+  const double q = -1.0 / (4.0 * Xi * xi);
+  double s = 0.0, qp = q;
+  for (int p = 0; p <= n; p++) {
+    double sg = ((n - p) % 2) ? -1.0 : 1.0;
+    s += qp * (factorial_d(n + p) / (factorial_d(p) * factorial_d(n - p))) * (sg * ep - em);
+    qp *= q;
+  }
+  return 2.0 / sqrt(M_PI) * s;
+}
+// eq 24
+double erfc_H(int n, double Xi, double xi) {
+  const double A = std::pow(Xi, 2 * n + 1), a = std::pow(xi, 2 * n + 1);
+  return ((A + a) * erfc(Xi + xi) - (A - a) * erfc(Xi - xi)) / (2.0 * std::pow(xi * Xi, n + 1));
+}
+// eq 21
+double erfc_Phi_general(int n, double Xi, double xi) {
+  double s = erfc_F(n, Xi, xi) + erfc_H(n, Xi, xi);
+  for (int m = 1; m <= n; m++) {
+    double Am = std::pow(Xi, m), am = std::pow(xi, m);
+    s += erfc_F(n - m, Xi, xi) * ((Am * Am + am * am) / (Am * am));
+  }
+  return s;
+}
+// eqs 28, 29
+double erfc_D(int n, int k, double Xi) {
+  const double pref = exp(-Xi * Xi) / sqrt(M_PI) * std::pow(2.0, n + 1) * std::pow(Xi, 2 * n + 1);
+  if (k == 0) {
+    double s = 0.0;
+    for (int m = 1; m <= n; m++) s += 1.0 / (double_factorial_d(2 * (n - m) + 1) * std::pow(2 * Xi * Xi, m));
+    return erfc(Xi) + pref * s;
+  }
+  double s = 0.0;
+  for (int m = 1; m <= k; m++) {
+    double c = g_erfc_binomial_mode ? ref_binomial(m - k - 1, m - 1) : gen_binomial(m - k - 1, m - 1);
+    s += c * std::pow(2 * Xi * Xi, k - m) / double_factorial_d(2 * (n + k - m) + 1);
+  }
+  return pref * (2.0 * n + 1.0) / (factorial_d(k) * (2.0 * (n + k) + 1.0)) * s;
+}
+// eq 30, summed until the (paired) terms drop below machine precision, at most 32 terms (erfc_expn.cpp:150-178)
+double erfc_Phi_short(int n, double Xi, double xi) {
+  if (xi == 0.0 && n > 0) return 0.0;
+  if (n == 0 && xi == 0.0 && Xi == 0.0) return 1.0;
+  double phi = 0.0;
+  for (int k = 0; k <= 30; k += 2) {
+    double d = erfc_D(n, k, Xi) * std::pow(xi, n + 2 * k) + erfc_D(n, k + 1, Xi) * std::pow(xi, n + 2 * (k + 1));
+    phi += d;
+    if (fabs(d) < DBL_EPSILON * fabs(phi)) break;
+  }
+  return phi / std::pow(Xi, n + 1);
+}
+}  // namespace
+
+void set_erfc_binomial_mode(int mode) { g_erfc_binomial_mode = mode; }
+
+double erfc_Phi(int n, double Xi, double xi) {
+  if (n < 0) throw std::logic_error("erfc_Phi: negative order");
+  if (Xi < xi) std::swap(Xi, xi);
+  // p. 8624 of the paper: the closed form loses its digits to cancellation for small arguments
+  if (xi < 0.4 || (Xi < 0.5 && xi < 2 * Xi)) return erfc_Phi_short(n, Xi, xi);
+  return erfc_Phi_general(n, Xi, xi);
 }
 
 static legendre_provider_t g_legendre_provider = nullptr;

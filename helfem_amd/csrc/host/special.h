@@ -55,6 +55,22 @@ typedef void (*legendre_provider_t)(int Lmax, int Mmax, int lpad, double xi, dou
 void set_legendre_provider(legendre_provider_t fn);
 legendre_provider_t get_legendre_provider();
 
+/// Modified spherical Bessel functions of the range-separated (Yukawa) kernel, exp(-lambda r12)/r12 =
+/// 4 pi lambda sum_LM i_L(lambda r<) k_L(lambda r>) Y_LM^* Y_LM.  Conventions of libhelfem/src/utils.cpp:47-70:
+/// i_L(x) -> x^L/(2L+1)!! (i_0 = sinh x / x); k_L is GSL's k_l divided by pi/2 (k_0 = exp(-x)/x).  GSL is absent:
+/// ascending series / stable upward recurrences here, pinned by mpmath (tests/golden/rs_special.json).
+double bessel_il(double x, int L);
+double bessel_kl(double x, int L);
+/// Phi_n(Xi,xi) of the Legendre expansion erfc(mu r12)/r12 = mu sum_n Phi_n(mu r>, mu r<) P_n(cos gamma)
+/// (Angyan, Gerber, Marsman, J. Phys. A 39, 8613 (2006), eqs 21-30; libhelfem/src/erfc_expn.cpp:181-195: short-range
+/// power series for xi < 0.4 or (Xi < 0.5 and xi < 2 Xi), closed form otherwise).  Argument order is free.
+double erfc_Phi(int n, double Xi, double xi);
+/// Test hook.  The reference evaluates the generalised binomial coefficients C(m-k-1, m-1) of eq 29 with a helper
+/// (erfc_expn.cpp:46-70) that is wrong for upper arguments <= -2 and lower arguments >= 2 (C(-2,2) = 1 instead of 3),
+/// which puts relative errors of up to 1e-5 into the short-range series; mode 1 reproduces that helper so the tests
+/// can measure what it does to integrals and energies.  Default 0 = exact binomials.  The product never sets it.
+void set_erfc_binomial_mode(int mode);
+
 /// Angular product rule: cos(theta) Chebyshev nodes (ltheta of them) x nphi uniform phi
 void angular_chebyshev(int ltheta, int nphi, Vec &cth, Vec &phi, Vec &w);
 

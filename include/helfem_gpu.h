@@ -105,6 +105,11 @@ int hfg_basis_nuclear(const hfg_basis *basis, double *V);
 int hfg_basis_sym_blocks(const hfg_basis *basis, int symm, int *nblk, int64_t *blk_ptr, int64_t *blk_idx);
 /* TwoDBasis::compute_tei (basis.cpp:1166): primitive two-electron integral tables (host, threaded) */
 int hfg_compute_tei(hfg_basis *basis, int exchange);
+/* Range-separated exchange tables of the atomic program: rs_kind 1 = TwoDBasis::compute_yukawa(omega)
+ * (src/atomic/TwoDBasis.cpp:741), 2 = TwoDBasis::compute_erfc(omega) (:780).  Call before hfg_basis_upload, which
+ * then also places the screened-kernel tables in HBM.  A diatomic basis fails like the reference driver
+ * ("Range separated functionals are not supported.", src/diatomic/main.cpp:393). */
+int hfg_compute_rs_tei(hfg_basis *basis, int rs_kind, double omega);
 /* the same tables built on the GPU (diatomic: host computes quadrature points and Legendre values, the
  * O(Nlm nq p^4) sums run on the device and the tables stay there); follow with hfg_basis_upload */
 int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis, int exchange);
@@ -118,6 +123,9 @@ double hfg_gaunt_coefficient(int L, int M, int l, int m, int lp, int mp);       
 double hfg_modified_gaunt_coefficient(int lj, int mj, int L, int M, int li, int mi); /* gaunt.cpp:55 */
 void hfg_legendre_PQ(int Lmax, int Mmax, double xi, double *P, double *Q);           /* Legendre_Wrapper.f90:135,173 */
 double hfg_theta_lm(int l, int m, double cth);                                       /* spherical_harmonics.cpp:25 */
+double hfg_bessel_il(double x, int L);              /* utils::bessel_il, libhelfem/src/utils.cpp:47 */
+double hfg_bessel_kl(double x, int L);              /* utils::bessel_kl, libhelfem/src/utils.cpp:59 */
+double hfg_erfc_phi(int n, double Xi, double xi);   /* atomic::erfc_expn::Phi, libhelfem/src/erfc_expn.cpp:181 */
 void hfg_chebyshev_rule(int n, double *x, double *w);                                /* chebyshev.cpp:22 */
 void hfg_lobatto_nodes(int n, double *x);                                            /* lobatto.cpp:588 */
 
@@ -131,6 +139,8 @@ int hfg_basis_upload(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
 int hfg_coulomb(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *J);
 /* arma::mat TwoDBasis::exchange(const arma::mat & P) const           basis.h:249, basis.cpp:1532 */
 int hfg_exchange(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *K);
+/* arma::mat atomic::basis::TwoDBasis::rs_exchange(const arma::mat & P) const   TwoDBasis.h:184, TwoDBasis.cpp:1142 */
+int hfg_rs_exchange(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *K);
 /* void DFTGrid::eval_Fxc(x_func,x_pars,c_func,c_pars,P,H,Exc,Nel,Ekin,thr)   dftgrid.h:179 (restricted).
  * Functional ids are libxc's: 1 lda_x, 7 lda_c_vwn, 12 lda_c_pw, 101 gga_x_pbe, 130 gga_c_pbe, 406 hyb_gga_xc_pbeh
  * (its 0.25 exact exchange is the caller's K), 202 mgga_x_tpss, 231 mgga_c_tpss (Ekin returns the integral of tau);
@@ -160,6 +170,7 @@ int hfg_gemm(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int64_t
 /* ---- device-resident API (pointers into HBM, asynchronous on the context's stream) ---------- */
 int hfg_coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
 int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+int hfg_rs_exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
 /* dScal: 3 doubles in HBM receiving Exc, Nel, Ekin */
 int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH,
                     double *dScal, double dens_thr);

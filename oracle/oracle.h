@@ -61,6 +61,8 @@ Mat grid_kinetic(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
 Mat atomic_coulomb(const helfem::atomic::TwoDBasis &b, const Mat &P);
 /// atomic::basis::TwoDBasis::exchange  src/atomic/TwoDBasis.cpp:957-1140
 Mat atomic_exchange(const helfem::atomic::TwoDBasis &b, const Mat &P);
+/// atomic::basis::TwoDBasis::rs_exchange  src/atomic/TwoDBasis.cpp:1142-1322 (after compute_yukawa / compute_erfc)
+Mat atomic_rs_exchange(const helfem::atomic::TwoDBasis &b, const Mat &P);
 /// atomic::dftgrid::DFTGrid::eval_Fxc (restricted)  src/atomic/dftgrid.cpp:810-870
 void atomic_eval_Fxc(const helfem::atomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &P, Mat &H,
                      double &Exc, double &Nel, double &Ekin, double thr);

@@ -3,6 +3,7 @@
 // Loop-for-loop CPU restatement of the atomic Fock build of the reference:
 //   atomic::basis::TwoDBasis::coulomb   src/atomic/TwoDBasis.cpp:817-955
 //   atomic::basis::TwoDBasis::exchange  src/atomic/TwoDBasis.cpp:957-1140
+//   atomic::basis::TwoDBasis::rs_exchange  src/atomic/TwoDBasis.cpp:1142-1322
 //   atomic::dftgrid::DFTGridWorker / DFTGrid::eval_Fxc  src/atomic/dftgrid.cpp:710-790 (compute_bf), :810-870,
 //       with the same update_density / compute_xc / eval_Fxc algebra as the diatomic worker
 //       (w = w_ang w_rad r^2, h_r = 1, h_theta = r, h_phi = r sin(theta);  atomic/dftgrid.cpp:724-743).
@@ -144,6 +145,76 @@ Mat atomic_exchange(const TwoDBasis &b, const Mat &P) {
               if (!couple[L]) continue;
               const Mat &iint = (iel > jel) ? b.disjoint_m1L[L * Nel + iel] : b.disjoint_L[L * Nel + iel];
               const Mat &jint = (iel > jel) ? b.disjoint_L[L * Nel + jel] : b.disjoint_m1L[L * Nel + jel];
+              Mat T = helfem::matmul(submat(Rmat[L], ifirst, jfirst, Ni, Nj), false, jint, true);
+              Ksub += helfem::matmul(iint, false, T, false);
+            }
+            add_submat(K, jang * Nrad + ifirst, kang * Nrad + jfirst, Ksub, -1.0);
+          }
+        }
+      }
+    }
+  return K;
+}
+
+Mat atomic_rs_exchange(const TwoDBasis &b, const Mat &P) {
+  if (b.rs_ktei.empty()) throw std::logic_error("Primitive teis have not been computed!\n");
+  const bool yukawa = (b.rs_kind == 1);
+  const double lambda = b.rs_lambda;
+  const size_t Nel = b.Nel(), Nrad = b.Nrad();
+  const helfem::IVec &lval = b.lval, &mval = b.mval;
+  const size_t NL = b.N_L();
+  Mat K(b.Nbf(), b.Nbf());
+  for (size_t jang = 0; jang < lval.size(); jang++)
+    for (size_t kang = 0; kang < lval.size(); kang++) {
+      int lj = lval[jang], mj = mval[jang], lk = lval[kang], mk = mval[kang];
+      // radial helpers: angular sums (:1207-1245)
+      std::vector<Mat> Rmat(NL, Mat(Nrad, Nrad));
+      std::vector<bool> couple(NL, false);
+      for (size_t iang = 0; iang < lval.size(); iang++) {
+        int li = lval[iang], mi = mval[iang];
+        for (size_t lang = 0; lang < lval.size(); lang++) {
+          int ll = lval[lang], ml = mval[lang];
+          int M = mj - mi, Mp = mk - ml;
+          if (M != Mp) continue;
+          Mat Psub = submat(P, iang * Nrad, lang * Nrad, Nrad, Nrad);
+          double bdens = 0.0;
+          for (double v : Psub.d) bdens += v * v;
+          if (sqrt(bdens) < 10 * DBL_EPSILON) continue;
+          int Lmin = std::max(std::max(std::abs(li - lj), std::abs(lk - ll)), std::abs(M));
+          int Lmax = std::min(li + lj, lk + ll);
+          for (int L = Lmin; L <= Lmax; L++) {
+            double cpl = b.gaunt.coeff(lj, mj, L, M, li, mi) * b.gaunt.coeff(lk, mk, L, M, ll, ml);
+            if (cpl == 0.0) continue;
+            double Lfac = yukawa ? 4.0 * M_PI * lambda : 4.0 * M_PI * lambda / (2 * L + 1);  // :1240
+            add_submat(Rmat[L], 0, 0, Psub, Lfac * cpl);
+            couple[L] = true;
+          }
+        }
+      }
+      for (size_t iel = 0; iel < Nel; iel++) {
+        size_t ifirst, ilast;
+        b.fem.get_idx(iel, ifirst, ilast);
+        for (size_t jel = 0; jel < Nel; jel++) {
+          size_t jfirst, jlast;
+          b.fem.get_idx(jel, jfirst, jlast);
+          size_t Ni = ilast - ifirst + 1, Nj = jlast - jfirst + 1;
+          if (!yukawa || iel == jel) {  // the error-function kernel does not factorise (:1262)
+            Vec Ksub(Ni * Nj, 0.0);
+            for (size_t L = 0; L < NL; L++) {
+              if (!couple[L]) continue;
+              const Mat &ktei = yukawa ? b.rs_ktei[L * Nel + iel] : b.rs_ktei[(L * Nel + iel) * Nel + jel];
+              Vec y = matvec(ktei, submat(Rmat[L], ifirst, jfirst, Ni, Nj).d);
+              for (size_t k = 0; k < Ksub.size(); k++) Ksub[k] += y[k];
+            }
+            for (size_t jj = 0; jj < Nj; jj++)
+              for (size_t ii = 0; ii < Ni; ii++)
+                K(jang * Nrad + ifirst + ii, kang * Nrad + jfirst + jj) -= Ksub[jj * Ni + ii];
+          } else {
+            Mat Ksub(Ni, Nj);
+            for (size_t L = 0; L < NL; L++) {
+              if (!couple[L]) continue;
+              const Mat &iint = (iel > jel) ? b.disjoint_kL[L * Nel + iel] : b.disjoint_iL[L * Nel + iel];
+              const Mat &jint = (iel > jel) ? b.disjoint_iL[L * Nel + jel] : b.disjoint_kL[L * Nel + jel];
               Mat T = helfem::matmul(submat(Rmat[L], ifirst, jfirst, Ni, Nj), false, jint, true);
               Ksub += helfem::matmul(iint, false, T, false);
             }

@@ -49,6 +49,10 @@ struct OracleBackend : public helfem::scf::Backend {
   }
   Mat coulomb(const Mat &P) override { return ab ? oracle::atomic_coulomb(*ab, P) : oracle::coulomb(*b, P); }
   Mat exchange(const Mat &P) override { return ab ? oracle::atomic_exchange(*ab, P) : oracle::exchange(*b, P); }
+  Mat rs_exchange(const Mat &P) override {
+    if (!ab) throw std::logic_error("Range separated functionals are not supported.\n");
+    return oracle::atomic_rs_exchange(*ab, P);
+  }
   void eval_Fxc(int x, int c, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin, double thr) override {
     if (ab) oracle::atomic_eval_Fxc(*ab, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
     else oracle::eval_Fxc(*b, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
@@ -323,6 +327,28 @@ int orc_atomic_exchange(void *h, const double *P, double *K) {
   memcpy(K, Km.memptr(), sizeof(double) * N * N);
   ORC_CATCH
 }
+/// rs_kind 1: compute_yukawa(omega), 2: compute_erfc(omega)   (TwoDBasis.cpp:741/780)
+int orc_atomic_compute_rs(void *h, int rs_kind, double omega) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  if (rs_kind == 1) b->compute_yukawa(omega);
+  else if (rs_kind == 2) b->compute_erfc(omega);
+  else throw std::logic_error("unknown range-separation kernel");
+  ORC_CATCH
+}
+int orc_atomic_rs_exchange(void *h, const double *P, double *K) {
+  ORC_TRY
+  ABasis *b = (ABasis *)h;
+  size_t N = b->Nbf();
+  Mat Km = atomic_rs_exchange(*b, to_mat(P, N, N));
+  memcpy(K, Km.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+/// test hook, see special.h: 1 = the reference's binomial helper inside the erfc short-range series
+void orc_set_erfc_binomial_mode(int mode) { helfem::set_erfc_binomial_mode(mode); }
+double orc_bessel_il(double x, int L) { return helfem::bessel_il(x, L); }
+double orc_bessel_kl(double x, int L) { return helfem::bessel_kl(x, L); }
+double orc_erfc_phi(int n, double Xi, double xi) { return helfem::erfc_Phi(n, Xi, xi); }
 int orc_atomic_eval_fxc(void *h, int lang, int mang, int x_func, int c_func, const double *P, double *H, double *Exc,
                         double *Nel, double *Ekin, double thr) {
   ORC_TRY
@@ -409,6 +435,12 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
   o.method = method;
   parse_xc_func(o.x_func, o.c_func, o.method);
   o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
+  if (o.x_func == 178) {  // hyb_lda_xc_cam_lda0: omega = 1/3, alpha = 1/2, beta = -1/4, erfc kernel
+    o.kfrac = 0.5;
+    o.kshort = -0.25;
+    o.omega = 1.0 / 3.0;
+    o.rs_kind = 2;
+  }
   o.ldft = ldft;
   o.mdft = mdft;
   o.symmetry = symmetry;

@@ -26,6 +26,65 @@ void lda_x(double rho, double &exc, double &vrho) {
   vrho = 4.0 / 3.0 * exc;
 }
 
+// ---- short-range LDA exchange (libxc lda_x_erf / lda_x_yukawa): exc = exc_LDA F(a), a = omega/(2 kF) ----
+// F and dF/da written out by hand (closed forms for moderate a, the 1/a^2 expansions beyond), see xc_device.h for
+// the formulas and sources.  kind 1: Yukawa, 2: erfc.
+void attenuation(double a, int kind, double &F, double &dF) {
+  if (kind == 2) {
+    if (a > 0.75) {
+      double u = 1.0 / (a * a), t = 1.0;
+      F = 0.0;
+      dF = 0.0;
+      for (int k = 1; k <= 24; k++) {
+        t *= -0.25 * u / k;
+        double c = -t * 2.0 / ((2.0 * k + 1.0) * (k + 1.0) * (k + 2.0));
+        F += c;
+        dF += -2.0 * k * c / a;
+      }
+      return;
+    }
+    double e = exp(-0.25 / (a * a)), a3 = a * a * a;
+    double G = a * (sqrt(PI) * erf(0.5 / a) + (2.0 * a - 4.0 * a3) * e - 3.0 * a + 4.0 * a3);
+    double dG = sqrt(PI) * erf(0.5 / a) + (2.0 * a - 16.0 * a3) * e - 6.0 * a + 16.0 * a3;
+    F = 1.0 - 8.0 / 3.0 * G;
+    dF = -8.0 / 3.0 * dG;
+  } else {
+    if (a > 2.0) {
+      double u = 1.0 / (a * a), t = -1.0;
+      F = 0.0;
+      dF = 0.0;
+      for (int k = 1; k <= 40; k++) {
+        t *= -u;
+        double c = t * 2.0 / ((2.0 * k + 1.0) * (k + 1.0) * (k + 2.0));
+        F += c;
+        dF += -2.0 * k * c / a;
+      }
+      return;
+    }
+    double a2 = a * a, lg = log(1.0 + 1.0 / a2);
+    double G = a * (atan(1.0 / a) + 0.25 * a - 0.25 * a * (a2 + 3.0) * lg);
+    double dG = atan(1.0 / a) - a / (1.0 + a2) + 0.5 * a - (a2 * a + 1.5 * a) * lg + a * (a2 + 3.0) / (2.0 * (a2 + 1.0));
+    F = 1.0 - 8.0 / 3.0 * G;
+    dF = -8.0 / 3.0 * dG;
+  }
+}
+void lda_x_sr(double rho, double omega, int kind, double &exc, double &vrho) {
+  double ex, vx;
+  lda_x(rho, ex, vx);
+  double kf = cbrt(3.0 * PI * PI * rho), a = 0.5 * omega / kf, F, dF;
+  attenuation(a, kind, F, dF);
+  exc = ex * F;
+  vrho = ex * (4.0 / 3.0 * F - a / 3.0 * dF);  // da/drho = -a/(3 rho)
+}
+// exchange part of hyb_lda_xc_cam_lda0: 1/2 lda_x + 1/4 lda_x_erf(omega = 1/3)
+void cam_lda0_x(double rho, double &exc, double &vrho) {
+  double e1, v1, e2, v2;
+  lda_x(rho, e1, v1);
+  lda_x_sr(rho, 1.0 / 3.0, 2, e2, v2);
+  exc = 0.5 * e1 + 0.25 * e2;
+  vrho = 0.5 * v1 + 0.25 * v2;
+}
+
 // ---- VWN5 paramagnetic correlation ----
 void lda_c_vwn(double rho, double &exc, double &vrho) {
   const double A = 0.0310907, b = 3.72744, c = 12.9352, x0 = -0.10498;
@@ -61,6 +120,13 @@ void lda_c_pw(double rho, double &exc, double &vrho) {
   double rs = cbrt(3.0 / (4.0 * PI * rho));
   double ec, dec;
   pw92(rs, false, ec, dec);
+  exc = ec;
+  vrho = ec - rs / 3.0 * dec;
+}
+void lda_c_pw_mod(double rho, double &exc, double &vrho) {
+  double rs = cbrt(3.0 / (4.0 * PI * rho));
+  double ec, dec;
+  pw92(rs, true, ec, dec);
   exc = ec;
   vrho = ec - rs / 3.0 * dec;
 }
@@ -124,6 +190,17 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
       case 1: lda_x(r, e, v); break;
       case 7: lda_c_vwn(r, e, v); break;
       case 12: lda_c_pw(r, e, v); break;
+      case 13: lda_c_pw_mod(r, e, v); break;
+      case 546: lda_x_sr(r, 0.3, 2, e, v); break;
+      case 641: lda_x_sr(r, 0.3, 1, e, v); break;
+      case 178: {  // hyb_lda_xc_cam_lda0, DFT part
+        double e2, v2;
+        cam_lda0_x(r, e, v);
+        lda_c_pw_mod(r, e2, v2);
+        e += e2;
+        v += v2;
+        break;
+      }
       case 101: gga_x_pbe(r, sigma[i], e, v, vs); break;
       case 130: gga_c_pbe(r, sigma[i], e, v, vs); break;
       case 406: {  // hyb_gga_xc_pbeh (PBE0), DFT part
@@ -245,6 +322,15 @@ D3 eps_pbe_c(D3 rho, D3 rs, D3 z, D3 sig) {
 
 void xc_polarized(int id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho, double *vsigma,
                   double thr) {
+  if (id == 178) {  // hyb_lda_xc_cam_lda0, DFT part: spin-scaled exchange mixture + lda_c_pw_mod
+    Vec e(N), v(2 * N);
+    xc_polarized(-178, N, rho, sigma, exc, vrho, nullptr, thr);
+    xc_polarized(13, N, rho, sigma, e.data(), v.data(), nullptr, thr);
+    for (size_t i = 0; i < N; i++) exc[i] += e[i];
+    for (size_t i = 0; i < 2 * N; i++) vrho[i] += v[i];
+    if (vsigma) std::fill(vsigma, vsigma + 3 * N, 0.0);
+    return;
+  }
   if (id == 406) {  // hyb_gga_xc_pbeh (PBE0), DFT part: 0.75 gga_x_pbe + gga_c_pbe
     Vec e(N), v(2 * N), vs(3 * N);
     xc_polarized(101, N, rho, sigma, exc, vrho, vsigma, thr);
@@ -272,11 +358,20 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
     }
     switch (id) {
       case 1:
+      case 546:
+      case 641:
+      case -178:
       case 101: {  // spin-scaled exchange
         double ea, va, vsa = 0, eb, vb, vsb = 0;
         if (id == 1) {
           lda_x(2.0 * ra, ea, va);
           lda_x(2.0 * rb, eb, vb);
+        } else if (id == 546 || id == 641) {
+          lda_x_sr(2.0 * ra, 0.3, id == 546 ? 2 : 1, ea, va);
+          lda_x_sr(2.0 * rb, 0.3, id == 546 ? 2 : 1, eb, vb);
+        } else if (id == -178) {
+          cam_lda0_x(2.0 * ra, ea, va);
+          cam_lda0_x(2.0 * rb, eb, vb);
         } else {
           gga_x_pbe(2.0 * ra, 4.0 * saa, ea, va, vsa);
           gga_x_pbe(2.0 * rb, 4.0 * sbb, eb, vb, vsb);
@@ -292,12 +387,13 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
       }
       case 7:
       case 12:
+      case 13:
       case 130: {
         D3 a = var(ra, 0), b = var(rb, 1), st = var(saa + 2.0 * sab + sbb, 2);
         D3 n = a + b;
         D3 rs = Dcbrt((3.0 / (4.0 * PI)) / n);
         D3 z = (a - b) / n;
-        D3 e = (id == 7) ? eps_vwn(rs, z) : (id == 12) ? eps_pw(rs, z, false) : eps_pbe_c(n, rs, z, st);
+        D3 e = (id == 7) ? eps_vwn(rs, z) : (id == 12) ? eps_pw(rs, z, false) : (id == 13) ? eps_pw(rs, z, true) : eps_pbe_c(n, rs, z, st);
         D3 en = n * e;
         exc[i] = e.v;
         vrho[2 * i] = en.d[0];
@@ -401,6 +497,10 @@ static int find_func(const std::string &name) {
   if (!strcasecmp(name.c_str(), "lda_x")) return 1;
   if (!strcasecmp(name.c_str(), "lda_c_vwn")) return 7;
   if (!strcasecmp(name.c_str(), "lda_c_pw")) return 12;
+  if (!strcasecmp(name.c_str(), "lda_c_pw_mod")) return 13;
+  if (!strcasecmp(name.c_str(), "lda_x_erf")) return 546;
+  if (!strcasecmp(name.c_str(), "lda_x_yukawa")) return 641;
+  if (!strcasecmp(name.c_str(), "hyb_lda_xc_cam_lda0")) return 178;
   if (!strcasecmp(name.c_str(), "gga_x_pbe")) return 101;
   if (!strcasecmp(name.c_str(), "gga_c_pbe")) return 130;
   if (!strcasecmp(name.c_str(), "hyb_gga_xc_pbeh")) return 406;

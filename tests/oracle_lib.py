@@ -53,6 +53,15 @@ def lib():
         L.orc_scf_atomic.argtypes = [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                                           ctypes.c_char_p] + [ctypes.c_int] * 6 + [
                                                               ctypes.c_double, ctypes.c_int, c_double_p]
+        L.orc_atomic_compute_rs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+        L.orc_atomic_rs_exchange.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
+        for nm in ("orc_bessel_il", "orc_bessel_kl"):
+            getattr(L, nm).argtypes = [ctypes.c_double, ctypes.c_int]
+            getattr(L, nm).restype = ctypes.c_double
+        L.orc_erfc_phi.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double]
+        L.orc_erfc_phi.restype = ctypes.c_double
+        L.orc_set_erfc_binomial_mode.argtypes = [ctypes.c_int]
+        L.orc_set_erfc_binomial_mode.restype = None
         for name in ("orc_basis_destroy", "orc_basis_dims", "orc_compute_tei", "orc_coulomb", "orc_exchange",
                      "orc_grid_overlap", "orc_grid_kinetic"):
             getattr(L, name).argtypes = None
@@ -210,6 +219,18 @@ class OracleAtomicBasis(object):
         _check(lib().orc_atomic_exchange(self.h, _p(P), _p(K)))
         return K
 
+    def compute_yukawa(self, lam):
+        _check(lib().orc_atomic_compute_rs(self.h, 1, float(lam)))
+
+    def compute_erfc(self, mu):
+        _check(lib().orc_atomic_compute_rs(self.h, 2, float(mu)))
+
+    def rs_exchange(self, P):
+        P = _f(P)
+        K = np.zeros_like(P, order="F")
+        _check(lib().orc_atomic_rs_exchange(self.h, _p(P), _p(K)))
+        return K
+
     def eval_Fxc(self, lang, mang, x_func, c_func, P, thr=1e-12):
         P = _f(P)
         H = np.zeros_like(P, order="F")
@@ -225,6 +246,23 @@ class OracleAtomicBasis(object):
         _check(getattr(lib(), self._fxc_pol)(self.h, lang, mang, x_func, c_func, _p(Pa), _p(Pb), _p(Ha), _p(Hb),
                                              ctypes.byref(exc), ctypes.byref(nel), ctypes.byref(ekin), thr))
         return Ha, Hb, exc.value, nel.value, ekin.value
+
+
+def bessel_il(x, L):
+    return lib().orc_bessel_il(float(x), int(L))
+
+
+def bessel_kl(x, L):
+    return lib().orc_bessel_kl(float(x), int(L))
+
+
+def erfc_phi(n, Xi, xi):
+    return lib().orc_erfc_phi(int(n), float(Xi), float(xi))
+
+
+def set_erfc_binomial_mode(mode):
+    """test hook: 1 = the reference's binomial helper in the erfc short-range series (see host/special.h)"""
+    lib().orc_set_erfc_binomial_mode(int(mode))
 
 
 def xc_polarized(func_id, rho, sigma, thr=1e-12):
