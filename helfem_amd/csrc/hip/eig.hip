@@ -23,6 +23,7 @@ namespace hfg {
 
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 
@@ -395,16 +396,40 @@ __global__ __launch_bounds__(256) void k_backtransform_lds(EigBatch b) {
 }
 
 // ---- 6. sort + scatter ---------------------------------------------------------------------------------
-__global__ void k_rank(const double *__restrict__ E, int n, int *__restrict__ rank) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double ei = E[i];
+// rank[i] = number of eigenvalues ordered before E[i] (ties by index).  Grid (ceil(n/256), segments): a workgroup
+// compares its 256 values with one segment of E staged through LDS in chunks of 256; the segment counts are integer
+// atomic adds into the zero-initialised rank array (order independent).
+constexpr int RANK_SEG = 8;
+__global__ __launch_bounds__(256) void k_rank(const double *__restrict__ E, int n, int *__restrict__ rank) {
+  __shared__ double sE[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const double ei = (i < n) ? E[i] : 0.0;
+  const int seg = (n + RANK_SEG - 1) / RANK_SEG;
+  const int j0 = blockIdx.y * seg, j1 = min(n, j0 + seg);
   int r = 0;
-  for (int j = 0; j < n; j++) {
-    double ej = E[j];
-    r += (ej < ei) || (ej == ei && j < i);
+  for (int c = j0; c < j1; c += 256) {
+    __syncthreads();
+    sE[threadIdx.x] = (c + (int)threadIdx.x < j1) ? E[c + threadIdx.x] : 0.0;
+    __syncthreads();
+    const int m = min(256, j1 - c);
+    if (m == 256) {
+#pragma unroll 16
+      for (int jj = 0; jj < 256; jj++) {
+        const double ej = sE[jj];
+        r += (ej < ei) || (ej == ei && c + jj < i);
+      }
+    } else {
+      for (int jj = 0; jj < m; jj++) {
+        const double ej = sE[jj];
+        r += (ej < ei) || (ej == ei && c + jj < i);
+      }
+    }
   }
-  rank[i] = r;
+  if (i < n && r) atomicAdd(&rank[i], r);
+}
+static void launch_rank(hfg_ctx *ctx, const double *E, int n, int *rank) {
+  HFG_HIP_CHECK(hipMemsetAsync(rank, 0, sizeof(int) * n, ctx->stream));
+  hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256, RANK_SEG), dim3(256), 0, ctx->stream, E, n, rank);
 }
 
 // Cout(rows[i], rank[coff+j]) = Cb(i,j) ; Eout[rank[coff+j]] = Eb[j]   (rows==nullptr: identity)
@@ -625,7 +650,8 @@ static void backtransform_wy(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nb
   for (int p = P - 1; p >= 0; p--) {
     gemm_tasklist64_dev(ctx, w.btslab.p + (size_t)p * BT_S * nblk, BT_S * nblk, BT_KB, nmax);
     hipLaunchKernelGGL(k_bt_wsum, dim3(64, nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk, BT_S);
-    gemm_tasklist_dev(ctx, w.bttasks.p + ((size_t)2 * P + p) * nblk, nblk, nmax, nmax);
+    static const int acc_tile = getenv("HELFEM_ACC_TILE") ? atoi(getenv("HELFEM_ACC_TILE")) : 0;  // A/B runs: 64 or 128
+    gemm_tasklist_acc_dev(ctx, w.bttasks.p + ((size_t)2 * P + p) * nblk, nblk, nmax, nmax, acc_tile != 128);
   }
   HFG_HIP_CHECK(hipGetLastError());
 }
@@ -750,7 +776,7 @@ void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC) 
   eig_sym_batch(ctx, w, 1, &n);
   DevBuf<int> &rank = w.ibuf1;
   rank.resize(n + 8);
-  hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w.d[0].p, n, rank.p);
+  launch_rank(ctx, w.d[0].p, n, rank.p);
   hipLaunchKernelGGL(k_scatter_cols, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, w.Z[0].p, n, n,
                      (const int64_t *)nullptr, rank.p, 0, w.d[0].p, n, dC, dE);
   check_status(ctx, w, 1);
@@ -776,7 +802,7 @@ void eig_gsym_dev(hfg_ctx *ctx, int N, int n, const double *dF, const double *dS
   }
   DevBuf<int> &rank = w.ibuf1;
   rank.resize(n + 8);
-  hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w.d[0].p, n, rank.p);
+  launch_rank(ctx, w.d[0].p, n, rank.p);
   hipLaunchKernelGGL(k_scatter_cols, dim3((N + 255) / 256, n), dim3(256), 0, ctx->stream, Ctmp.p, N, n,
                      (const int64_t *)nullptr, rank.p, 0, w.d[0].p, N, dC, dE);
   check_status(ctx, w, 1);
@@ -929,7 +955,7 @@ void eig_assemble_dev(hfg_ctx *ctx, int N, int nblk, const int64_t *blk_ptr, con
   DevBuf<int> &rank = w.ibuf1;
   rank.resize(N + 8);
   HFG_HIP_CHECK(hipMemsetAsync(dC, 0, sizeof(double) * (size_t)N * N, s));
-  hipLaunchKernelGGL(k_rank, dim3((N + 255) / 256), dim3(256), 0, s, Etmp.p, N, rank.p);
+  launch_rank(ctx, Etmp.p, N, rank.p);
   for (int ib = 0; ib < nblk; ib++) {
     int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
     hipLaunchKernelGGL(k_scatter_cols, dim3((n + 255) / 256, n), dim3(256), 0, s, dBlockBuf + (size_t)ib * slot, n, n,

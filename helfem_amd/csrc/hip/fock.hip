@@ -277,36 +277,65 @@ __global__ void k_coulomb_bra(const double *__restrict__ Jaux, int A, int E, int
 // X1 radial contraction of the density: D0[Q][x][y] = sum_ij B_i(q) Pc[x][y][e][j][i] B_j(q),
 //    D1[Q][x][y] = sum_ij B'_i(q) Pc[..][j][i] B_j(q)            (replaces Pv = P conj(bf), dftgrid.cpp:62)
 //    (meta-GGA: D2[Q][x][y] = sum_ij B'_i Pc B'_j for the kinetic energy density)
-__global__ void k_xc_density_radial(const double *__restrict__ Pc, const double *__restrict__ B,
-                                    const double *__restrict__ dB, int A, int E, int p, int nq, int do_grad,
-                                    int do_tau, int rank, int nranks, double *__restrict__ D0, double *__restrict__ D1,
-                                    double *__restrict__ D2) {
-  extern __shared__ double sh[];  // P[pp]
-  int xy = blockIdx.x, e = blockIdx.y;
-  int pp = p * p;
-  for (int t = threadIdx.x; t < pp; t += blockDim.x) sh[t] = Pc[((size_t)xy * E + e) * pp + t];
+__global__ __launch_bounds__(256) void k_xc_density_radial(const double *__restrict__ Pc, const double *__restrict__ B,
+                                                           const double *__restrict__ dB, int A, int E, int p, int nq,
+                                                           int do_grad, int do_tau, int rank, int nranks,
+                                                           double *__restrict__ D0, double *__restrict__ D1,
+                                                           double *__restrict__ D2) {
+  // One workgroup per (shell pair, element).  The p x p block of P and the element's B, B' tables sit in LDS (the
+  // tables transposed to [i][q]: consecutive q <-> consecutive banks); thread (q, jc) forms the rows j = jc, jc+NJ, ...
+  // of T = P b(q), contracts them with b_j, b'_j, and the NJ partial results of a point are summed through LDS in a
+  // fixed order.
+  extern __shared__ double sh[];  // P[pp], Bt[p][nq], dBt[p][nq], part[3][NJ][nq]
+  const int xy = blockIdx.x, e = blockIdx.y;
+  const int pp = p * p;
+  double *sP = sh, *sB = sh + pp, *sdB = sB + p * nq;
+  const int NJ = blockDim.x / nq > 0 ? min((int)(blockDim.x / nq), p) : 1;
+  double *part = sdB + p * nq;
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) sP[t] = Pc[((size_t)xy * E + e) * pp + t];
+  for (int t = threadIdx.x; t < p * nq; t += blockDim.x) {
+    int q = t / p, i = t % p;
+    sB[i * nq + q] = B[((size_t)e * nq + q) * p + i];
+    sdB[i * nq + q] = dB[((size_t)e * nq + q) * p + i];
+  }
   __syncthreads();
-  size_t AA = (size_t)A * A;
-  for (int q = threadIdx.x; q < nq; q += blockDim.x) {
-    if ((e * nq + q) % nranks != rank) continue;  // radial quadrature points are the multi-GPU shards of XC
-    const double *b = B + ((size_t)e * nq + q) * p;
-    const double *db = dB + ((size_t)e * nq + q) * p;
+  const size_t AA = (size_t)A * A;
+  // work items (q, jc), q fastest; with nq <= blockDim.x every point is finished in one pass
+  for (int q0 = 0; q0 < nq; q0 += blockDim.x / NJ) {
+    const int ql = threadIdx.x % (blockDim.x / NJ), jc = threadIdx.x / (blockDim.x / NJ);
+    const int q = q0 + ql;
     double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-    for (int j = 0; j < p; j++) {
-      double s0 = 0.0, s1 = 0.0;
-      for (int i = 0; i < p; i++) {
-        double pv = sh[j * p + i];
-        s0 += b[i] * pv;
-        s1 += db[i] * pv;
+    if (q < nq && jc < NJ)
+      for (int j = jc; j < p; j += NJ) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < p; i++) {
+          double pv = sP[j * p + i];
+          s0 += sB[i * nq + q] * pv;
+          s1 += sdB[i * nq + q] * pv;
+        }
+        d0 += s0 * sB[j * nq + q];
+        d1 += s1 * sB[j * nq + q];
+        d2 += s1 * sdB[j * nq + q];
       }
-      d0 += s0 * b[j];
-      d1 += s1 * b[j];
-      d2 += s1 * db[j];
+    if (q < nq && jc < NJ) {
+      part[(0 * NJ + jc) * nq + q] = d0;
+      part[(1 * NJ + jc) * nq + q] = d1;
+      part[(2 * NJ + jc) * nq + q] = d2;
     }
-    size_t Q = (size_t)e * nq + q;
-    D0[Q * AA + xy] = d0;
-    if (do_grad) D1[Q * AA + xy] = d1;
-    if (do_tau) D2[Q * AA + xy] = d2;
+    __syncthreads();
+    if (jc == 0 && q < nq && (e * nq + q) % nranks == rank) {  // radial quadrature points are the multi-GPU shards of XC
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int k = 0; k < NJ; k++) {
+        a0 += part[(0 * NJ + k) * nq + q];
+        a1 += part[(1 * NJ + k) * nq + q];
+        a2 += part[(2 * NJ + k) * nq + q];
+      }
+      const size_t Q = (size_t)e * nq + q;
+      D0[Q * AA + xy] = a0;
+      if (do_grad) D1[Q * AA + xy] = a1;
+      if (do_tau) D2[Q * AA + xy] = a2;
+    }
+    __syncthreads();
   }
 }
 
@@ -730,12 +759,13 @@ __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__
                                  const double *__restrict__ GC, const double *__restrict__ B,
                                  const double *__restrict__ dB, int A, int E, int p, int nq, int do_grad, int do_tau,
                                  int rank, int nranks, double *__restrict__ Hc) {
-  extern __shared__ double sh[];  // gs[nq], g1[nq], g2[nq], g3[nq]
+  extern __shared__ double sh[];  // gs[nq], g1[nq], g2[nq], g3[nq], B[nq][p], dB[nq][p] of this element
   int xy = blockIdx.x, e = blockIdx.y;
   int x = xy / A, y = xy % A;
   int yx = y * A + x;
   size_t AA = (size_t)A * A;
   double *gs = sh, *g1 = sh + nq, *g2 = sh + 2 * nq, *g3 = sh + 3 * nq;
+  double *sB = sh + 4 * nq, *sdB = sB + nq * p;
   for (int q = threadIdx.x; q < nq; q += blockDim.x) {
     size_t Q = (size_t)e * nq + q;
     bool own = ((int)(Q % nranks) == rank);
@@ -744,15 +774,18 @@ __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__
     g2[q] = (own && do_grad) ? GB[Q * AA + yx] : 0.0;
     g3[q] = (own && do_tau) ? GC[Q * AA + xy] + GC[Q * AA + yx] : 0.0;
   }
+  for (int t = threadIdx.x; t < nq * p; t += blockDim.x) {
+    sB[t] = B[(size_t)e * nq * p + t];
+    sdB[t] = dB[(size_t)e * nq * p + t];
+  }
   __syncthreads();
   int pp = p * p;
   for (int t = threadIdx.x; t < pp; t += blockDim.x) {
     int n = t % p, m = t / p;
     double acc = 0.0;
     for (int q = 0; q < nq; q++) {
-      const double *b = B + ((size_t)e * nq + q) * p;
-      const double *db = dB + ((size_t)e * nq + q) * p;
-      acc += b[n] * b[m] * gs[q] + db[n] * b[m] * g1[q] + b[n] * db[m] * g2[q] + db[n] * db[m] * g3[q];
+      const double bn = sB[q * p + n], bm = sB[q * p + m], dn = sdB[q * p + n], dm = sdB[q * p + m];
+      acc += bn * bm * gs[q] + dn * bm * g1[q] + bn * dm * g2[q] + dn * dm * g3[q];
     }
     Hc[((size_t)xy * E + e) * pp + t] = acc;
   }
@@ -776,6 +809,13 @@ __global__ void k_xc_sum_partials(const double *__restrict__ partial, size_t NQ,
 // launchers
 // -------------------------------------------------------------------------------------------------
 static int round_up64(int n) { return ((n + 63) / 64) * 64; }
+// LDS of k_xc_density_radial (256 threads): P block, the two transposed tables, the partial sums of the j classes
+static size_t xc_density_radial_lds(int p, int nq) {
+  const int NJ = (256 / nq > 0) ? std::min(256 / nq, p) : 1;
+  size_t shb = (size_t)(p * p + 2 * p * nq + 3 * NJ * nq) * sizeof(double);
+  if (shb > 64 * 1024) throw std::runtime_error("radial quadrature too large for the XC density kernel's LDS tables");
+  return shb;
+}
 
 struct FockAux {
   DevBuf<int> pure_shell, pure_n, lmpos;
@@ -905,7 +945,7 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   int maxgrp = 0;
   for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
 
-  hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(std::min(256, round_up64(nq))), p * p * sizeof(double),
+  hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(256), xc_density_radial_lds(p, nq),
                      ctx->stream, dPc, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau, ctx->shard_rank, ctx->shard_n, a.D0.p,
                      a.D1.p, a.D2.p);
   hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
@@ -920,7 +960,7 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 5 * nth * sizeof(double), ctx->stream,
                      a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, NQ,
                      ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
-  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 4 * nq * sizeof(double),
+  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 2 * nq * p) * sizeof(double),
                      ctx->stream, a.GA.p, a.GB.p, a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                      ctx->shard_rank, ctx->shard_n, dHc);
   hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
@@ -965,7 +1005,7 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
   int maxgrp = 0;
   for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
   for (int sp = 0; sp < 2; sp++) {
-    hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(std::min(256, round_up64(nq))), p * p * sizeof(double),
+    hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(256), xc_density_radial_lds(p, nq),
                        ctx->stream, sp ? dPcb : dPca, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, 0, ctx->shard_rank,
                        ctx->shard_n, a.D0.p, a.D1.p, (double *)nullptr);
     hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
@@ -984,7 +1024,7 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
     hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 5 * nth * sizeof(double), ctx->stream,
                        a.Fo.p + (size_t)sp * 3 * nv, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad,
                        0, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, (double *)nullptr);
-    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), 4 * nq * sizeof(double),
+    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 2 * nq * p) * sizeof(double),
                        ctx->stream, a.GA.p, a.GB.p, (const double *)nullptr, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, 0,
                        ctx->shard_rank, ctx->shard_n, sp ? dHcb : dHca);
   }

@@ -25,7 +25,11 @@ namespace hfg {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // one BM x BN tile (linear tile index id) of one product; As/Bs are the workgroup's LDS tiles
-template <int BM, int BN>
+// ACC: the epilogue reads C (beta != 0).  All loads of the old tile are issued back to back with clamped indices
+// before the first store: interleaved "load, scale, store" through the bounds branches serialises 64 memory round
+// trips per thread, which made the rank-2NB trailing updates and the compact-WY updates of the eigensolver (K = 32
+// or 64: pure streaming of C) run at 1.2-1.6 TB/s.
+template <int BM, int BN, bool ACC = false>
 __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
                                            const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
                                            double beta, double *__restrict__ C, int ldc, double (*As)[BM + 16],
@@ -56,6 +60,22 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
   for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int j = 0; j < TN; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  // ACC with 64 x 64 tiles: the 16 old values of C per thread are requested before the K loop, so their latency
+  // hides behind the operand loads and the MFMAs (the product is a rank-32/64 update: C is all the traffic there is)
+  constexpr bool PRE = ACC && (TM * TN <= 4);
+  double cpre[PRE ? TM : 1][PRE ? TN : 1][4];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int gm = min(bm + wm + i * 16 + l15, M - 1), gn = min(bn + wn + j * 16 + l4 + 4 * r, N - 1);
+          cpre[i][j][r] = C[(size_t)gn * ldc + gm];
+        }
+  }
 
   double ra[EA], rb[EB];
   auto load_tiles = [&](int k0) {
@@ -142,6 +162,43 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
     }
   }
   // acc[i][j][r] = C[bm+wm+16i+l15][bn+wn+16j+l4+4r]
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int gm = bm + wm + i * 16 + l15, gn = bn + wn + j * 16 + l4 + 4 * r;
+          if (gm < M && gn < N) C[(size_t)gn * ldc + gm] = alpha * acc[i][j][r] + beta * cpre[i][j][r];
+        }
+    return;
+  } else if constexpr (ACC) {
+    constexpr int HI = (TM > 2) ? TM / 2 : TM;  // rows of 16 handled per batch (32 or 16 values in flight per thread)
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += HI) {
+      double cv[HI][TN][4];
+#pragma unroll
+      for (int i = 0; i < HI; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            int gm = min(bm + wm + (i0 + i) * 16 + l15, M - 1), gn = min(bn + wn + j * 16 + l4 + 4 * r, N - 1);
+            cv[i][j][r] = C[(size_t)gn * ldc + gm];
+          }
+#pragma unroll
+      for (int i = 0; i < HI; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            int gm = bm + wm + (i0 + i) * 16 + l15, gn = bn + wn + j * 16 + l4 + 4 * r;
+            if (gm < M && gn < N) C[(size_t)gn * ldc + gm] = alpha * acc[i0 + i][j][r] + beta * cv[i][j][r];
+          }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -168,7 +225,7 @@ __global__ __launch_bounds__(256) void k_dgemm(int transA, int transB, int M, in
 }
 
 // the same tile engine over a device-side task list: C_t = A_t B_t, grid (max tiles, tasks)
-template <int BM, int BN>
+template <int BM, int BN, bool ACC = false>
 __global__ __launch_bounds__(256) void k_dgemm_tasklist(const GemmTask *__restrict__ tasks) {
   __shared__ double As[16][BM + 16];
   __shared__ double Bs[16][BN + 16];
@@ -176,7 +233,22 @@ __global__ __launch_bounds__(256) void k_dgemm_tasklist(const GemmTask *__restri
   if (t.M <= 0 || t.N <= 0) return;
   const int nt = ((t.M + BM - 1) / BM) * ((t.N + BN - 1) / BN);
   if ((int)blockIdx.x >= nt) return;
-  dgemm_tile<BM, BN>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As, Bs);
+  dgemm_tile<BM, BN, ACC>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As,
+                          Bs);
+}
+
+/// task lists whose products accumulate into C (beta != 0 in every active task): streaming epilogue
+void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64) {
+  if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  if (tile64) {
+    const int tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
+    hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  } else {
+    const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
+    hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  }
+  HFG_HIP_CHECK(hipGetLastError());
 }
 
 /// launches the task list with 64 x 64 tiles (small products, more workgroups)

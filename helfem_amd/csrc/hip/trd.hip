@@ -27,6 +27,7 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
               const double *B, int ldb, double beta, double *C, int ldc);
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
 
 constexpr int TB_MAXB = 8;
 constexpr int TB_NB = 16;   // panel width (measured: 16 beats 8 and 32 at n ~ 1400 x 3 blocks)
@@ -955,8 +956,8 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
       const int mt = nmax - j0 - TB_NB;
       if (mt > 0) {
         const GemmTask *pt = w.ptasks.p + (size_t)(j0 / TB_NB) * nblk;
-        if ((long)((mt + 127) / 128) * ((mt + 127) / 128) * nblk >= 200) gemm_tasklist_dev(ctx, pt, nblk, mt, mt);
-        else gemm_tasklist64_dev(ctx, pt, nblk, mt, mt);
+        static const int acc_tile = getenv("HELFEM_ACC_TILE") ? atoi(getenv("HELFEM_ACC_TILE")) : 0;  // A/B runs: 64 or 128
+        gemm_tasklist_acc_dev(ctx, pt, nblk, mt, mt, acc_tile != 128);
       }
     }
     for (int k = 0; k < nblk; k++) {

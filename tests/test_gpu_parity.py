@@ -472,8 +472,18 @@ def test_unrestricted_scf_energy_parity(hf, name, prog, kw, lit, littol):
     o = ofn(convthr=1e-9, maxit=80, **kw)
     assert g["converged"] and o["converged"]
     assert abs(g["Etot"] - o["Etot"]) < 1e-8 * max(1.0, abs(o["Etot"]) / 10), (name, g["Etot"], o["Etot"])
-    for k in ("Ekin", "Epot", "Ecoul", "Exx", "Exc"):
-        assert abs(g[k] - o[k]) < 1e-6 * max(1.0, abs(o[k]) / 10), (name, k, g[k], o[k])
+    if kw.get("maverage"):
+        # The averaged Fock operator leaves the open p shell exactly degenerate in m: which member the Aufbau rule
+        # occupies (the torus of m = +-1 or the dumbbell of m = 0) is decided by rounding noise in the eigenvalue order.
+        # The members share the radial functions, hence Etot, Ekin, Epot and the SUM of the two-electron terms; the
+        # split between Coulomb and exchange energy differs between them (observed: 8.6e-3 Eh for boron).
+        g2, o2 = (g["Ecoul"] + g["Exx"] + g["Exc"]), (o["Ecoul"] + o["Exx"] + o["Exc"])
+        assert abs(g2 - o2) < 1e-6 * max(1.0, abs(o2) / 10), (name, "two-electron", g2, o2)
+        for k in ("Ekin", "Epot"):
+            assert abs(g[k] - o[k]) < 1e-6 * max(1.0, abs(o[k]) / 10), (name, k, g[k], o[k])
+    else:
+        for k in ("Ekin", "Epot", "Ecoul", "Exx", "Exc"):
+            assert abs(g[k] - o[k]) < 1e-6 * max(1.0, abs(o[k]) / 10), (name, k, g[k], o[k])
     if lit is not None:
         assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
 
