@@ -57,6 +57,14 @@ using namespace hfg;
   return 0;
 
 // ---- context helpers ---------------------------------------------------------------------------
+hipStream_t hfg_ctx::side() {
+  if (!side_stream) {
+    HFG_HIP_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    HFG_HIP_CHECK(hipEventCreateWithFlags(&side_ev[0], hipEventDisableTiming));
+    HFG_HIP_CHECK(hipEventCreateWithFlags(&side_ev[1], hipEventDisableTiming));
+  }
+  return side_stream;
+}
 void *hfg_ctx::pinned_buf(size_t bytes) {
   if (bytes > pinned_bytes) {
     if (pinned) (void)hipHostFree(pinned);
@@ -180,6 +188,12 @@ int hfg_ctx_destroy(hfg_ctx *c) {
     }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->side_stream) {
+    (void)hipStreamSynchronize(c->side_stream);
+    (void)hipStreamDestroy(c->side_stream);
+    (void)hipEventDestroy(c->side_ev[0]);
+    (void)hipEventDestroy(c->side_ev[1]);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   HFG_CATCH

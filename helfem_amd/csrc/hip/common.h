@@ -64,6 +64,11 @@ struct hfg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // second, non-blocking stream for work that is independent of what runs on `stream` (the compact-WY set-up of the
+  // back-transformation beside the divide-and-conquer stage); ordered with `stream` through the two events
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_ev[2] = {nullptr, nullptr};
+  hipStream_t side();
   int shard_rank = 0, shard_n = 1;
   bool profiling = false;
   std::map<std::string, hfg::ProfEntry> prof;
@@ -111,6 +116,8 @@ struct GemmTask {
   int M, N, K, lda, ldb, ldc;
   int tA = 0, tB = 0;  // op(A), op(B) transposed (k_dgemm_tasklist only)
   double alpha = 1.0, beta = 0.0;  // C = alpha op(A) op(B) + beta C (k_dgemm_tasklist only)
+  int sym = 0;  // the product is known to be symmetric (M == N, e.g. X^T (F X)): tiles above the diagonal are skipped and
+                // the tiles below it also store their transpose (k_dgemm_tasklist with beta == 0 only)
 };
 
 struct ProfScope {

@@ -216,23 +216,29 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
     if (rho * zz <= tol) {
       for (int j = 0; j < n; j++) sflag[j] = 1;
     } else {
+      // One lane walks the sorted list (the chain through pj is sequential).  z and D of the running candidate pj stay
+      // in registers, and the rotation test |t c s| <= tol is made on the unnormalised pair, |t c0 s0| <= tol (c0^2 +
+      // s0^2), so that hypot and the two divisions are only paid when a rotation really happens (rare): this loop is
+      // the critical path of the upper merge levels.
       int pj = -1;
+      double zp = 0.0, dp = 0.0;
       for (int j = 0; j < n; j++) {
-        sflag[j] = 0;
-        if (rho * fabs(sz[j]) <= tol) {
+        const double zj = sz[j], dj = sD[j];
+        if (rho * fabs(zj) <= tol) {
           sflag[j] = 1;
           continue;
         }
+        sflag[j] = 0;
         if (pj < 0) {
           pj = j;
+          zp = zj;
+          dp = dj;
           continue;
         }
-        double s = sz[pj], c = sz[j];
-        double tau = hypot(c, s);
-        double t = sD[j] - sD[pj];
-        c /= tau;
-        s = -s / tau;
-        if (fabs(t * c * s) <= tol) {
+        const double t = dj - dp;
+        if (fabs(t * zj * zp) <= tol * (zj * zj + zp * zp)) {
+          const double tau = hypot(zj, zp);
+          const double c = zj / tau, s = -zp / tau;
           sz[j] = tau;
           sz[pj] = 0.0;
           ri[nr] = pj;
@@ -240,14 +246,19 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
           rc[nr] = c;
           rsn[nr] = s;
           nr++;
-          double tt = sD[pj] * c * c + sD[j] * s * s;
-          sD[j] = sD[pj] * s * s + sD[j] * c * c;
+          const double tt = dp * c * c + dj * s * s;
+          const double dn = dp * s * s + dj * c * c;
+          sD[j] = dn;
           sD[pj] = tt;
           sflag[pj] = 1;
           pj = j;
+          zp = tau;
+          dp = dn;
         } else {
           ndl[k++] = pj;
           pj = j;
+          zp = zj;
+          dp = dj;
         }
       }
       if (pj >= 0) ndl[k++] = pj;
@@ -471,10 +482,13 @@ __global__ void k_dc_gather(DCBatch b, const DCNode *__restrict__ nodes, int nod
 // ---- step 8: final order of the node's eigenvalues --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dc_rank(DCBatch b, const DCNode *__restrict__ nodes, int node0,
                                                  const int *__restrict__ kcount) {
+  // grid (node, slice): every workgroup stages the node's n values in LDS, then ranks its own slice of 256 of them
+  // (one workgroup per node left the top merges, n ~ 1400, with three busy CUs for 250 us)
   extern __shared__ double sh[];  // values[n]
   const int ni = node0 + blockIdx.x;
   const DCNode nd = nodes[ni];
   const int blk = nd.blk, lo = nd.lo, n = nd.hi - nd.lo;
+  if ((int)blockIdx.y * 256 >= n) return;
   const int k = kcount[ni];
   // value of sorted slot s: the new root if s is non-deflated (position c in the nd list), else the deflated Ds[s]
   const int *ndl = b.nd[blk] + lo;
@@ -494,19 +508,27 @@ __global__ __launch_bounds__(256) void k_dc_rank(DCBatch b, const DCNode *__rest
     sh[s] = v;
   }
   __syncthreads();
-  for (int s = threadIdx.x; s < n; s += blockDim.x) {
-    double v = sh[s];
+  const int s = blockIdx.y * 256 + threadIdx.x;
+  if (s < n) {
+    const double v = sh[s];
     int rk = 0;
-    for (int j = 0; j < n; j++) {
-      double u = sh[j];
-      rk += (u < v) || (u == v && j < s);
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const double x = sh[j + u];
+        rk += (x < v) || (x == v && j + u < s);
+      }
+    }
+    for (; j < n; j++) {
+      const double x = sh[j];
+      rk += (x < v) || (x == v && j < s);
     }
     b.rank[blk][lo + s] = rk;
     b.d2[blk][lo + rk] = v;
   }
 }
 
-// ---- step 9: the node's eigenvectors in final order, written to Qg (free after the GEMM) --------------------
 __global__ void k_dc_scatter(DCBatch b, const DCNode *__restrict__ nodes, int node0, const int *__restrict__ kcount) {
   const int ni = node0 + blockIdx.z;
   const DCNode nd = nodes[ni];
@@ -761,7 +783,7 @@ void tridiag_dc_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, d
     size_t shr = (size_t)mx * sizeof(double);
     if (shr > 64 * 1024)
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_dc_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shr));
-    hipLaunchKernelGGL(k_dc_rank, dim3(nn), dim3(256), shr, s, b, w.nodes.p, node0, w.kcount.p);
+    hipLaunchKernelGGL(k_dc_rank, dim3(nn, (mx + 255) / 256), dim3(256), shr, s, b, w.nodes.p, node0, w.kcount.p);
     hipLaunchKernelGGL(k_dc_scatter, dim3((mx + 255) / 256, mx, nn), dim3(256), 0, s, b, w.nodes.p, node0, w.kcount.p);
     hipLaunchKernelGGL(k_dc_copyback, dim3((mx + 255) / 256, mx, nn), dim3(256), 0, s, b, w.nodes.p, node0);
   }

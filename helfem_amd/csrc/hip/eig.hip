@@ -24,6 +24,7 @@ namespace hfg {
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
+void gemm_mirror_lower_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxN);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 
@@ -482,22 +483,30 @@ __global__ void k_bt_wsum(EigBatch b, double *const *__restrict__ Wpart, double 
 
 // T_p from the Gram matrix G_p = V_p^T V_p and tau (one workgroup per block p of one matrix):
 //   T(i,i) = tau_i,   T(0:i, i) = -tau_i T(0:i,0:i) G(0:i, i)
-__global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restrict__ G, double *const *__restrict__ T) {
+constexpr int BT_GS = 4;  // split-K slabs of the Gram products (K = rows of the reflector block, one 64 x 64 tile each)
+__global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restrict__ G, double *const *__restrict__ T,
+                                             int P) {
   __shared__ double sT[BT_KB][BT_KB + 1];
+  __shared__ double sG[BT_KB][BT_KB + 1];
   __shared__ double sg[BT_KB];
   const int blk = blockIdx.y, p = blockIdx.x;
   const int n = b.n[blk];
   const int j0 = p * BT_KB;
   if (j0 > n - 3) return;
   const int kb = min(BT_KB, n - 2 - j0);
-  const double *Gp = G[blk] + (size_t)p * BT_KB * BT_KB;
   double *Tp = T[blk] + (size_t)p * BT_KB * BT_KB;
   const int t = threadIdx.x;
-  for (int c = 0; c < BT_KB; c++) sT[t][c] = 0.0;
+  // Gram matrix = sum of the BT_GS partial products (fixed order), staged in LDS
+  for (int c = 0; c < BT_KB; c++) {
+    double g = 0.0;
+    for (int sl = 0; sl < BT_GS; sl++) g += G[blk][((size_t)sl * P + p) * BT_KB * BT_KB + (size_t)c * BT_KB + t];
+    sG[c][t] = g;  // column c of G
+    sT[t][c] = 0.0;
+  }
   __syncthreads();
   for (int i = 0; i < kb; i++) {
     const double ti = b.tau[blk][j0 + i];
-    sg[t] = (t < i) ? Gp[(size_t)i * BT_KB + t] : 0.0;
+    sg[t] = (t < i) ? sG[i][t] : 0.0;
     __syncthreads();
     if (t < i) {
       double acc = 0.0;
@@ -514,7 +523,7 @@ struct EigWork {
   DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
-  DevBuf<GemmTask> gtasks, bttasks, btslab;
+  DevBuf<GemmTask> gtasks, bttasks, btslab, btgram;
   DevBuf<double> Vx[MAXB], G[MAXB], T[MAXB], VT[MAXB], Wb[MAXB], Wp[MAXB];
   DevBuf<double *> btptr;
   bool used_dc = true;
@@ -537,7 +546,11 @@ void eig_release(hfg_ctx *ctx) {
 
 /// Eigen-decomposition of nblk symmetric matrices already in w.A[blk] (n x n); eigenvalues end up in
 /// w.d[blk] (unsorted), eigenvectors in w.Z[blk].
-static void backtransform_wy(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, const int *ns, int nmax) {
+// (1) buffers and task lists (host work + one stream synchronisation: done before the tridiagonalisation is queued),
+// (2) the part that needs only the reflectors -- explicit V, Gram matrices, T, V T -- queued on the context's side
+//     stream so that it runs beside the divide-and-conquer stage (which keeps few CUs busy),
+// (3) the sweep over the reflector blocks on the main stream.
+static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, const int *ns, int nmax) {
   hipStream_t s = ctx->stream;
   const int P = (nmax - 3) / BT_KB + 1;  // reflector blocks of the largest matrix
   constexpr int BT_S = 6;                // split-K slabs of the skinny product W = V^T Z (few tiles, long K otherwise)
@@ -545,7 +558,7 @@ static void backtransform_wy(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nb
   for (int k = 0; k < nblk; k++) {
     const int n = ns[k];
     w.Vx[k].resize((size_t)n * n);
-    w.G[k].resize((size_t)P * BT_KB * BT_KB);
+    w.G[k].resize((size_t)BT_GS * P * BT_KB * BT_KB);
     w.T[k].resize((size_t)P * BT_KB * BT_KB);
     w.VT[k].resize((size_t)n * P * BT_KB);
     w.Wb[k].resize((size_t)BT_KB * n);
@@ -638,15 +651,73 @@ static void backtransform_wy(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nb
     for (int sl = 0; sl < BT_S; sl++)
       for (int k = 0; k < nblk; k++) slab[((size_t)p * BT_S + sl) * nblk + k] = t[(((size_t)3 + sl) * P + p) * nblk + k];
   w.btslab.upload(slab, s);
-  HFG_HIP_CHECK(hipStreamSynchronize(s));  // ptrs, t and slab live on this stack frame
+  // Gram products split over BT_GS row slabs (one 64 x 64 tile with K ~ n per reflector block kept 66 workgroups busy
+  // for 170 us); k_bt_T adds the partial matrices
+  std::vector<GemmTask> gram((size_t)BT_GS * P * nblk);
+  for (int sl = 0; sl < BT_GS; sl++)
+    for (int p = 0; p < P; p++)
+      for (int k = 0; k < nblk; k++) {
+        GemmTask g = t[(size_t)p * nblk + k];
+        if (g.M > 0) {
+          const int n = ns[k], mr = g.K;
+          const int chunk = ((mr + BT_GS - 1) / BT_GS + 15) / 16 * 16;
+          const int k0 = sl * chunk, kk = std::max(0, std::min(chunk, mr - k0));
+          g.C = w.G[k].p + ((size_t)sl * P + p) * BT_KB * BT_KB;
+          if (kk > 0) {
+            g.A += k0;
+            g.B += k0;
+          }
+          g.K = kk;  // K = 0 writes zeros
+          (void)n;
+        }
+        gram[((size_t)sl * P + p) * nblk + k] = g;
+      }
+  w.btgram.upload(gram, s);
+  HFG_HIP_CHECK(hipStreamSynchronize(s));  // ptrs, t, slab and gram live on this stack frame
+}
+
+static bool bt_use_side() {
+  static const bool v = (getenv("HELFEM_BT_SIDE") && atoi(getenv("HELFEM_BT_SIDE")) == 1);
+  return v;
+}
+
+static void bt_wy_prepare(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, int nmax) {
+  const int P = (nmax - 3) / BT_KB + 1;
+  // HELFEM_BT_SIDE=1 queues this part on a second stream beside the divide-and-conquer stage.  Measured: the 0.25 ms it
+  // hides are outweighed by what a second live stream costs every launch on the framework's null stream (the
+  // tridiagonalisation alone went from 17.4 to 19.1 ms), so the default keeps everything on the context's stream.
+  const bool use_side = bt_use_side();
+  hipStream_t main = ctx->stream, q = main;
+  const bool prof = ctx->profiling;
+  if (use_side) {
+    q = ctx->side();
+    HFG_HIP_CHECK(hipEventRecord(ctx->side_ev[0], main));  // reflectors and tau are complete
+    HFG_HIP_CHECK(hipStreamWaitEvent(q, ctx->side_ev[0], 0));
+    ctx->profiling = false;  // the profiling brackets are events of the main stream
+    ctx->stream = q;
+  }
+  try {
+    double *const *dptr = w.btptr.p;
+    hipLaunchKernelGGL(k_bt_extract, dim3((nmax + 255) / 256, nmax, nblk), dim3(256), 0, q, b, dptr);
+    gemm_tasklist64_dev(ctx, w.btgram.p, BT_GS * P * nblk, BT_KB, BT_KB);
+    hipLaunchKernelGGL(k_bt_T, dim3(P, nblk), dim3(BT_KB), 0, q, b, dptr + nblk, dptr + 2 * nblk, P);
+    gemm_tasklist64_dev(ctx, w.bttasks.p + (size_t)P * nblk, P * nblk, nmax, BT_KB);
+  } catch (...) {
+    ctx->stream = main;
+    ctx->profiling = prof;
+    throw;
+  }
+  ctx->stream = main;
+  ctx->profiling = prof;
+  if (use_side) HFG_HIP_CHECK(hipEventRecord(ctx->side_ev[1], q));
+}
+
+static void bt_wy_apply(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, int nmax) {
+  hipStream_t s = ctx->stream;
+  const int P = (nmax - 3) / BT_KB + 1;
+  constexpr int BT_S = 6;
   double *const *dptr = w.btptr.p;
-  hipLaunchKernelGGL(k_bt_extract, dim3((nmax + 255) / 256, nmax, nblk), dim3(256), 0, s, b, dptr);
-  gemm_tasklist64_dev(ctx, w.bttasks.p, P * nblk, BT_KB, BT_KB);
-  hipLaunchKernelGGL(k_bt_T, dim3(P, nblk), dim3(BT_KB), 0, s, b, dptr + nblk, dptr + 2 * nblk);
-  gemm_tasklist64_dev(ctx, w.bttasks.p + (size_t)P * nblk, P * nblk, nmax, BT_KB);
-  // the slabs of one reflector block are P*nblk tasks apart: launch them as BT_S lists in one go per block p by
-  // laying the lists out [slab][p][blk] and launching slab by slab would cost BT_S launches; instead the slab lists
-  // of block p are gathered contiguously below
+  if (bt_use_side()) HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));
   for (int p = P - 1; p >= 0; p--) {
     gemm_tasklist64_dev(ctx, w.btslab.p + (size_t)p * BT_S * nblk, BT_S * nblk, BT_KB, nmax);
     hipLaunchKernelGGL(k_bt_wsum, dim3(64, nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk, BT_S);
@@ -687,6 +758,9 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
     b.sweeps[i] = w.sweeps[i].p;
   }
   hipStream_t s = ctx->stream;
+  static const bool bt_column = (getenv("HELFEM_BT") && !strcmp(getenv("HELFEM_BT"), "column"));
+  const bool bt_wy = !bt_column && nmax >= 4 * BT_KB;
+  if (bt_wy) bt_wy_setup(ctx, w, b, nblk, ns, nmax);
   {
     ProfScope ps(ctx, "eig_tridiag");
     static const bool unblocked = (getenv("HELFEM_TRD") && !strcmp(getenv("HELFEM_TRD"), "unblocked"));
@@ -713,6 +787,7 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
       tridiagonalize_batch(ctx, nblk, ns, Ap, dp, ep, tp);
     }
   }
+  if (bt_wy) bt_wy_prepare(ctx, w, b, nblk, nmax);
   {
     ProfScope ps(ctx, "eig_tridiag_solve");
     static const bool use_ql = (getenv("HELFEM_TRIDIAG") && !strcmp(getenv("HELFEM_TRIDIAG"), "ql"));
@@ -734,9 +809,8 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
   }
   {
     ProfScope ps(ctx, "eig_backtransform");
-    static const bool bt_column = (getenv("HELFEM_BT") && !strcmp(getenv("HELFEM_BT"), "column"));
-    if (!bt_column && nmax >= 4 * BT_KB) {
-      backtransform_wy(ctx, w, b, nblk, ns, nmax);
+    if (bt_wy) {
+      bt_wy_apply(ctx, w, b, nblk, nmax);
     } else {
     dim3 grid((nmax + 3) / 4, nblk);
     if (nmax <= 64 * 8)
@@ -896,7 +970,9 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
       g.tA = 1;
       g.B = Tk;
       g.C = w.A[k].p;
+      g.sym = 1;  // X^T (F X): the lower tiles are computed, the upper ones mirrored
       gt[nb + k] = g;
+      g.sym = 0;
       g.tA = 0;
       g.A = Xb;
       g.B = w.Z[k].p;
@@ -914,7 +990,8 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
                            dcols + coff[ib], n, Fb.p + (size_t)k * nmax * nmax, Xall.p + (size_t)k * nmax * nmax);
       }
       gemm_tasklist_dev(ctx, w.gtasks.p, nb, nm, nm);
-      gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);
+      gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);      // lower tiles of X^T (F X) only (GemmTask::sym)
+      gemm_mirror_lower_dev(ctx, w.gtasks.p + nb, nb, nm);        // the tridiagonalisation sweeps the full square
     }
     eig_sym_batch(ctx, w, nb, ns.data());
     {

@@ -33,7 +33,7 @@ template <int BM, int BN, bool ACC = false>
 __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
                                            const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
                                            double beta, double *__restrict__ C, int ldc, double (*As)[BM + 16],
-                                           double (*Bs)[BN + 16]) {
+                                           double (*Bs)[BN + 16], int sym = 0) {
   constexpr int BK = 16;
   constexpr int PAD = 16;
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
@@ -44,12 +44,24 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
   // contiguous strip of tiles (they share A row panels / B column panels in that XCD's L2)
   int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
-  int nwg = nbm * nbn;
+  int nwg = sym ? nbm * (nbm + 1) / 2 : nbm * nbn;
   {
     int q = nwg / 8, r = nwg % 8, xcd = id % 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
   }
-  const int bm = (id % nbm) * BM, bn = (id / nbm) * BN;
+  int bm = (id % nbm) * BM, bn = (id / nbm) * BN;
+  if (sym) {
+    // symmetric product (BM == BN, M == N): the grid enumerates the tiles on and below the diagonal only (id counts
+    // them row by row: id = i (i + 1) / 2 + j, j <= i); k_mirror_lower fills the upper triangle afterwards.  Skipping
+    // the upper tiles of a full grid instead leaves their CU slots empty while other CUs still hold two tiles.
+    int ti = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > id) ti--;
+    while ((ti + 1) * (ti + 2) / 2 <= id) ti++;
+    const int tj = id - ti * (ti + 1) / 2;
+    if (ti >= nbm) return;
+    bm = ti * BM;
+    bn = tj * BN;
+  }
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = (wave & 1) * WM, wn = (wave >> 1) * WN;
@@ -231,10 +243,12 @@ __global__ __launch_bounds__(256) void k_dgemm_tasklist(const GemmTask *__restri
   __shared__ double Bs[16][BN + 16];
   const GemmTask t = tasks[blockIdx.y];
   if (t.M <= 0 || t.N <= 0) return;
-  const int nt = ((t.M + BM - 1) / BM) * ((t.N + BN - 1) / BN);
+  const int sym = (!ACC && BM == BN && t.M == t.N && t.beta == 0.0) ? t.sym : 0;
+  const int nbm = (t.M + BM - 1) / BM;
+  const int nt = sym ? nbm * (nbm + 1) / 2 : nbm * ((t.N + BN - 1) / BN);
   if ((int)blockIdx.x >= nt) return;
   dgemm_tile<BM, BN, ACC>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As,
-                          Bs);
+                          Bs, sym);
 }
 
 /// task lists whose products accumulate into C (beta != 0 in every active task): streaming epilogue
@@ -248,6 +262,40 @@ void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int
     const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
     hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   }
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+// upper triangle := transpose of the lower one for the symmetric products of a task list (sym tasks only): 64 x 64
+// blocks through LDS, coalesced on both sides
+__global__ __launch_bounds__(256) void k_mirror_lower(const GemmTask *__restrict__ tasks) {
+  __shared__ double tile[64][65];
+  const GemmTask t = tasks[blockIdx.y];
+  if (!t.sym || t.M <= 0 || t.M != t.N) return;
+  const int nb = (t.M + 63) / 64;
+  // strictly-lower block (bi > bj) number blockIdx.x
+  int bi = (int)((1.0 + sqrt(1.0 + 8.0 * (double)blockIdx.x)) * 0.5);
+  while (bi * (bi - 1) / 2 > (int)blockIdx.x) bi--;
+  while ((bi + 1) * bi / 2 <= (int)blockIdx.x) bi++;
+  const int bj = blockIdx.x - bi * (bi - 1) / 2;
+  if (bi >= nb) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) {
+    int gm = bi * 64 + tx, gn = bj * 64 + c;
+    tile[c][tx] = (gm < t.M && gn < t.N) ? t.C[(size_t)gn * t.ldc + gm] : 0.0;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    // C(bj*64 + tx, bi*64 + c) = C(bi*64 + c, bj*64 + tx)
+    int gm = bj * 64 + tx, gn = bi * 64 + c;
+    if (gm < t.M && gn < t.N) t.C[(size_t)gn * t.ldc + gm] = tile[tx][c];
+  }
+}
+
+/// after a task list with symmetric products (GemmTask::sym): fill the skipped upper triangles
+void gemm_mirror_lower_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxN) {
+  if (ntasks <= 0 || maxN <= 64) return;
+  const int nb = (maxN + 63) / 64;
+  hipLaunchKernelGGL(k_mirror_lower, dim3(nb * (nb - 1) / 2, ntasks), dim3(256), 0, ctx->stream, dtasks);
   HFG_HIP_CHECK(hipGetLastError());
 }
 

@@ -397,10 +397,15 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define HFG_G(p) ((gdouble *)(p))
 #define HFG_GC(p) ((const gdouble *)(p))
 
-constexpr int TF_NTH = 1024;            // threads per workgroup
-constexpr int TF_NG = TF_NTH / 256;     // thread groups sharing a row's panel corrections
-constexpr int TF_NW = TF_NTH / 64;      // waves
+// TF_NTH threads per workgroup.  1024 (one workgroup per CU) is the production shape.  The 512-thread instantiation
+// (two per CU, HELFEM_TRDF_NTH=512) exists for A/B runs: measured slower everywhere (18.0 vs 17.4 ms per
+// factorisation at 3 x n ~ 1400), also for the early columns whose 3 x 121 tiles need two rounds of 1024-thread
+// workgroups (16-18 us per column against 8-9 us once a launch fits the 256 CUs): those columns are bound by what a
+// CU can issue, not by occupancy.
+template <int TF_NTH>
 __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp, int i, int c, int sweep) {
+  constexpr int TF_NG = TF_NTH / 256;  // thread groups sharing a row's panel corrections
+  constexpr int TF_NW = TF_NTH / 64;   // waves
   // 512 threads: the panel corrections of a row are split over two thread groups (cc = grp, grp+2, ...), the 128
   // columns of the tile over eight waves.  Load order matters more than thread count here: a workgroup pulls its
   // 128 KB tile through one CU in 2-3 us, so the small phase-A loads are issued first and the tile streams in
@@ -933,7 +938,10 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
         const int sweep = (i < jend) ? 1 : 0;  // the last launch of the panel only finishes column jend-1
         const int m = nmax - i - 1;
         const int nrt = (m + 1 + TF_T - 1) / TF_T, ncs = std::max(1, (m + TF_T - 1) / TF_T);
-        hipLaunchKernelGGL(k_trdf, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(TF_NTH), 0, s, db, i, i - j0, sweep);
+        static const int force_nth = getenv("HELFEM_TRDF_NTH") ? atoi(getenv("HELFEM_TRDF_NTH")) : 0;  // A/B runs
+        const bool small_wg = (force_nth == 512);
+        if (small_wg) hipLaunchKernelGGL(k_trdf<512>, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(512), 0, s, db, i, i - j0, sweep);
+        else hipLaunchKernelGGL(k_trdf<1024>, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(1024), 0, s, db, i, i - j0, sweep);
       }
     } else {
     {
@@ -1005,7 +1013,10 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
       const int nrt = (m + 1 + TF_T - 1) / TF_T, ncs = std::max(1, (m + TF_T - 1) / TF_T);
       const int cfix = getenv("HELFEM_TRDF_C") ? atoi(getenv("HELFEM_TRDF_C")) : c;
       const int dbg = getenv("HELFEM_TRDF_DBG") ? atoi(getenv("HELFEM_TRDF_DBG")) : 0;
-      hipLaunchKernelGGL(k_trdf, dim3(nrt * ncs, nblk), dim3(TF_NTH), 0, s, db, i, cfix, 1 | (dbg << 1));
+      static const int force_nth = getenv("HELFEM_TRDF_NTH") ? atoi(getenv("HELFEM_TRDF_NTH")) : 0;
+      const bool small_wg = (force_nth == 512);
+      if (small_wg) hipLaunchKernelGGL(k_trdf<512>, dim3(nrt * ncs, nblk), dim3(512), 0, s, db, i, cfix, 1 | (dbg << 1));
+      else hipLaunchKernelGGL(k_trdf<1024>, dim3(nrt * ncs, nblk), dim3(1024), 0, s, db, i, cfix, 1 | (dbg << 1));
     } else {
       const int nrg = (m + 1 + 127) / 128;
       int ncs = std::max(1, std::min(64, (m + 63) / 64));
