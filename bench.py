@@ -183,7 +183,9 @@ def main():
         try:
             if args.workload == "n2_pbe_nbf4230" and world == 1:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    traffic = json.load(fh).get("hfg::" + TRD_KERNEL, {}).get("traffic_bytes_per_launch")
+                    for kname, rec in json.load(fh).items():  # "void hfg::k_trdf<1024>" (template) or "hfg::k_trdb_gemv"
+                        if ("hfg::" + TRD_KERNEL) in kname:
+                            traffic = rec.get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
         out = {
