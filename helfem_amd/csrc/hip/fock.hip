@@ -573,9 +573,12 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
                               const double *__restrict__ rad_sh, const double *__restrict__ th_s,
                               const double *__restrict__ th_w, const int *__restrict__ grp_m,
                               const double *__restrict__ cosd, const double *__restrict__ sind, int Dmax, int G, int nth,
-                              int nphi, double Rh, int geom, int x_func, int c_func, int do_grad, double thr, size_t NQ,
-                              int rank, int nranks, double *__restrict__ Fo, double *__restrict__ partial /* [2][NQ] */) {
-  extern __shared__ double sh[];  // pot[8][nth*nphi], red[2*nwave]
+                              int nphi, double Rh, int geom, int x_func, int c_func, int do_grad, int do_tau, double thr,
+                              size_t NQ, int rank, int nranks, double *__restrict__ Fo,
+                              double *__restrict__ partial /* [3][NQ] */) {
+  // meta-GGA (do_tau): V and Fo carry five planes per spin (the tau planes 3, 4 as in k_xc_grid), LDS one more potential
+  // plane per spin
+  extern __shared__ double sh[];  // pot[npot][nth*nphi] (npot = 8, or 10 with tau), red[3*nwave]
   size_t Q = blockIdx.x;
   if ((int)(Q % nranks) != rank) {
     if (threadIdx.x == 0) {
@@ -586,11 +589,13 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
     return;
   }
   int ng = nth * nphi;
-  double *red = sh + 8 * ng;
+  const int npl = do_tau ? 5 : 3;    // planes per spin in V and Fo
+  const int npot = do_tau ? 5 : 4;   // potential planes per spin in LDS
+  double *red = sh + 2 * npot * ng;
   double shm = rad_sh[Q], wr = rad_w[Q];
   double dphi = 2.0 * HFG_PI / nphi;
   size_t stride = NQ * G * G * nth;
-  double nel = 0.0, exc_sum = 0.0;
+  double nel = 0.0, exc_sum = 0.0, kin_sum = 0.0;
   for (int pt = threadIdx.x; pt < ng; pt += blockDim.x) {
     int i = pt / nphi, j = pt % nphi;
     double sth = th_s[i];
@@ -606,7 +611,7 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
       hphi = shm * sth;
       w = th_w[i] * dphi * wr * shm * shm;
     }
-    double rho[2] = {0.0, 0.0}, gmu[2] = {0.0, 0.0}, gnu[2] = {0.0, 0.0}, gphi[2] = {0.0, 0.0};
+    double rho[2] = {0.0, 0.0}, gmu[2] = {0.0, 0.0}, gnu[2] = {0.0, 0.0}, gphi[2] = {0.0, 0.0}, tau[2] = {0.0, 0.0};
     for (int ga = 0; ga < G; ga++)
       for (int gb = 0; gb < G; gb++) {
         int D = grp_m[ga] - grp_m[gb];
@@ -614,9 +619,12 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
         double sd = sind[(size_t)(D + Dmax) * nphi + j];
         size_t o = ((Q * G + ga) * G + gb) * nth + i;
         for (int sp = 0; sp < 2; sp++) {
-          const double *Vs = V + (size_t)sp * 3 * stride;
+          const double *Vs = V + (size_t)sp * npl * stride;
           double vr = Vs[o];
           rho[sp] += cd * vr;
+          if (do_tau)  // dftgrid.cpp:159-200: tau of each spin density
+            tau[sp] += 0.5 * cd * (Vs[3 * stride + o] / (hmu * hmu) + Vs[4 * stride + o] / (hnu * hnu) +
+                                   (double)(grp_m[ga] * grp_m[gb]) * vr / (hphi * hphi));
           if (do_grad) {
             gnu[sp] += cd * Vs[stride + o];
             gmu[sp] += cd * Vs[2 * stride + o];
@@ -635,46 +643,58 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
       sab = gmu[0] * gmu[1] + gnu[0] * gnu[1] + gphi[0] * gphi[1];
       sbb = gmu[1] * gmu[1] + gnu[1] * gnu[1] + gphi[1] * gphi[1];
     }
-    double exc = 0.0, va = 0.0, vb = 0.0, vsaa = 0.0, vsab = 0.0, vsbb = 0.0;
+    double exc = 0.0, va = 0.0, vb = 0.0, vsaa = 0.0, vsab = 0.0, vsbb = 0.0, vta = 0.0, vtb = 0.0;
     const double rt = rho[0] + rho[1];
     if (rt >= thr && rt > 0.0) {
       double ra = fmax(rho[0], thr), rb = fmax(rho[1], thr);
-      if (x_func > 0) xc::eval_add_pol(x_func, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
-      if (c_func > 0) xc::eval_add_pol(c_func, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+      for (int f = 0; f < 2; f++) {
+        const int id = f ? c_func : x_func;
+        if (id <= 0) continue;
+        if (xc::is_mgga(id)) xc::eval_add_mgga_pol(id, ra, rb, saa, sab, sbb, tau[0], tau[1], rho[0] >= thr, rho[1] >= thr, exc, va, vb, vsaa, vsab, vsbb, vta, vtb);
+        else xc::eval_add_pol(id, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+      }
     }
     nel += w * rt;
     exc_sum += w * exc * rt;
+    kin_sum += w * (tau[0] + tau[1]);
     sh[0 * ng + pt] = w * va;
-    sh[4 * ng + pt] = w * vb;
+    sh[npot * ng + pt] = w * vb;
+    if (do_tau) {
+      sh[4 * ng + pt] = 0.5 * w * vta;
+      sh[(npot + 4) * ng + pt] = 0.5 * w * vtb;
+    }
     if (do_grad) {
       // gr_a = w (2 vs_aa grad rho_a + vs_ab grad rho_b) / h ; gr_b likewise   (dftgrid.cpp:583-601)
       sh[1 * ng + pt] = w * (2.0 * vsaa * gmu[0] + vsab * gmu[1]) / hmu;
       sh[2 * ng + pt] = w * (2.0 * vsaa * gnu[0] + vsab * gnu[1]) / hnu;
       sh[3 * ng + pt] = w * (2.0 * vsaa * gphi[0] + vsab * gphi[1]) / hphi;
-      sh[5 * ng + pt] = w * (2.0 * vsbb * gmu[1] + vsab * gmu[0]) / hmu;
-      sh[6 * ng + pt] = w * (2.0 * vsbb * gnu[1] + vsab * gnu[0]) / hnu;
-      sh[7 * ng + pt] = w * (2.0 * vsbb * gphi[1] + vsab * gphi[0]) / hphi;
+      sh[(npot + 1) * ng + pt] = w * (2.0 * vsbb * gmu[1] + vsab * gmu[0]) / hmu;
+      sh[(npot + 2) * ng + pt] = w * (2.0 * vsbb * gnu[1] + vsab * gnu[0]) / hnu;
+      sh[(npot + 3) * ng + pt] = w * (2.0 * vsbb * gphi[1] + vsab * gphi[0]) / hphi;
     }
   }
   int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
   for (int o = 32; o > 0; o >>= 1) {
     nel += __shfl_down(nel, o, 64);
     exc_sum += __shfl_down(exc_sum, o, 64);
+    kin_sum += __shfl_down(kin_sum, o, 64);
   }
   if (lane == 0) {
     red[wave] = nel;
     red[nwave + wave] = exc_sum;
+    red[2 * nwave + wave] = kin_sum;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, c2 = 0.0;
     for (int w = 0; w < nwave; w++) {
       a += red[w];
       b += red[nwave + w];
+      c2 += red[2 * nwave + w];
     }
     partial[Q] = a;
     partial[NQ + Q] = b;
-    partial[2 * NQ + Q] = 0.0;
+    partial[2 * NQ + Q] = c2;
   }
   int nout = G * G * nth;
   for (int t = threadIdx.x; t < 2 * nout; t += blockDim.x) {
@@ -685,8 +705,8 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
     int D = grp_m[ga] - grp_m[gb];
     const double *cd = cosd + (size_t)(D + Dmax) * nphi;
     const double *sd = sind + (size_t)(D + Dmax) * nphi;
-    const double *p0 = sh + (size_t)(4 * sp) * ng, *p1 = p0 + ng, *p2 = p0 + 2 * ng, *p3 = p0 + 3 * ng;
-    double fa = 0.0, fs = 0.0, fb = 0.0;
+    const double *p0 = sh + (size_t)(npot * sp) * ng, *p1 = p0 + ng, *p2 = p0 + 2 * ng, *p3 = p0 + 3 * ng, *p4 = p0 + 4 * ng;
+    double fa = 0.0, fs = 0.0, fb = 0.0, ft = 0.0;
     double mga = grp_m[ga];
     for (int j = 0; j < nphi; j++) {
       int pt = i * nphi + j;
@@ -696,9 +716,24 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
         fs += p2[pt] * cd[j];
         fb += p1[pt] * cd[j];
       }
+      if (do_tau) ft += p4[pt] * cd[j];
     }
     size_t o = ((Q * G + ga) * G + gb) * nth + i;
-    double *Fs = Fo + (size_t)sp * 3 * stride;
+    double *Fs = Fo + (size_t)sp * npl * stride;
+    if (do_tau) {  // the three tau terms of eval_Fxc, as in k_xc_grid
+      double sth = th_s[i], hmu, hnu, hphi;
+      if (geom == 0) {
+        hmu = hnu = Rh * sqrt(shm * shm + sth * sth);
+        hphi = Rh * shm * sth;
+      } else {
+        hmu = 1.0;
+        hnu = shm;
+        hphi = shm * sth;
+      }
+      fa += 0.5 * mga * (double)grp_m[gb] * ft / (hphi * hphi);
+      Fs[3 * stride + o] = 0.5 * ft / (hmu * hmu);
+      Fs[4 * stride + o] = 0.5 * ft / (hnu * hnu);
+    }
     Fs[o] = fa;
     if (do_grad) {
       Fs[stride + o] = fs;
@@ -988,44 +1023,48 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
   if (!t->have_xc) throw std::runtime_error("XC grid tables were not uploaded (hfg_basis_upload with ldft,mdft > 0)\n");
   if ((x_func > 0 && !xc::is_supported(x_func)) || (c_func > 0 && !xc::is_supported(c_func)))
     throw std::runtime_error("Functional not found!");
-  if ((x_func > 0 && xc::is_mgga(x_func)) || (c_func > 0 && xc::is_mgga(c_func)))
-    throw std::runtime_error("meta-GGAs are implemented for spin-restricted runs only\n");
   FockAux &a = aux_for(ctx, basis);
   const int A = t->A, E = t->E, p = t->p, nq = t->nq, G = t->G, nth = t->ntheta, nphi = t->nphi;
   const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
   int do_grad = ((x_func > 0 && xc::is_gga(x_func)) || (c_func > 0 && xc::is_gga(c_func))) ? 1 : 0;
+  int do_tau = ((x_func > 0 && xc::is_mgga(x_func)) || (c_func > 0 && xc::is_mgga(c_func))) ? 1 : 0;
+  const int npl = do_tau ? 5 : 3;
   a.D0.resize(NQ * AA);
   a.D1.resize(NQ * AA);
   a.GA.resize(NQ * AA);
   a.GB.resize(NQ * AA);
+  if (do_tau) {
+    a.D2.resize(NQ * AA);
+    a.GC.resize(NQ * AA);
+  }
   const size_t nv = NQ * G * G * nth;
-  a.V.resize(6 * nv);
-  a.Fo.resize(6 * nv);
+  a.V.resize(2 * npl * nv);
+  a.Fo.resize(2 * npl * nv);
   a.partial.resize(3 * NQ);
   int maxgrp = 0;
   for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
   for (int sp = 0; sp < 2; sp++) {
     hipLaunchKernelGGL(k_xc_density_radial, dim3(A * A, E), dim3(256), xc_density_radial_lds(p, nq),
-                       ctx->stream, sp ? dPcb : dPca, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, 0, ctx->shard_rank,
-                       ctx->shard_n, a.D0.p, a.D1.p, (double *)nullptr);
+                       ctx->stream, sp ? dPcb : dPca, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau, ctx->shard_rank,
+                       ctx->shard_n, a.D0.p, a.D1.p, a.D2.p);
     hipLaunchKernelGGL(k_xc_density_theta, dim3((unsigned)NQ, G * G), dim3(std::min(256, round_up64(nth))),
-                       3 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, (const double *)nullptr, t->Th.p, t->dTh.p,
-                       A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, 0, NQ, ctx->shard_rank, ctx->shard_n,
-                       a.V.p + (size_t)sp * 3 * nv);
+                       3 * maxgrp * maxgrp * sizeof(double), ctx->stream, a.D0.p, a.D1.p, (const double *)a.D2.p, t->Th.p, t->dTh.p,
+                       A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, NQ, ctx->shard_rank, ctx->shard_n,
+                       a.V.p + (size_t)sp * npl * nv);
   }
-  size_t shb = (size_t)(8 * nth * nphi + 2 * 4) * sizeof(double);
+  size_t shb = (size_t)((do_tau ? 10 : 8) * nth * nphi + 3 * 4) * sizeof(double);
   if (shb > 160 * 1024) throw std::runtime_error("XC angular grid too large for the polarised grid kernel's LDS tile");
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_grid_pol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   hipLaunchKernelGGL(k_xc_grid_pol, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
-                     x_func, c_func, do_grad, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
+                     x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
   for (int sp = 0; sp < 2; sp++) {
     hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 5 * nth * sizeof(double), ctx->stream,
-                       a.Fo.p + (size_t)sp * 3 * nv, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad,
-                       0, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, (double *)nullptr);
+                       a.Fo.p + (size_t)sp * npl * nv, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad,
+                       do_tau, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
     hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 2 * nq * p) * sizeof(double),
-                       ctx->stream, a.GA.p, a.GB.p, (const double *)nullptr, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, 0,
+                       ctx->stream, a.GA.p, a.GB.p, (const double *)a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                        ctx->shard_rank, ctx->shard_n, sp ? dHcb : dHca);
   }
   hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);

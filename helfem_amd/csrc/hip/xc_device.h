@@ -253,7 +253,93 @@ __host__ __device__ inline T3 tpow23(T3 x) {
   return t3f(x, c * c, 2.0 / (3.0 * c));
 }
 
-__host__ __device__ inline T3 pol_fzeta(T3 z) {
+// ---- seven-slot duals: derivatives with respect to (rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb, tau_a, tau_b), for
+// the spin-polarised meta-GGA correlation; the correlation building blocks below are templates over the dual type ----
+struct T7 {
+  double v, d[7];
+};
+__host__ __device__ inline T7 t7(double v) {
+  T7 r;
+  r.v = v;
+#pragma unroll
+  for (int k = 0; k < 7; k++) r.d[k] = 0.0;
+  return r;
+}
+__host__ __device__ inline T7 t7var(double v, int k) {
+  T7 r = t7(v);
+  r.d[k] = 1.0;
+  return r;
+}
+__host__ __device__ inline T7 t7f(T7 x, double f, double df) {
+  T7 r;
+  r.v = f;
+#pragma unroll
+  for (int k = 0; k < 7; k++) r.d[k] = df * x.d[k];
+  return r;
+}
+__host__ __device__ inline T7 operator+(T7 x, T7 y) {
+  T7 r;
+  r.v = x.v + y.v;
+#pragma unroll
+  for (int k = 0; k < 7; k++) r.d[k] = x.d[k] + y.d[k];
+  return r;
+}
+__host__ __device__ inline T7 operator-(T7 x, T7 y) {
+  T7 r;
+  r.v = x.v - y.v;
+#pragma unroll
+  for (int k = 0; k < 7; k++) r.d[k] = x.d[k] - y.d[k];
+  return r;
+}
+__host__ __device__ inline T7 operator-(T7 x) { return t7f(x, -x.v, -1.0); }
+__host__ __device__ inline T7 operator*(T7 x, T7 y) {
+  T7 r;
+  r.v = x.v * y.v;
+#pragma unroll
+  for (int k = 0; k < 7; k++) r.d[k] = x.d[k] * y.v + x.v * y.d[k];
+  return r;
+}
+__host__ __device__ inline T7 operator/(T7 x, T7 y) {
+  const double inv = 1.0 / y.v, q = x.v * inv;
+  T7 r;
+  r.v = q;
+#pragma unroll
+  for (int k = 0; k < 7; k++) r.d[k] = (x.d[k] - q * y.d[k]) * inv;
+  return r;
+}
+__host__ __device__ inline T7 operator+(T7 x, double c) { x.v += c; return x; }
+__host__ __device__ inline T7 operator+(double c, T7 x) { x.v += c; return x; }
+__host__ __device__ inline T7 operator-(T7 x, double c) { x.v -= c; return x; }
+__host__ __device__ inline T7 operator-(double c, T7 x) { return t7f(x, c - x.v, -1.0); }
+__host__ __device__ inline T7 operator*(T7 x, double c) { return t7f(x, x.v * c, c); }
+__host__ __device__ inline T7 operator*(double c, T7 x) { return t7f(x, x.v * c, c); }
+__host__ __device__ inline T7 operator/(T7 x, double c) { return x * (1.0 / c); }
+__host__ __device__ inline T7 operator/(double c, T7 x) { return t7f(x, c / x.v, -c / (x.v * x.v)); }
+__host__ __device__ inline T7 tsqrt(T7 x) {
+  double r = sqrt(x.v);
+  return t7f(x, r, 0.5 / r);
+}
+__host__ __device__ inline T7 tcbrt(T7 x) {
+  double c = cbrt(x.v);
+  return t7f(x, c, c / (3.0 * x.v));
+}
+__host__ __device__ inline T7 tlog(T7 x) { return t7f(x, log(x.v), 1.0 / x.v); }
+__host__ __device__ inline T7 texp(T7 x) {
+  double e = exp(x.v);
+  return t7f(x, e, e);
+}
+__host__ __device__ inline T7 tpow43(T7 x) {
+  double c = cbrt(x.v);
+  return t7f(x, x.v * c, (4.0 / 3.0) * c);
+}
+__host__ __device__ inline T7 tpow23(T7 x) {
+  double c = cbrt(x.v);
+  return t7f(x, c * c, 2.0 / (3.0 * c));
+}
+__host__ __device__ inline T7 tmaxv(T7 x, T7 y) { return (x.v >= y.v) ? x : y; }
+
+template <class T>
+__host__ __device__ inline T pol_fzeta(T z) {
   return (tpow43(1.0 + z) + tpow43(1.0 - z) - 2.0) / (2.0 * 1.2599210498948732 - 2.0);
 }
 __host__ __device__ inline T3 pol_vwn_fit(T3 x, double A, double b, double c, double x0) {
@@ -273,32 +359,35 @@ __host__ __device__ inline T3 pol_eps_vwn(T3 rs, T3 z) {
   T3 z4 = z2 * z2;
   return eP + al * f * (1.0 - z4) / fpp + (eF - eP) * f * z4;
 }
-__host__ __device__ inline T3 pol_pw_G(T3 rs, double A, double a1, double b1, double b2, double b3, double b4) {
-  T3 s = tsqrt(rs);
-  T3 den = (2.0 * A) * (b1 * s + b2 * rs + b3 * rs * s + b4 * rs * rs);
+template <class T>
+__host__ __device__ inline T pol_pw_G(T rs, double A, double a1, double b1, double b2, double b3, double b4) {
+  T s = tsqrt(rs);
+  T den = (2.0 * A) * (b1 * s + b2 * rs + b3 * rs * s + b4 * rs * rs);
   return (-2.0 * A) * (1.0 + a1 * rs) * tlog(1.0 + 1.0 / den);
 }
-__host__ __device__ inline T3 pol_eps_pw(T3 rs, T3 z, bool mod) {
-  T3 e0 = pol_pw_G(rs, mod ? 0.0310907 : 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
-  T3 e1 = pol_pw_G(rs, mod ? 0.01554535 : 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
-  T3 mac = pol_pw_G(rs, mod ? 0.0168869 : 0.016887, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);
+template <class T>
+__host__ __device__ inline T pol_eps_pw(T rs, T z, bool mod) {
+  T e0 = pol_pw_G(rs, mod ? 0.0310907 : 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+  T e1 = pol_pw_G(rs, mod ? 0.01554535 : 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+  T mac = pol_pw_G(rs, mod ? 0.0168869 : 0.016887, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);
   const double fz20 = mod ? 1.709920934161365617563962776245 : 1.709921;
-  T3 f = pol_fzeta(z), z2 = z * z;
-  T3 z4 = z2 * z2;
+  T f = pol_fzeta(z), z2 = z * z;
+  T z4 = z2 * z2;
   return e0 - mac * f * (1.0 - z4) / fz20 + (e1 - e0) * f * z4;
 }
-__host__ __device__ inline T3 pol_eps_pbe_c(T3 n, T3 rs, T3 z, T3 sig) {
+template <class T>
+__host__ __device__ inline T pol_eps_pbe_c(T n, T rs, T z, T sig) {
   const double beta = 0.06672455060314922;
   const double gamma = (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI);
   const double B = beta / gamma;
-  T3 ec = pol_eps_pw(rs, z, true);
-  T3 phi = 0.5 * (tpow23(1.0 + z) + tpow23(1.0 - z));
-  T3 phi3 = phi * phi * phi;
-  T3 kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
-  T3 ks2 = (4.0 / HFG_PI) * kf;
-  T3 t2 = sig / (4.0 * phi * phi * ks2 * n * n);
-  T3 Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
-  T3 At2 = Aa * t2;
+  T ec = pol_eps_pw(rs, z, true);
+  T phi = 0.5 * (tpow23(1.0 + z) + tpow23(1.0 - z));
+  T phi3 = phi * phi * phi;
+  T kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
+  T ks2 = (4.0 / HFG_PI) * kf;
+  T t2 = sig / (4.0 * phi * phi * ks2 * n * n);
+  T Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
+  T At2 = Aa * t2;
   return ec + gamma * phi3 * tlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
 }
 
@@ -393,19 +482,50 @@ __host__ __device__ inline T3 mg_eps_tpss_x(T3 rho, T3 sig, T3 tau) {
   return exu * F;
 }
 
-__host__ __device__ inline T3 mg_eps_pbe_c_fullpol(T3 n, T3 sig) {
+template <class T>
+__host__ __device__ inline T mg_eps_pbe_c_fullpol(T n, T sig) {
   const double beta = 0.06672455060314922;
   const double gamma = (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI);
   const double B = beta / gamma;
-  T3 rs = tcbrt((3.0 / (4.0 * HFG_PI)) / n);
-  T3 ec = pol_pw_G(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+  T rs = tcbrt((3.0 / (4.0 * HFG_PI)) / n);
+  T ec = pol_pw_G(rs, 0.01554535, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
   const double phi = 0.7937005259840998, phi3 = 0.5;  // 2^{-1/3}
-  T3 kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
-  T3 ks2 = (4.0 / HFG_PI) * kf;
-  T3 t2 = sig / ((4.0 * phi * phi) * ks2 * n * n);
-  T3 Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
-  T3 At2 = Aa * t2;
+  T kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
+  T ks2 = (4.0 / HFG_PI) * kf;
+  T t2 = sig / ((4.0 * phi * phi) * ks2 * n * n);
+  T Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
+  T At2 = Aa * t2;
   return ec + (gamma * phi3) * tlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+}
+
+// TPSS correlation for a spin-polarised density (Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 (2003), eqs 11-14):
+//   rev = e_PBE [1 + C(zeta,xi) z^2] - [1 + C(zeta,xi)] z^2 sum_s (n_s/n) max(e_PBE(n_s,0,grad n_s,0), e_PBE)
+//   C(zeta,xi) = C(zeta,0) / {1 + xi^2 [(1+zeta)^{-4/3} + (1-zeta)^{-4/3}]/2}^4,  C(zeta,0) = 0.53 + 0.87 z^2 + 0.50 z^4 + 2.26 z^6
+//   xi = |grad zeta| / (2 (3 pi^2 n)^{1/3}),  z = tau_W/tau,  e_c = rev [1 + d rev z^3]
+__host__ __device__ inline T7 mg_eps_tpss_c_pol(T7 ra, T7 rb, T7 saa, T7 sab, T7 sbb, T7 ta, T7 tb) {
+  const double d = 2.8;
+  T7 n = ra + rb;
+  T7 rs = tcbrt((3.0 / (4.0 * HFG_PI)) / n);
+  T7 zeta = (ra - rb) / n;
+  T7 st = saa + 2.0 * sab + sbb;
+  T7 epbe = pol_eps_pbe_c(n, rs, zeta, st);
+  T7 eta = tmaxv(mg_eps_pbe_c_fullpol(ra, saa), epbe);
+  T7 etb = tmaxv(mg_eps_pbe_c_fullpol(rb, sbb), epbe);
+  T7 tauw = st / (8.0 * n);
+  T7 tt = tmaxv(ta + tb, tauw);
+  T7 z = tauw / tt;
+  T7 z2 = z * z;
+  T7 omz = 1.0 - zeta, opz = 1.0 + zeta;
+  T7 gz2 = (omz * omz * saa - 2.0 * omz * opz * sab + opz * opz * sbb) / (n * n);  // |grad zeta|^2
+  T7 kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
+  T7 xi2 = gz2 / (4.0 * kf * kf);
+  T7 zz = zeta * zeta;
+  T7 C0 = 0.53 + 0.87 * zz + 0.50 * zz * zz + 2.26 * zz * zz * zz;
+  T7 den = 1.0 + 0.5 * xi2 * (1.0 / tpow43(opz) + 1.0 / tpow43(omz));
+  T7 den2 = den * den;
+  T7 Cz = C0 / (den2 * den2);
+  T7 rev = epbe * (1.0 + Cz * z2) - (1.0 + Cz) * z2 * (ra * eta + rb * etb) / n;
+  return rev * (1.0 + d * rev * z2 * z);
 }
 
 __host__ __device__ inline T3 mg_eps_tpss_c(T3 rho, T3 sig, T3 tau) {
@@ -434,6 +554,50 @@ __host__ __device__ inline void eval_add_mgga(int id, double rho, double sigma, 
   vrho += en.a;
   vsigma += en.b;
   vtau += en.s;
+}
+
+/// spin-polarised meta-GGA: adds exc (per particle of ra + rb), v_rho[2], v_sigma[3] (aa, ab, bb), v_tau[2]; ra, rb
+/// already raised to the threshold.  Exchange by spin scaling, E_x[a,b] = (E_x[2a] + E_x[2b])/2.
+/// live_a, live_b: the channel's own density reached the threshold.  A channel below it is left out of the exchange sum
+/// (libxc screens it the same way): its v_tau = d(n e)/d tau would be of order 1/tau_unif(threshold) and enters the Fock
+/// matrix unweighted, unlike v_rho and v_sigma which multiply the channel's density or gradient.
+__host__ __device__ inline void eval_add_mgga_pol(int id, double ra, double rb, double saa, double sab, double sbb, double ta,
+                                                  double tb, bool live_a, bool live_b, double &exc, double &va, double &vb,
+                                                  double &vsaa, double &vsab, double &vsbb, double &vta, double &vtb) {
+  const double rt = ra + rb;
+  if (id == 202) {
+    T3 na = t3(0.0), nb = t3(0.0);
+    if (live_a) {
+      T3 Ra = t3(2.0 * ra, 1.0, 0.0, 0.0), Sa = t3(fmax(4.0 * saa, 1e-40), 0.0, 1.0, 0.0), Ta = t3(fmax(2.0 * ta, 1e-40), 0.0, 0.0, 1.0);
+      na = Ra * mg_eps_tpss_x(Ra, Sa, Ta);
+    }
+    if (live_b) {
+      T3 Rb = t3(2.0 * rb, 1.0, 0.0, 0.0), Sb = t3(fmax(4.0 * sbb, 1e-40), 0.0, 1.0, 0.0), Tb = t3(fmax(2.0 * tb, 1e-40), 0.0, 0.0, 1.0);
+      nb = Rb * mg_eps_tpss_x(Rb, Sb, Tb);
+    }
+    exc += 0.5 * (na.v + nb.v) / rt;
+    va += na.a;  // d/d ra [ n(2 ra, 4 saa, 2 ta)/2 ]
+    vb += nb.a;
+    vsaa += 2.0 * na.b;
+    vsbb += 2.0 * nb.b;
+    vta += na.s;
+    vtb += nb.s;
+    return;
+  }
+  if (id != 231) return;
+  T7 A = t7var(ra, 0), B = t7var(rb, 1);
+  T7 Saa = t7var(fmax(saa, 1e-40), 2), Sab = t7var(sab, 3), Sbb = t7var(fmax(sbb, 1e-40), 4);
+  T7 Ta = t7var(fmax(ta, 1e-40), 5), Tb = t7var(fmax(tb, 1e-40), 6);
+  T7 e = mg_eps_tpss_c_pol(A, B, Saa, Sab, Sbb, Ta, Tb);
+  T7 en = (A + B) * e;
+  exc += e.v;
+  va += en.d[0];
+  vb += en.d[1];
+  vsaa += en.d[2];
+  vsab += en.d[3];
+  vsbb += en.d[4];
+  vta += en.d[5];
+  vtb += en.d[6];
 }
 
 }  // namespace xc

@@ -143,8 +143,9 @@ int hfg_exchange(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *K);
 int hfg_rs_exchange(hfg_ctx *ctx, hfg_basis *basis, const double *P, double *K);
 /* void DFTGrid::eval_Fxc(x_func,x_pars,c_func,c_pars,P,H,Exc,Nel,Ekin,thr)   dftgrid.h:179 (restricted).
  * Functional ids are libxc's: 1 lda_x, 7 lda_c_vwn, 12 lda_c_pw, 101 gga_x_pbe, 130 gga_c_pbe, 406 hyb_gga_xc_pbeh
- * (its 0.25 exact exchange is the caller's K), 202 mgga_x_tpss, 231 mgga_c_tpss (Ekin returns the integral of tau);
- * <=0 none. */
+ * (its 0.25 exact exchange is the caller's K), 202 mgga_x_tpss, 231 mgga_c_tpss (Ekin returns the integral of tau),
+ * 13 lda_c_pw_mod, 546 lda_x_erf, 641 lda_x_yukawa (omega = 0.3, libxc's default), 178 hyb_lda_xc_cam_lda0 (DFT part;
+ * the caller adds 0.5 K - 0.25 K_erfc(omega = 1/3)); <=0 none.  The spin-polarised entry takes the same ids. */
 int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *P, double *H, double *Exc,
                 double *Nel, double *Ekin, double dens_thr);
 /* void DFTGrid::eval_Fxc(x_func,x_pars,c_func,c_pars,Pa,Pb,Ha,Hb,Exc,Nel,Ekin,beta,thr)   dftgrid.h:181,

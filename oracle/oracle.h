@@ -79,6 +79,9 @@ bool xc_is_mgga(int func_id);
 /// meta-GGA (tau-dependent), spin-unpolarised: 202 = mgga_x_tpss, 231 = mgga_c_tpss; vtau = d(rho exc)/d tau
 void xc_unpolarized_mgga(int func_id, size_t N, const double *rho, const double *sigma, const double *tau, double *exc,
                          double *vrho, double *vsigma, double *vtau, double dens_threshold);
+/// spin-polarised meta-GGA: rho[2N] (a,b), sigma[3N] (aa,ab,bb), tau[2N] per point; vtau[2N]
+void xc_polarized_mgga(int func_id, size_t N, const double *rho, const double *sigma, const double *tau, double *exc,
+                       double *vrho, double *vsigma, double *vtau, double dens_threshold);
 void xc_unpolarized(int func_id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
                     double *vsigma, double dens_threshold);
 /// spin-polarised: rho[2N] = (a,b) per point, sigma[3N] = (aa,ab,bb) per point; exc[N] per particle of the total

@@ -314,19 +314,20 @@ void atomic_eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int
   grid.do_tau = (x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func));
   Ha.zeros(b.Nbf(), b.Nbf());
   Hb.zeros(b.Nbf(), b.Nbf());
-  double exc = 0.0, nel = 0.0;
+  double exc = 0.0, nel = 0.0, ekin = 0.0;
   for (size_t iel = 0; iel < b.Nel(); iel++)
     for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
       grid.compute_bf(iel, irad);
       grid.update_density(Pa, Pb);
       nel += grid.compute_Nel();
+      ekin += grid.compute_Ekin();
       grid.compute_xc(x_func, c_func, thr);
       exc += grid.eval_Exc();
       grid.eval_Fxc(Ha, Hb);
     }
   Exc = exc;
   Nel = nel;
-  Ekin = 0.0;
+  Ekin = ekin;
 }
 
 }  // namespace oracle

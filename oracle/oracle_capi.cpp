@@ -216,6 +216,12 @@ int orc_xc_unpolarized_mgga(int func_id, int64_t N, const double *rho, const dou
   xc_unpolarized_mgga(func_id, N, rho, sigma, tau, exc, vrho, vsigma, vtau, thr);
   ORC_CATCH
 }
+int orc_xc_polarized_mgga(int func_id, int64_t n, const double *rho, const double *sigma, const double *tau, double *exc,
+                          double *vrho, double *vsigma, double *vtau, double thr) {
+  ORC_TRY
+  xc_polarized_mgga(func_id, (size_t)n, rho, sigma, tau, exc, vrho, vsigma, vtau, thr);
+  ORC_CATCH
+}
 int orc_xc_polarized(int func_id, int64_t N, const double *rho, const double *sigma, double *exc, double *vrho,
                      double *vsigma, double thr) {
   ORC_TRY

@@ -318,7 +318,7 @@ void eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int c_func
                   Mat &Hbout, double &Exc, double &Nel, double &Ekin, double thr) {
   Mat Ha(b.Ndummy(), b.Ndummy()), Hb(b.Ndummy(), b.Ndummy());
   Mat Pa(b.expand_boundaries(Pa0)), Pb(b.expand_boundaries(Pb0));
-  double exc = 0.0, nel = 0.0;
+  double exc = 0.0, nel = 0.0, ekin = 0.0;
   GridWorker grid(b, lang, mang);
   grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
   grid.do_tau = (x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func));
@@ -327,13 +327,14 @@ void eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int c_func
       grid.compute_bf(iel, irad);
       grid.update_density(Pa, Pb);
       nel += grid.compute_Nel();
+      ekin += grid.compute_Ekin();
       grid.compute_xc(x_func, c_func, thr);
       exc += grid.eval_Exc();
       grid.eval_Fxc(Ha, Hb);
     }
   Exc = exc;
   Nel = nel;
-  Ekin = 0.0;
+  Ekin = ekin;
   Haout = b.remove_boundaries(Ha);
   Hbout = b.remove_boundaries(Hb);
 }

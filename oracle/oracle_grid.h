@@ -16,8 +16,8 @@ typedef std::complex<double> cplx;
 
 struct DenseGrid {
   bool do_grad = false, do_gga = false, polarized = false;
-  bool do_tau = false, do_mgga_t = false;  // kinetic energy density (restricted runs only)
-  Vec tau, vtau;
+  bool do_tau = false, do_mgga_t = false;  // kinetic energy density
+  Vec tau, vtau;                           // polarised: 2 x Ng, point-major
   std::vector<size_t> bf_ind;
   size_t ne = 0, Ng = 0;
   std::vector<cplx> bf, bf_rho, bf_theta, bf_phi;  // ne x Ng column-major
@@ -72,29 +72,33 @@ struct DenseGrid {
         double gr = grho[ip], gt = grho[Ng + ip], gp = grho[2 * Ng + ip];
         sigma[ip] = gr * gr + gt * gt + gp * gp;
       }
-    if (do_tau) {  // tau = 1/2 sum_c Re[(P conj(d_c bf)) . d_c bf] / h_c^2   (dftgrid.cpp:90-112)
+    if (do_tau) {
       tau.assign(Ng, 0.0);
-      const std::vector<cplx> *dbf[3] = {&bf_rho, &bf_theta, &bf_phi};
-      const Vec *sc[3] = {&scale_r, &scale_theta, &scale_phi};
-      std::vector<cplx> Pv(ne);
-      for (int c = 0; c < 3; c++)
-        for (size_t ip = 0; ip < Ng; ip++) {
-          const cplx *f = &(*dbf[c])[ip * ne];
-          for (size_t i = 0; i < ne; i++) Pv[i] = 0;
-          for (size_t j = 0; j < ne; j++) {
-            cplx cb = std::conj(f[j]);
-            for (size_t i = 0; i < ne; i++) Pv[i] += P(i, j) * cb;
-          }
-          cplx k(0);
-          for (size_t i = 0; i < ne; i++) k += Pv[i] * f[i];
-          tau[ip] += 0.5 * k.real() / ((*sc[c])[ip] * (*sc[c])[ip]);
-        }
+      tau_of(P, tau.data(), 1);
     }
+  }
+  // tau = 1/2 sum_c Re[(P conj(d_c bf)) . d_c bf] / h_c^2   (dftgrid.cpp:90-112, 159-200)
+  void tau_of(const Mat &P, double *tau_out, size_t stride) const {
+    const std::vector<cplx> *dbf[3] = {&bf_rho, &bf_theta, &bf_phi};
+    const Vec *sc[3] = {&scale_r, &scale_theta, &scale_phi};
+    std::vector<cplx> Pv(ne);
+    for (int c = 0; c < 3; c++)
+      for (size_t ip = 0; ip < Ng; ip++) {
+        const cplx *f = &(*dbf[c])[ip * ne];
+        for (size_t i = 0; i < ne; i++) Pv[i] = 0;
+        for (size_t j = 0; j < ne; j++) {
+          cplx cb = std::conj(f[j]);
+          for (size_t i = 0; i < ne; i++) Pv[i] += P(i, j) * cb;
+        }
+        cplx k(0);
+        for (size_t i = 0; i < ne; i++) k += Pv[i] * f[i];
+        tau_out[ip * stride] += 0.5 * k.real() / ((*sc[c])[ip] * (*sc[c])[ip]);
+      }
   }
   double compute_Ekin() const {
     double e = 0.0;
-    if (do_tau && !polarized)
-      for (size_t ip = 0; ip < Ng; ip++) e += wtot[ip] * tau[ip];
+    if (do_tau)
+      for (size_t ip = 0; ip < Ng; ip++) e += wtot[ip] * (polarized ? tau[2 * ip] + tau[2 * ip + 1] : tau[ip]);
     return e;
   }
 
@@ -115,6 +119,11 @@ struct DenseGrid {
         sigma[3 * ip + 1] = ga[0] * gb[0] + ga[Ng] * gb[Ng] + ga[2 * Ng] * gb[2 * Ng];
         sigma[3 * ip + 2] = gb[0] * gb[0] + gb[Ng] * gb[Ng] + gb[2 * Ng] * gb[2 * Ng];
       }
+    if (do_tau) {
+      tau.assign(2 * Ng, 0.0);
+      tau_of(Pa, tau.data(), 2);
+      tau_of(Pb, tau.data() + 1, 2);
+    }
   }
 
   double compute_Nel() const {
@@ -135,16 +144,18 @@ struct DenseGrid {
     vsigma.assign(ns * Ng, 0.0);
     do_gga = false;
     do_mgga_t = false;
-    vtau.assign(Ng, 0.0);
+    vtau.assign(nr * Ng, 0.0);
     Vec e(Ng), v(nr * Ng), vs(ns * Ng);
     for (int id : {x_func, c_func}) {
       if (id <= 0) continue;
       do_gga = do_gga || xc_is_gga(id);
       if (xc_is_mgga(id)) {
-        if (polarized) throw std::logic_error("meta-GGAs are implemented for spin-restricted runs only\n");
-        Vec vt(Ng);
-        xc_unpolarized_mgga(id, Ng, rho.data(), sigma.data(), tau.data(), e.data(), v.data(), vs.data(), vt.data(), thr);
-        for (size_t i = 0; i < Ng; i++) vtau[i] += vt[i];
+        Vec vt(nr * Ng);
+        if (polarized)
+          xc_polarized_mgga(id, Ng, rho.data(), sigma.data(), tau.data(), e.data(), v.data(), vs.data(), vt.data(), thr);
+        else
+          xc_unpolarized_mgga(id, Ng, rho.data(), sigma.data(), tau.data(), e.data(), v.data(), vs.data(), vt.data(), thr);
+        for (size_t i = 0; i < nr * Ng; i++) vtau[i] += vt[i];
         do_mgga_t = true;
       } else if (polarized)
         xc_polarized(id, Ng, rho.data(), do_grad ? sigma.data() : nullptr, e.data(), v.data(), vs.data(), thr);
@@ -234,6 +245,20 @@ struct DenseGrid {
       increment_gga(Ha, gra);
       increment_gga(Hb, grb);
     }
+    if (do_mgga_t)  // dftgrid.cpp:615-636: the three tau terms of each spin
+      for (int sp = 0; sp < 2; sp++) {
+        Vec v0(Ng), v1(Ng), v2(Ng);
+        for (size_t ip = 0; ip < Ng; ip++) {
+          double vt = 0.5 * wtot[ip] * vtau[2 * ip + sp];
+          v0[ip] = vt / (scale_r[ip] * scale_r[ip]);
+          v1[ip] = vt / (scale_theta[ip] * scale_theta[ip]);
+          v2[ip] = vt / (scale_phi[ip] * scale_phi[ip]);
+        }
+        Mat &H = sp ? Hb : Ha;
+        increment_lda(H, v0, bf_rho);
+        increment_lda(H, v1, bf_theta);
+        increment_lda(H, v2, bf_phi);
+      }
     scatter_add(Hadummy, Ha);
     scatter_add(Hbdummy, Hb);
   }

@@ -233,22 +233,52 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
 // evaluating a polarised functional), which keeps (1 -+ zeta) away from the non-analytic end points.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
+constexpr int ND = 7;  // derivative slots: (rho_a, rho_b, sigma_tot) for the GGAs, (rho, sigma, tau) for the unpolarised
+                       // meta-GGAs, (rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb, tau_a, tau_b) for the polarised ones
 struct D3 {
-  double v, d[3];
+  double v, d[ND];
 };
-inline D3 C(double v) { return D3{v, {0, 0, 0}}; }
+inline D3 C(double v) {
+  D3 r;
+  r.v = v;
+  for (int k = 0; k < ND; k++) r.d[k] = 0.0;
+  return r;
+}
 inline D3 var(double v, int k) {
   D3 r = C(v);
   r.d[k] = 1.0;
   return r;
 }
-inline D3 operator+(D3 a, D3 b) { return D3{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
-inline D3 operator-(D3 a, D3 b) { return D3{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
-inline D3 operator-(D3 a) { return D3{-a.v, {-a.d[0], -a.d[1], -a.d[2]}}; }
-inline D3 operator*(D3 a, D3 b) {
-  return D3{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
+inline D3 operator+(D3 a, D3 b) {
+  D3 r;
+  r.v = a.v + b.v;
+  for (int k = 0; k < ND; k++) r.d[k] = a.d[k] + b.d[k];
+  return r;
 }
-inline D3 chain(D3 a, double f, double df) { return D3{f, {df * a.d[0], df * a.d[1], df * a.d[2]}}; }
+inline D3 operator-(D3 a, D3 b) {
+  D3 r;
+  r.v = a.v - b.v;
+  for (int k = 0; k < ND; k++) r.d[k] = a.d[k] - b.d[k];
+  return r;
+}
+inline D3 operator-(D3 a) {
+  D3 r;
+  r.v = -a.v;
+  for (int k = 0; k < ND; k++) r.d[k] = -a.d[k];
+  return r;
+}
+inline D3 operator*(D3 a, D3 b) {
+  D3 r;
+  r.v = a.v * b.v;
+  for (int k = 0; k < ND; k++) r.d[k] = a.d[k] * b.v + a.v * b.d[k];
+  return r;
+}
+inline D3 chain(D3 a, double f, double df) {
+  D3 r;
+  r.v = f;
+  for (int k = 0; k < ND; k++) r.d[k] = df * a.d[k];
+  return r;
+}
 inline D3 operator/(D3 a, D3 b) { return a * chain(b, 1.0 / b.v, -1.0 / (b.v * b.v)); }
 inline D3 operator+(D3 a, double c) { return a + C(c); }
 inline D3 operator+(double c, D3 a) { return a + C(c); }
@@ -471,6 +501,88 @@ D3 eps_tpss_c(D3 rho, D3 sig, D3 tau) {
   return rev * (1.0 + d * rev * z2 * z);
 }
 }  // namespace
+
+namespace {
+// TPSS correlation, spin-polarised (PRL 91, 146401 (2003), eqs 11-14; see xc_device.h for the formulas)
+D3 eps_tpss_c_pol(D3 ra, D3 rb, D3 saa, D3 sab, D3 sbb, D3 ta, D3 tb) {
+  const double d = 2.8;
+  D3 n = ra + rb;
+  D3 rs = Dcbrt((3.0 / (4.0 * PI)) / n);
+  D3 zeta = (ra - rb) / n;
+  D3 st = saa + 2.0 * sab + sbb;
+  D3 epbe = eps_pbe_c(n, rs, zeta, st);
+  D3 eta = Dmax(eps_pbe_c_fullpol(ra, saa), epbe), etb = Dmax(eps_pbe_c_fullpol(rb, sbb), epbe);
+  D3 tauw = st / (8.0 * n);
+  D3 z = tauw / Dmax(ta + tb, tauw);
+  D3 z2 = z * z;
+  D3 omz = 1.0 - zeta, opz = 1.0 + zeta;
+  D3 gz2 = (omz * omz * saa - 2.0 * omz * opz * sab + opz * opz * sbb) / (n * n);
+  D3 kf = Dcbrt((3.0 * PI * PI) * n);
+  D3 xi2 = gz2 / (4.0 * kf * kf);
+  D3 zz = zeta * zeta;
+  D3 C0 = 0.53 + 0.87 * zz + 0.50 * zz * zz + 2.26 * zz * zz * zz;
+  D3 den = 1.0 + 0.5 * xi2 * (1.0 / Dpow43(opz) + 1.0 / Dpow43(omz));
+  D3 Cz = C0 / (den * den * den * den);
+  D3 rev = epbe * (1.0 + Cz * z2) - (1.0 + Cz) * z2 * (ra * eta + rb * etb) / n;
+  return rev * (1.0 + d * rev * z2 * z);
+}
+}  // namespace
+
+/// spin-polarised meta-GGA: rho[2N], sigma[3N], tau[2N] point-major; exc[N], vrho[2N], vsigma[3N], vtau[2N]
+void xc_polarized_mgga(int id, size_t N, const double *rho, const double *sigma, const double *tau, double *exc, double *vrho,
+                       double *vsigma, double *vtau, double thr) {
+  for (size_t i = 0; i < N; i++) {
+    exc[i] = 0.0;
+    vrho[2 * i] = vrho[2 * i + 1] = 0.0;
+    vsigma[3 * i] = vsigma[3 * i + 1] = vsigma[3 * i + 2] = 0.0;
+    vtau[2 * i] = vtau[2 * i + 1] = 0.0;
+    double ra = rho[2 * i], rb = rho[2 * i + 1];
+    if (!(ra + rb >= thr) || ra + rb <= 0.0) continue;
+    // Exchange is a sum over the spin channels: a channel whose density is below the threshold contributes nothing
+    // (libxc screens it the same way).  Raising it to the threshold instead, as the GGAs above do, is harmless for
+    // v_rho and v_sigma (they multiply the channel's own density or gradient) but not for v_tau = d(n e)/d tau, which
+    // enters the Fock matrix unweighted and is of order 1/tau_unif(threshold) there.
+    const bool live_a = ra >= thr, live_b = rb >= thr;
+    ra = std::max(ra, thr);
+    rb = std::max(rb, thr);
+    const double saa = sigma[3 * i], sab = sigma[3 * i + 1], sbb = sigma[3 * i + 2];
+    const double ta = tau[2 * i], tb = tau[2 * i + 1];
+    if (id == 202) {  // exchange: spin scaling of the unpolarised functional
+      D3 na = C(0.0), nb = C(0.0);
+      if (live_a) {
+        D3 Ra = var(2.0 * ra, 0), Sa = var(std::max(4.0 * saa, 1e-40), 1), Ta = var(std::max(2.0 * ta, 1e-40), 2);
+        na = Ra * eps_tpss_x(Ra, Sa, Ta);
+      }
+      if (live_b) {
+        D3 Rb = var(2.0 * rb, 0), Sb = var(std::max(4.0 * sbb, 1e-40), 1), Tb = var(std::max(2.0 * tb, 1e-40), 2);
+        nb = Rb * eps_tpss_x(Rb, Sb, Tb);
+      }
+      exc[i] = 0.5 * (na.v + nb.v) / (ra + rb);
+      vrho[2 * i] = na.d[0];
+      vrho[2 * i + 1] = nb.d[0];
+      vsigma[3 * i] = 2.0 * na.d[1];
+      vsigma[3 * i + 2] = 2.0 * nb.d[1];
+      vtau[2 * i] = na.d[2];
+      vtau[2 * i + 1] = nb.d[2];
+    } else if (id == 231) {
+      D3 e = eps_tpss_c_pol(var(ra, 0), var(rb, 1), var(std::max(saa, 1e-40), 2), var(sab, 3), var(std::max(sbb, 1e-40), 4),
+                            var(std::max(ta, 1e-40), 5), var(std::max(tb, 1e-40), 6));
+      D3 en = (var(ra, 0) + var(rb, 1)) * e;
+      exc[i] = e.v;
+      vrho[2 * i] = en.d[0];
+      vrho[2 * i + 1] = en.d[1];
+      vsigma[3 * i] = en.d[2];
+      vsigma[3 * i + 1] = en.d[3];
+      vsigma[3 * i + 2] = en.d[4];
+      vtau[2 * i] = en.d[5];
+      vtau[2 * i + 1] = en.d[6];
+    } else {
+      std::ostringstream oss;
+      oss << "Functional " << id << " not found!";
+      throw std::runtime_error(oss.str());
+    }
+  }
+}
 
 bool xc_is_mgga(int id) { return id == 202 || id == 231; }
 

@@ -53,6 +53,8 @@ def lib():
         L.orc_scf_atomic.argtypes = [ctypes.c_int] * 7 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                                           ctypes.c_char_p] + [ctypes.c_int] * 6 + [
                                                               ctypes.c_double, ctypes.c_int, c_double_p]
+        for nm in ("orc_xc_polarized_mgga", "orc_xc_unpolarized_mgga"):
+            getattr(L, nm).argtypes = [ctypes.c_int, ctypes.c_int64] + [c_double_p] * 7 + [ctypes.c_double]
         L.orc_atomic_compute_rs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
         L.orc_atomic_rs_exchange.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
         for nm in ("orc_bessel_il", "orc_bessel_kl"):
@@ -263,6 +265,27 @@ def erfc_phi(n, Xi, xi):
 def set_erfc_binomial_mode(mode):
     """test hook: 1 = the reference's binomial helper in the erfc short-range series (see host/special.h)"""
     lib().orc_set_erfc_binomial_mode(int(mode))
+
+
+def xc_polarized_mgga(func_id, rho, sigma, tau, thr=1e-12):
+    """rho (n,2), sigma (n,3), tau (n,2) -> exc (n), vrho (n,2), vsigma (n,3), vtau (n,2)"""
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    n = rho.shape[0]
+    exc, vrho, vsigma, vtau = np.zeros(n), np.zeros((n, 2)), np.zeros((n, 3)), np.zeros((n, 2))
+    _check(lib().orc_xc_polarized_mgga(func_id, n, _p(rho), _p(sigma), _p(tau), _p(exc), _p(vrho), _p(vsigma), _p(vtau), thr))
+    return exc, vrho, vsigma, vtau
+
+
+def xc_unpolarized_mgga(func_id, rho, sigma, tau, thr=1e-12):
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    n = rho.size
+    exc, vrho, vsigma, vtau = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    _check(lib().orc_xc_unpolarized_mgga(func_id, n, _p(rho), _p(sigma), _p(tau), _p(exc), _p(vrho), _p(vsigma), _p(vtau), thr))
+    return exc, vrho, vsigma, vtau
 
 
 def xc_polarized(func_id, rho, sigma, thr=1e-12):

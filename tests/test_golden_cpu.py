@@ -490,3 +490,72 @@ def test_unrestricted_oracle_literature_energies(name, kw, lit, tol):
     r = orc.scf_atomic(convthr=1e-8, maxit=80, **kw)
     assert r["converged"]
     assert abs(r["Etot"] - lit) < tol, (name, r["Etot"], lit)
+
+
+# ---- spin-polarised meta-GGA (TPSS): known answers -------------------------------------------------------
+def test_polarized_tpss_known_answers():
+    """(1) zeta = 0 reduces to the spin-unpolarised functional (itself pinned by the He/Be/Ne literature energies);
+    (2) all seven derivatives against central differences; (3) TPSS correlation vanishes for any fully spin-polarised
+    one-orbital density (tau = tau_W): its self-correlation freedom; (4) on the exact hydrogen density the exchange
+    energy is -5/16 Eh -- the constants c, e of TPSS were fitted to that -- and the correlation energy 0."""
+    import oracle_lib as orc
+    import common
+    import scipy.linalg as sl
+    rho = np.array([1e-3, 0.05, 0.3, 2.0, 40.0])
+    sig = np.array([1e-6, 0.01, 0.2, 3.0, 500.0])
+    tau = np.array([2e-4, 0.03, 0.3, 4.0, 300.0])
+    for fid in (202, 231):
+        e, v, vs, vt = orc.xc_unpolarized_mgga(fid, rho, sig, tau)
+        rp, sp, tp = np.stack([rho / 2] * 2, 1), np.stack([sig / 4] * 3, 1), np.stack([tau / 2] * 2, 1)
+        e2, v2, vs2, vt2 = orc.xc_polarized_mgga(fid, rp, sp, tp)
+        assert np.max(np.abs(e2 - e) / np.abs(e)) < 1e-13
+        assert np.max(np.abs(0.5 * v2.sum(1) - v) / np.abs(v)) < 1e-12
+        assert np.max(np.abs(0.25 * vs2.sum(1) - vs) / np.abs(vs)) < 1e-12
+        assert np.max(np.abs(0.5 * vt2.sum(1) - vt) / np.abs(vt)) < 1e-12
+    rng = np.random.RandomState(3)
+    N = 6
+    ra, rb = rng.uniform(0.05, 2, N), rng.uniform(0.02, 1.5, N)
+    ga, gb = rng.uniform(-1, 1, (N, 3)), rng.uniform(-1, 1, (N, 3))
+    saa, sab, sbb = (ga * ga).sum(1), (ga * gb).sum(1), (gb * gb).sum(1)
+    ta, tb = saa / (8 * ra) + rng.uniform(0.01, 1, N), sbb / (8 * rb) + rng.uniform(0.01, 1, N)
+    X = np.stack([ra, rb, saa, sab, sbb, ta, tb], 1)
+
+    def energy(fid, Y):
+        return orc.xc_polarized_mgga(fid, Y[:, 0:2], Y[:, 2:5], Y[:, 5:7])[0] * (Y[:, 0] + Y[:, 1])
+
+    for fid in (202, 231):
+        _, v, vs, vt = orc.xc_polarized_mgga(fid, X[:, 0:2], X[:, 2:5], X[:, 5:7])
+        an = np.concatenate([v, vs, vt], 1)
+        for k in range(7):
+            h = 1e-6 * np.maximum(np.abs(X[:, k]), 1e-2)
+            Xp, Xm = X.copy(), X.copy()
+            Xp[:, k] += h
+            Xm[:, k] -= h
+            fd = (energy(fid, Xp) - energy(fid, Xm)) / (2 * h)
+            assert np.max(np.abs(fd - an[:, k]) / np.maximum(np.abs(an[:, k]), 1e-6)) < 1e-4, (fid, k)
+    n = np.array([0.01, 0.3, 5.0])
+    s = np.array([0.05, 0.4, 20.0]) ** 2
+    z3 = np.zeros(3)
+    e, _, _, _ = orc.xc_polarized_mgga(231, np.stack([n, z3], 1), np.stack([s, z3, z3], 1), np.stack([s / (8 * n), z3], 1))
+    epbe, _, _ = orc.xc_polarized(130, np.stack([n, z3], 1), np.stack([s, z3, z3], 1))
+    assert np.max(np.abs(e)) < 1e-10 * np.max(np.abs(epbe))
+    _, ob = common.make_atomic_bases(Z=1, lmax=0, mmax=0, nelem=5, nnodes=12, product=False)
+    S, T, V = ob.onebody("overlap"), ob.onebody("kinetic"), ob.onebody("nuclear")
+    _, C = sl.eigh(T + V, S)
+    Pa = np.asfortranarray(C[:, :1] @ C[:, :1].T)
+    Pb = np.zeros_like(Pa, order="F")
+    _, _, Ex, Nel, Ekin = ob.eval_Fxc_pol(10, 5, 202, 0, Pa, Pb)
+    _, _, Ec, _, _ = ob.eval_Fxc_pol(10, 5, 0, 231, Pa, Pb)
+    assert abs(Nel - 1.0) < 1e-12 and abs(Ekin - 0.5) < 1e-8  # integral of tau = <T> of the 1s orbital
+    assert abs(Ex + 0.3125) < 2e-7, Ex
+    assert abs(Ec) < 1e-10, Ec
+
+
+def test_oracle_unrestricted_tpss_atoms():
+    """TPSS total energies of open-shell atoms, Staroverov, Scuseria, Tao, Perdew, PRB 69, 075102 (4 decimals):
+    H -0.5002, Li -7.4891; N is this oracle's own number (regression)."""
+    import oracle_lib as orc
+    for Z, M, lm, lit, tol in ((1, 2, 0, -0.5002, 1e-4), (3, 2, 0, -7.4891, 1e-4), (7, 4, 1, -54.616172, 2e-6)):
+        r = orc.scf_atomic(Z, lm, lm, 5, 12, "mgga_x_tpss-mgga_c_tpss", M=M, convthr=1e-9, maxit=60)
+        assert r["converged"]
+        assert abs(r["Etot"] - lit) < tol, (Z, r["Etot"], lit)

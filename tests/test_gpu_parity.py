@@ -394,6 +394,39 @@ def _spin_densities(gb):
     return Pa, Pb
 
 
+def _orbital_spin_densities(gb, na=3, nb=2):
+    """spin densities of the lowest core-Hamiltonian orbitals: smooth, with the tails real densities have.  The
+    polarised meta-GGA potentials are ill-conditioned on random matrices: where rho_b sinks under the threshold while its
+    gradient stays finite (a node of a random density), d e_c/d sigma_bb ~ (1 - zeta)^{-4/3} reaches 1e11 and more, and
+    two arithmetic routes then differ in the leading digits.  Physical densities have the gradient vanish with the
+    density."""
+    import scipy.linalg as sl
+    E, C = sl.eigh(gb.kinetic() + gb.nuclear(), gb.overlap())
+    return np.asfortranarray(C[:, :na] @ C[:, :na].T), np.asfortranarray(C[:, :nb] @ C[:, :nb].T)
+
+
+@pytest.mark.parametrize("funcs", [(202, 231), (202, 0), (0, 231), (202, 130)])
+def test_xc_polarized_mgga_parity(case, hf, funcs):
+    """DFTGridWorker::update_density(Pa,Pb) with tau, compute_xc and eval_Fxc(Ha,Hb) for a tau-dependent functional
+    (src/diatomic/dftgrid.cpp:119-200, 343-458, 547-640)"""
+    import common
+    name, gb, ob, ldft, mdft = case
+    grid = hf.DFTGrid(gb, ldft, mdft)
+    x, c = funcs
+    for Pa, Pb in (_orbital_spin_densities(gb, 3, 2), _orbital_spin_densities(gb, 2, 0)):
+        Ha, Hb, Exc, Nel, Ekin = grid.eval_Fxc_pol(x, c, Pa, Pb)
+        Hao, Hbo, Exco, Nelo, Ekino = ob.eval_Fxc_pol(ldft, mdft, x, c, Pa, Pb)
+        assert np.all(np.isfinite(Ha)) and np.all(np.isfinite(Hb))
+        assert abs(Nel - Nelo) < 1e-11 * max(1.0, abs(Nelo)), (name, Nel, Nelo)
+        assert abs(Exc - Exco) < 1e-10 * max(1.0, abs(Exco)), (name, funcs, Exc, Exco)
+        assert abs(Ekin - Ekino) < 1e-10 * max(1.0, abs(Ekino)), (name, funcs, Ekin, Ekino)
+        assert common.relerr(Ha, Hao) < 1e-8, (name, funcs, common.relerr(Ha, Hao))
+        if np.max(np.abs(Pb)) > 0:
+            assert common.relerr(Hb, Hbo) < 1e-8, (name, funcs, common.relerr(Hb, Hbo))
+        else:  # empty channel: potential evaluated at rho_b = threshold, see test_xc_polarized_parity
+            assert common.relerr(Hb, Hbo) < 1e-4, (name, funcs, common.relerr(Hb, Hbo))
+
+
 @pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (1, 12), (101, 0), (0, 130), (406, 0)])
 def test_xc_polarized_parity(case, hf, funcs):
     import common
@@ -458,6 +491,12 @@ OPEN_SHELL_CASES = [
     ("N_LSD_maverage", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=4, nnodes=10, method="lda_x-lda_c_vwn", M=4, maverage=True),
      None, None),
     ("H_PBE0", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh", M=2), None, None),
+    # unrestricted meta-GGA: TPSS, Staroverov et al., PRB 69, 075102 (4 decimals)
+    ("H_TPSS", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=12, method="mgga_x_tpss-mgga_c_tpss", M=2), -0.5002, 1e-4),
+    ("Li_TPSS", "atomic", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=12, method="mgga_x_tpss-mgga_c_tpss", M=2), -7.4891, 1e-4),
+    ("N_TPSS", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=12, method="mgga_x_tpss-mgga_c_tpss", M=4), None, None),
+    ("HeH_TPSS_diatomic", "diatomic", dict(Z1=2, Z2=1, Rbond=1.5, lmmax=[3, 1], nelem=2, nnodes=8,
+                                           method="mgga_x_tpss-mgga_c_tpss", M=2), None, None),
     ("H2+_like_HeH2+", "diatomic", dict(Z1=1, Z2=1, Rbond=2.0, lmmax=[6], nelem=3, nnodes=10, method="HF", M=3), None, None),
     ("OH_like_LiH+_PBE", "diatomic", dict(Z1=3, Z2=0, Rbond=3.0, lmmax=[4, 2], nelem=3, nnodes=8,
                                           method="gga_x_pbe-gga_c_pbe", M=2), None, None),
@@ -501,6 +540,11 @@ ATOMIC_SCF_CASES = [
     # meta-GGA (tau): TPSS, total energies of Staroverov et al., PRB 69, 075102, Table (4 decimals)
     ("He_TPSS", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="mgga_x_tpss-mgga_c_tpss"), -2.9097, 1e-4),
     ("Ne_TPSS", dict(Z=10, lmax=1, mmax=1, nelem=4, nnodes=12, method="mgga_x_tpss-mgga_c_tpss"), -128.9811, 2e-4),
+    # BASELINE config 2 itself: Ar, PBE, 20 radial elements x 15 nodes, lmax = mmax = 1 (Nbf = 1116, (l,m) blocks of 279);
+    # the same basis with LDA against the NIST reference-data total energy
+    ("Ar_PBE_config2", dict(Z=18, lmax=1, mmax=1, nelem=20, nnodes=15, method="gga_x_pbe-gga_c_pbe", symmetry=2), None, None),
+    ("Ar_LDA_config2_basis", dict(Z=18, lmax=1, mmax=1, nelem=20, nnodes=15, method="lda_x-lda_c_vwn", symmetry=2),
+     -525.946195, 2e-6),
 ]
 
 
@@ -513,7 +557,8 @@ def test_atomic_scf_energy_parity(hf, name, kw, lit, littol):
     assert abs(g["Etot"] - o["Etot"]) < 1e-8 * max(1.0, abs(o["Etot"]) / 10), (name, g["Etot"], o["Etot"])
     for k in ("Ekin", "Epot", "Ecoul", "Exx", "Exc"):
         assert abs(g[k] - o[k]) < 1e-6 * max(1.0, abs(o[k]) / 10), (name, k, g[k], o[k])
-    assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
+    if lit is not None:
+        assert abs(g["Etot"] - lit) < littol, (name, g["Etot"], lit)
 
 
 # ---------------------------------------------------------------------------------------------------
