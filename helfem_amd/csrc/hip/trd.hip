@@ -420,7 +420,13 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   const int j = i - 1;
   const bool has_prev = (c > 0) && (j >= 0) && (j <= n - 3);
   const bool has_cur = (sweep & 1) && (i <= n - 3);
-  const int dbg = sweep >> 1;  // measurement-only switches of the replay (0 in the factorisation)
+  const int dbg = (sweep >> 1) & 7;  // measurement-only switches of the replay (0 in the factorisation)
+  // sweep & 16: symmetric sweep (the whole panel runs in this mode).  Rows and columns share one slab partition
+  // (shifted by delta), only the tiles on and below the diagonal are launched, an off-diagonal tile (rs > cs) also
+  // forms the transposed product T^T x_rows for its column slab and stores it in partial slot rs: every row still
+  // receives exactly one partial per slot, so phase A of the next launch reads the same buffers.  Used while a full
+  // grid would need more workgroups than the chip has CUs (two rounds of workgroups per column otherwise).
+  const bool symm = (sweep & 16) != 0;
   // dbg & 4: workgroup 0 of block 0 records wall-clock stamps (100 MHz) of its phases into fdots' spare tail
 #define TRDF_STAMP(k)                                                                                        \
   if ((dbg & 4) && blockIdx.x == 0 && blk == 0 && threadIdx.x == 0)                                          \
@@ -442,7 +448,14 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   const bool vec2 = ((n & 1) == 0);
   const int delta = (has_cur && vec2) ? ((i + 1) & 1) : 0;  // shift that makes every row pair a 16-byte aligned double2
   int rs, cs, ncs, nrt;
-  if (has_cur) {
+  if (has_cur && symm) {
+    nrt = ncs = (m + delta + TF_T - 1) / TF_T;
+    rs = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while (rs * (rs + 1) / 2 > (int)blockIdx.x) rs--;
+    while ((rs + 1) * (rs + 2) / 2 <= (int)blockIdx.x) rs++;
+    cs = blockIdx.x - rs * (rs + 1) / 2;
+    if (rs >= nrt) return;
+  } else if (has_cur) {
     ncs = (m + TF_T - 1) / TF_T;
     nrt = (m + 1 + TF_T - 1) / TF_T;
     rs = blockIdx.x / ncs;
@@ -456,7 +469,8 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     if (rs >= nrt) return;
   }
   const int gR0 = has_cur ? (i + 1 + TF_T * rs - delta) : (i + TF_T * rs);  // first row of the row slab
-  const int gC0 = i + 1 + TF_T * cs;                                        // first row/col of the column slab
+  const int cshift = (has_cur && symm) ? delta : 0;                         // symmetric mode: one partition for both
+  const int gC0 = i + 1 + TF_T * cs - cshift;                               // first row/col of the column slab
 
   __shared__ double xR[TF_T], xC[TF_T], vC[TF_T], wC[TF_T];
   __shared__ double red[TF_NW * TF_T];
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
       const unsigned a1 = (unsigned)(i + 1) * (unsigned)n + (unsigned)(i + 1) + (unsigned)rowc;
 #pragma unroll
       for (int u = 0; u < NU; u++) {
-        const int cc = min(TF_T * cs + wave * NU + u, m - 1);  // local column, clamped
+        const int cc = max(0, min(TF_T * cs - cshift + wave * NU + u, m - 1));  // local column, clamped
         d2_t t = *(const gdouble2 *)(A + (a1 + (unsigned)cc * (unsigned)n));
         r0[u] = t.x;  // rows outside the block are masked after the FMAs, x is zero on the clamped columns
         r1[u] = t.y;
@@ -497,10 +511,10 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     } else {
 #pragma unroll
       for (int u = 0; u < NU; u++) {
-        const int cc = TF_T * cs + wave * NU + u;
-        const unsigned off = a0 + (unsigned)cc * (unsigned)n;
-        r0[u] = (ok0 && cc < m) ? A[off] : 0.0;
-        r1[u] = (ok1 && cc < m) ? A[off + 1u] : 0.0;
+        const int cc = TF_T * cs - cshift + wave * NU + u;
+        const unsigned off = a0 + (unsigned)max(cc, 0) * (unsigned)n;
+        r0[u] = (ok0 && cc >= 0 && cc < m) ? A[off] : 0.0;
+        r1[u] = (ok1 && cc >= 0 && cc < m) ? A[off + 1u] : 0.0;
       }
     }
   };
@@ -509,12 +523,13 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   // row slot rid < 128: row gR0 + rid of the row slab; rid >= 128: row gC0 + rid - 128 of the column slab
   const bool isR = rid < TF_T;
   const int g = isR ? gR0 + rid : gC0 + (rid - TF_T);
-  const bool live = (g >= i + 1) && g < n && (isR || (has_cur && (rs != cs || delta)));
+  const bool live = (g >= i + 1) && g < n && (isR || (has_cur && (rs != cs || (delta && !symm))));
   double xnew = 0.0, vg = 0.0, wg = 0.0;
   if (has_prev) {
     const int mp = m + 1;                         // rows of column j's reflector, g >= i
-    const int pncs = (mp + TF_T - 1) / TF_T;      // column slabs of K_{i-1}
-    const int pnrt = (mp + 1 + TF_T - 1) / TF_T;  // its row slabs
+    const int pdelta = (symm && vec2) ? (i & 1) : 0;               // delta of K_{i-1} (symmetric mode)
+    const int pncs = (mp + pdelta + TF_T - 1) / TF_T;              // column slabs (partial slots) of K_{i-1}
+    const int pnrt = symm ? pncs : (mp + 1 + TF_T - 1) / TF_T;     // its row slabs
     const gdouble *ppv = fppw + (size_t)ppar * TF_MAXS * n;
     const gdouble *pdots = fdotsw + (size_t)ppar * TF_MAXS * TF_MAXS;
     const gdouble *pxn2 = fxn2w + (size_t)ppar * TF_MAXS;
@@ -550,7 +565,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     }
     // scalar stage (every workgroup, redundantly): reductions of the partials of K_{i-1}
     {
-      const int nd = pnrt * pncs;
+      const int nd = symm ? pnrt * (pnrt + 1) / 2 : pnrt * pncs;  // tiles of K_{i-1}
       double s0 = (tid < nd) ? pdots[tid] : 0.0, s1 = (tid + TF_NTH < nd) ? pdots[tid + TF_NTH] : 0.0;  // x^T A22 x
       double t2 = (tid < pncs) ? pxn2[tid] : 0.0;                 // |x[1:]|^2
       double qi = (tid < pncs) ? ppv[(unsigned)tid * un + (unsigned)i] : 0.0;  // q_raw at row i
@@ -706,7 +721,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   if (!has_cur) return;
 
   // x_i on the row slab and the column slab (and v, w of the previous column on the column slab)
-  const bool same = (rs == cs) && !delta;  // the two slabs are the same rows
+  const bool same = (rs == cs) && (!delta || symm);  // the two slabs are the same rows
   if (grp == 0) {
     if (isR) {
       xR[rid] = live ? xnew : 0.0;
@@ -736,6 +751,42 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     const bool ok0 = row >= 0 && row < m, ok1 = row + 1 >= 0 && row + 1 < m;
     red[wave * TF_T + 2 * lane] = ok0 ? acc0 : 0.0;
     red[wave * TF_T + 2 * lane + 1] = ok1 ? acc1 : 0.0;
+    if (symm && rs > cs) {
+      // transposed product of an off-diagonal tile: qT[col] = sum_rows T[row][col] x[row].  The wave's 64 lanes hold all
+      // 128 rows of its NU columns: a halving butterfly (NU/2, NU/4, ... values exchanged with lane^32, ^16, ...) leaves
+      // one column per lane group, the last log2(64/NU) steps add within the group.
+      const double xr0 = ok0 ? xR[2 * lane] : 0.0, xr1 = ok1 ? xR[2 * lane + 1] : 0.0;
+      double tv[NU];
+#pragma unroll
+      for (int u = 0; u < NU; u++) tv[u] = r0[u] * xr0 + r1[u] * xr1;
+      int width = NU, lmask = 32;
+#pragma unroll
+      for (int st = 0; st < 6; st++) {
+        if (width > 1) {
+          const int half = width / 2;
+          const bool up = (lane & lmask) != 0;  // upper lanes keep the upper half of the values
+#pragma unroll
+          for (int u = 0; u < NU / 2; u++) {
+            if (u < half) {
+              const double send = up ? tv[u] : tv[u + half];
+              const double keep = up ? tv[u + half] : tv[u];
+              tv[u] = keep + __shfl_xor(send, lmask, 64);
+            }
+          }
+          width = half;
+        } else {
+          tv[0] += __shfl_xor(tv[0], lmask, 64);
+        }
+        lmask >>= 1;
+      }
+      // lane bits 5.. select the column: after the NU-halving steps lane group (lane >> (6 - log2 NU)) holds column index
+      constexpr int LG = (NU == 8) ? 3 : (NU == 16 ? 4 : 2);
+      if ((lane & ((64 >> LG) - 1)) == 0) {
+        const int u = lane >> (6 - LG);
+        const int h = gC0 + wave * NU + u;
+        if (h >= i + 1 && h < n) fppw[((size_t)par * TF_MAXS + rs) * n + h] = tv[0];
+      }
+    }
   }
   __syncthreads();
   TRDF_STAMP(4)
@@ -748,11 +799,13 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     for (int w = 0; w < TF_NW; w++) pq += red[w * TF_T + tid];
     if (okr) fppw[((size_t)par * TF_MAXS + cs) * n + gr] = pq;
     dv = okr ? pq * xR[tid] : 0.0;
+    if (symm && rs > cs) dv *= 2.0;  // x_r^T T x_c + x_c^T T^T x_r
     for (int o = 32; o > 0; o >>= 1) dv += __shfl_down(dv, o, 64);
     if (lane == 0) sred[48 + wave] = dv;
   }
   // ---- per column slab (first row slab only): |x[1:]|^2, V^T x, W^T x over the slab ----
-  if (rs == 0) {
+  const bool slab_owner = symm ? (rs == cs) : (rs == 0);  // the tile that forms the per-column-slab sums
+  if (slab_owner) {
     if (tid >= TF_T && tid < 2 * TF_T) {
       int k = tid - TF_T;
       int h = gC0 + k;
@@ -802,7 +855,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   TRDF_STAMP(5)
   if (tid == 0) {
     fdotsw[(size_t)par * TF_MAXS * TF_MAXS + blockIdx.x] = sred[48] + sred[49];
-    if (rs == 0) fxn2w[(size_t)par * TF_MAXS + cs] = sred[50] + sred[51];
+    if (slab_owner) fxn2w[(size_t)par * TF_MAXS + cs] = sred[50] + sred[51];
   }
 #undef TRDF_STAMP
 #undef TRDF_LDS_BARRIER
@@ -823,6 +876,16 @@ __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
   b.d[blk][n - 1] = A[(size_t)(n - 1) * n + (n - 1)];
   b.e[blk][n - 1] = 0.0;
   if (n >= 1) b.tau[blk][n - 1] = 0.0;
+}
+
+static int trd_num_cus(hfg_ctx *ctx) {
+  static int ncu = 0;
+  if (!ncu && getenv("HELFEM_TRDF_SYM_MIN")) ncu = atoi(getenv("HELFEM_TRDF_SYM_MIN"));  // A/B runs: switch-over tile count
+  if (!ncu) {
+    hipDeviceProp_t prop;
+    ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return ncu;
 }
 
 struct TrdWork {
@@ -934,14 +997,30 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
   for (int j0 = 0; j0 <= nmax - 3; j0 += TB_NB) {
     if (fused) {
       const int jend = std::min(j0 + TB_NB, nmax - 2);
+      // symmetric sweep (lower tiles only) for the panels whose full grid would not fit the chip in one round
+      // (HELFEM_TRDF_SYM: 0 never, 1 always, default by size)
+      static const int force_sym = getenv("HELFEM_TRDF_SYM") ? atoi(getenv("HELFEM_TRDF_SYM")) : -1;
+      bool symm;
+      {
+        const int m0 = nmax - j0 - 1;
+        const long full = (long)((m0 + 1 + TF_T - 1) / TF_T) * std::max(1, (m0 + TF_T - 1) / TF_T) * nblk;
+        symm = (force_sym >= 0) ? (force_sym != 0) : (full > trd_num_cus(ctx));
+      }
       for (int i = j0; i <= jend; i++) {
-        const int sweep = (i < jend) ? 1 : 0;  // the last launch of the panel only finishes column jend-1
+        const int sweep = ((i < jend) ? 1 : 0) | (symm ? 16 : 0);  // the last launch of the panel only finishes column jend-1
         const int m = nmax - i - 1;
         const int nrt = (m + 1 + TF_T - 1) / TF_T, ncs = std::max(1, (m + TF_T - 1) / TF_T);
+        int grid = (sweep & 1) ? nrt * ncs : nrt;
+        if (symm && (sweep & 1)) {
+          const int delta = ((nmax & 1) == 0) ? ((i + 1) & 1) : 0;  // largest block; smaller blocks need no more tiles
+          const int nt = (m + 1 + TF_T - 1) / TF_T;                 // >= ceil((m + delta)/T) for either parity of n
+          grid = nt * (nt + 1) / 2;
+          (void)delta;
+        }
         static const int force_nth = getenv("HELFEM_TRDF_NTH") ? atoi(getenv("HELFEM_TRDF_NTH")) : 0;  // A/B runs
         const bool small_wg = (force_nth == 512);
-        if (small_wg) hipLaunchKernelGGL(k_trdf<512>, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(512), 0, s, db, i, i - j0, sweep);
-        else hipLaunchKernelGGL(k_trdf<1024>, dim3(sweep ? nrt * ncs : nrt, nblk), dim3(1024), 0, s, db, i, i - j0, sweep);
+        if (small_wg) hipLaunchKernelGGL(k_trdf<512>, dim3(grid, nblk), dim3(512), 0, s, db, i, i - j0, sweep);
+        else hipLaunchKernelGGL(k_trdf<1024>, dim3(grid, nblk), dim3(1024), 0, s, db, i, i - j0, sweep);
       }
     } else {
     {
@@ -1014,9 +1093,18 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
       const int cfix = getenv("HELFEM_TRDF_C") ? atoi(getenv("HELFEM_TRDF_C")) : c;
       const int dbg = getenv("HELFEM_TRDF_DBG") ? atoi(getenv("HELFEM_TRDF_DBG")) : 0;
       static const int force_nth = getenv("HELFEM_TRDF_NTH") ? atoi(getenv("HELFEM_TRDF_NTH")) : 0;
+      static const int force_sym = getenv("HELFEM_TRDF_SYM") ? atoi(getenv("HELFEM_TRDF_SYM")) : -1;
       const bool small_wg = (force_nth == 512);
-      if (small_wg) hipLaunchKernelGGL(k_trdf<512>, dim3(nrt * ncs, nblk), dim3(512), 0, s, db, i, cfix, 1 | (dbg << 1));
-      else hipLaunchKernelGGL(k_trdf<1024>, dim3(nrt * ncs, nblk), dim3(1024), 0, s, db, i, cfix, 1 | (dbg << 1));
+      bool symm;
+      {
+        const int m0 = nmax - (i - c) - 1;  // the panel's first column decides, as in the factorisation
+        const long full = (long)((m0 + 1 + TF_T - 1) / TF_T) * std::max(1, (m0 + TF_T - 1) / TF_T) * nblk;
+        symm = (force_sym >= 0) ? (force_sym != 0) : (full > trd_num_cus(ctx));
+      }
+      const int grid = symm ? nrt * (nrt + 1) / 2 : nrt * ncs;
+      const int sw = 1 | ((dbg & 7) << 1) | (symm ? 16 : 0);
+      if (small_wg) hipLaunchKernelGGL(k_trdf<512>, dim3(grid, nblk), dim3(512), 0, s, db, i, cfix, sw);
+      else hipLaunchKernelGGL(k_trdf<1024>, dim3(grid, nblk), dim3(1024), 0, s, db, i, cfix, sw);
     } else {
       const int nrg = (m + 1 + 127) / 128;
       int ncs = std::max(1, std::min(64, (m + 63) / 64));
