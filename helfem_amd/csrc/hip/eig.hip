@@ -720,6 +720,8 @@ static void bt_wy_apply(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, i
   if (bt_use_side()) HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));
   for (int p = P - 1; p >= 0; p--) {
     gemm_tasklist64_dev(ctx, w.btslab.p + (size_t)p * BT_S * nblk, BT_S * nblk, BT_KB, nmax);
+    // (summing the slabs inside the update's operand loads instead was measured: 2.73 -> 3.11 ms, six times the operand
+    // traffic on every tile's critical path)
     hipLaunchKernelGGL(k_bt_wsum, dim3(64, nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk, BT_S);
     static const int acc_tile = getenv("HELFEM_ACC_TILE") ? atoi(getenv("HELFEM_ACC_TILE")) : 0;  // A/B runs: 64 or 128
     gemm_tasklist_acc_dev(ctx, w.bttasks.p + ((size_t)2 * P + p) * nblk, nblk, nmax, nmax, acc_tile != 128);

@@ -749,7 +749,9 @@ __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__r
                                 const int *__restrict__ grp_off, const int *__restrict__ grp_shell, int do_grad,
                                 int do_tau, size_t NQ, int rank, int nranks, double *__restrict__ GA,
                                 double *__restrict__ GB, double *__restrict__ GC) {
-  extern __shared__ double sh[];  // f0[nth], f1[nth], f2[nth], f3[nth], f4[nth]
+  // LDS: f0..f4[nth], then the Theta / dTheta rows of the two shell groups, [i][shell] (the pair loop reads them with
+  // consecutive b across threads; from global memory the loop was latency-bound: 0.26 ms per build at Nbf = 4230)
+  extern __shared__ double sh[];
   size_t Q = blockIdx.x;
   if ((int)(Q % nranks) != rank) return;
   int ga = blockIdx.y / G, gb = blockIdx.y % G;
@@ -758,6 +760,7 @@ __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__r
   size_t stride = NQ * G * G * nth;
   size_t o = ((Q * G + ga) * G + gb) * nth;
   double *f0 = sh, *f1 = sh + nth, *f2 = sh + 2 * nth, *f3 = sh + 3 * nth, *f4 = sh + 4 * nth;
+  double *sTa = sh + 5 * nth, *sDa = sTa + (size_t)nth * na, *sTb = sDa + (size_t)nth * na, *sDb = sTb + (size_t)nth * nb;
   for (int i = threadIdx.x; i < nth; i += blockDim.x) {
     f0[i] = Fo[o + i];
     f1[i] = do_grad ? Fo[stride + o + i] : 0.0;
@@ -765,20 +768,31 @@ __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__r
     f3[i] = do_tau ? Fo[3 * stride + o + i] : 0.0;
     f4[i] = do_tau ? Fo[4 * stride + o + i] : 0.0;
   }
+  for (int t = threadIdx.x; t < nth * na; t += blockDim.x) {
+    int ia = t / nth, i = t % nth;  // consecutive threads read consecutive theta points of one shell
+    int a = grp_shell[a0 + ia];
+    sTa[i * na + ia] = Th[(size_t)a * nth + i];
+    sDa[i * na + ia] = dTh[(size_t)a * nth + i];
+  }
+  for (int t = threadIdx.x; t < nth * nb; t += blockDim.x) {
+    int ib = t / nth, i = t % nth;
+    int b = grp_shell[b0 + ib];
+    sTb[i * nb + ib] = Th[(size_t)b * nth + i];
+    sDb[i * nb + ib] = dTh[(size_t)b * nth + i];
+  }
   __syncthreads();
   size_t AA = (size_t)A * A;
   for (int t = threadIdx.x; t < na * nb; t += blockDim.x) {
-    int a = grp_shell[a0 + t / nb], b = grp_shell[b0 + t % nb];
-    const double *ta = Th + (size_t)a * nth, *tb = Th + (size_t)b * nth, *da = dTh + (size_t)a * nth;
+    const int ia = t / nb, ib = t % nb;
+    int a = grp_shell[a0 + ia], b = grp_shell[b0 + ib];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    const double *dbb = dTh + (size_t)b * nth;
     for (int i = 0; i < nth; i++) {
-      double tbi = tb[i];
-      s0 += (ta[i] * f0[i] + da[i] * f1[i]) * tbi;
-      s1 += ta[i] * f2[i] * tbi;
+      const double tai = sTa[i * na + ia], dai = sDa[i * na + ia], tbi = sTb[i * nb + ib];
+      s0 += (tai * f0[i] + dai * f1[i]) * tbi;
+      s1 += tai * f2[i] * tbi;
       if (do_tau) {
-        s0 += da[i] * dbb[i] * f4[i];
-        s2 += ta[i] * tbi * f3[i];
+        s0 += dai * sDb[i * nb + ib] * f4[i];
+        s2 += tai * tbi * f3[i];
       }
     }
     GA[Q * AA + (size_t)a * A + b] = s0;
@@ -814,26 +828,39 @@ __global__ void k_xc_fock_radial(const double *__restrict__ GA, const double *__
     sdB[t] = dB[(size_t)e * nq * p + t];
   }
   __syncthreads();
+  // U[q][m] = gs B_m + g2 B'_m,  W[q][m] = g1 B_m + g3 B'_m:  H[n][m] = sum_q B_n U[q][m] + B'_n W[q][m]  (four LDS reads
+  // per point and output instead of eight: the loop is LDS-bound)
+  double *sU = sdB + nq * p, *sW = sU + nq * p;
+  for (int t = threadIdx.x; t < nq * p; t += blockDim.x) {
+    const int q = t / p;
+    sU[t] = gs[q] * sB[t] + g2[q] * sdB[t];
+    sW[t] = g1[q] * sB[t] + g3[q] * sdB[t];
+  }
+  __syncthreads();
   int pp = p * p;
   for (int t = threadIdx.x; t < pp; t += blockDim.x) {
     int n = t % p, m = t / p;
     double acc = 0.0;
-    for (int q = 0; q < nq; q++) {
-      const double bn = sB[q * p + n], bm = sB[q * p + m], dn = sdB[q * p + n], dm = sdB[q * p + m];
-      acc += bn * bm * gs[q] + dn * bm * g1[q] + bn * dm * g2[q] + dn * dm * g3[q];
-    }
+    for (int q = 0; q < nq; q++) acc += sB[q * p + n] * sU[q * p + m] + sdB[q * p + n] * sW[q * p + m];
     Hc[((size_t)xy * E + e) * pp + t] = acc;
   }
 }
 
 __global__ void k_xc_sum_partials(const double *__restrict__ partial, size_t NQ, double *__restrict__ scal) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double nel = 0.0, exc = 0.0, kin = 0.0;
-    for (size_t q = 0; q < NQ; q++) {
-      nel += partial[q];
-      exc += partial[NQ + q];
-      kin += partial[2 * NQ + q];
-    }
+  // one wave: lane l adds the points l, l + 64, ... in order, then a fixed shuffle tree (deterministic)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  double nel = 0.0, exc = 0.0, kin = 0.0;
+  for (size_t q = threadIdx.x; q < NQ; q += 64) {
+    nel += partial[q];
+    exc += partial[NQ + q];
+    kin += partial[2 * NQ + q];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    nel += __shfl_down(nel, o, 64);
+    exc += __shfl_down(exc, o, 64);
+    kin += __shfl_down(kin, o, 64);
+  }
+  if (threadIdx.x == 0) {
     scal[0] = exc;  // Exc
     scal[1] = nel;  // Nel
     scal[2] = kin;  // Ekin = integral of tau (zero unless a meta-GGA asked for tau; dftgrid.cpp:227-240)
@@ -844,6 +871,14 @@ __global__ void k_xc_sum_partials(const double *__restrict__ partial, size_t NQ,
 // launchers
 // -------------------------------------------------------------------------------------------------
 static int round_up64(int n) { return ((n + 63) / 64) * 64; }
+// LDS of k_xc_fock_theta: five potential rows and the Theta, dTheta rows of two shell groups
+static size_t xc_fock_theta_lds(int nth, int maxgrp) {
+  size_t shb = (size_t)(5 * nth + 4 * nth * maxgrp) * sizeof(double);
+  if (shb > 160 * 1024) throw std::runtime_error("angular grid too large for the XC Fock kernel's LDS tables");
+  if (shb > 64 * 1024)
+    HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_fock_theta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+  return shb;
+}
 // LDS of k_xc_density_radial (256 threads): P block, the two transposed tables, the partial sums of the j classes
 static size_t xc_density_radial_lds(int p, int nq) {
   const int NJ = (256 / nq > 0) ? std::min(256 / nq, p) : 1;
@@ -992,10 +1027,10 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   hipLaunchKernelGGL(k_xc_grid, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
                      x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
-  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 5 * nth * sizeof(double), ctx->stream,
+  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), xc_fock_theta_lds(nth, maxgrp), ctx->stream,
                      a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, NQ,
                      ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
-  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 2 * nq * p) * sizeof(double),
+  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 4 * nq * p) * sizeof(double),
                      ctx->stream, a.GA.p, a.GB.p, a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                      ctx->shard_rank, ctx->shard_n, dHc);
   hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
@@ -1060,10 +1095,10 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
                      x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
   for (int sp = 0; sp < 2; sp++) {
-    hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), 5 * nth * sizeof(double), ctx->stream,
+    hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), xc_fock_theta_lds(nth, maxgrp), ctx->stream,
                        a.Fo.p + (size_t)sp * npl * nv, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad,
                        do_tau, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
-    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 2 * nq * p) * sizeof(double),
+    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 4 * nq * p) * sizeof(double),
                        ctx->stream, a.GA.p, a.GB.p, (const double *)a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                        ctx->shard_rank, ctx->shard_n, sp ? dHcb : dHca);
   }
