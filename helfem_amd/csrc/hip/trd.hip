@@ -861,6 +861,108 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
 #undef TRDF_LDS_BARRIER
 }
 
+// Tail of the factorisation: once the trailing matrix of every block fits one workgroup's LDS (order <= TT_MAX) the
+// remaining columns are reduced by the unblocked algorithm (LAPACK dsytd2 algebra: v, p = tau A22 v,
+// w = p - tau/2 (p^T v) v, A22 -= v w^T + w v^T) inside ONE launch per batch: a column then costs a few workgroup
+// barriers (~1.5 us) instead of a dependent launch (~8 us).  Same reflector convention as k_trdf (beta = -sign(alpha)|x|,
+// v_1 = 1 implicit, v stored below the subdiagonal of column j, d/e/tau), fixed summation orders.
+constexpr int TT_MAX = 128;
+constexpr int TT_LD = TT_MAX + 1;
+constexpr int TT_CG = 8;  // column groups: thread (r, cg) owns the columns c = cg, cg + 8, ... of row r
+__global__ __launch_bounds__(1024) void k_trd_tail(const TrdBatch *__restrict__ bp, int j0) {
+  extern __shared__ double sm[];  // S[m][TT_LD] | v[TT_MAX] | w[TT_MAX] | part[TT_CG][TT_MAX] | red[32]
+  const TrdBatch &b = *bp;
+  const int blk = blockIdx.x;
+  const int n = b.n[blk];
+  const int m = n - j0;  // order of the trailing matrix (rows/cols j0 .. n-1)
+  if (m < 3 || m > TT_MAX) return;
+  double *S = sm, *v = sm + TT_MAX * TT_LD, *w = v + TT_MAX, *part = w + TT_MAX, *red = part + TT_CG * TT_MAX;
+  gdouble *A = HFG_G(b.A[blk]);
+  const int tid = threadIdx.x, r = tid & (TT_MAX - 1), cg = tid >> 7, wave = tid >> 6, lane = tid & 63;
+  for (int c = cg; c < m; c += TT_CG)
+    if (r < m) S[c * TT_LD + r] = A[(size_t)(j0 + c) * n + j0 + r];
+  __syncthreads();
+  for (int k = 0; k <= m - 3; k++) {
+    const int j = j0 + k;
+    const int k1 = k + 1;  // first row/col of the trailing block of this step
+    // |x[1:]|^2 of the column below the subdiagonal element
+    double sq = 0.0;
+    if (tid < TT_MAX && tid > k1 && tid < m) {
+      double xv = S[k * TT_LD + tid];
+      sq = xv * xv;
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+    if (lane == 0 && wave < 2) red[wave] = sq;
+    __syncthreads();
+    double tau, beta, scale;
+    {
+      const double xn2 = red[0] + red[1];
+      const double alpha = S[k * TT_LD + k1];
+      if (xn2 == 0.0) {
+        tau = 0.0;
+        beta = alpha;
+        scale = 0.0;
+      } else {
+        const double nrm = sqrt(alpha * alpha + xn2);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+    }
+    if (tid < TT_MAX) {
+      double vv = 0.0;
+      if (tid == k1) vv = 1.0;
+      else if (tid > k1 && tid < m) vv = S[k * TT_LD + tid] * scale;
+      v[tid] = vv;
+      if (tid > k1 && tid < m) A[(size_t)j * n + j0 + tid] = vv;  // reflector for the back-transformation
+    }
+    if (tid == 0) {
+      b.d[blk][j] = S[k * TT_LD + k];
+      b.e[blk][j] = beta;
+      b.tau[blk][j] = tau;
+    }
+    __syncthreads();
+    // p = tau S22 v: partial sums over this thread's columns, then over the column groups
+    {
+      double acc = 0.0;
+      if (r >= k1 && r < m)
+        for (int c = k1 + ((cg - k1) % TT_CG + TT_CG) % TT_CG; c < m; c += TT_CG) acc += S[c * TT_LD + r] * v[c];
+      part[cg * TT_MAX + r] = acc;
+    }
+    __syncthreads();
+    double pv = 0.0;
+    if (tid < TT_MAX) {
+      double pr = 0.0;
+      if (tid >= k1 && tid < m) {
+#pragma unroll
+        for (int g = 0; g < TT_CG; g++) pr += part[g * TT_MAX + tid];
+        pr *= tau;
+      }
+      w[tid] = pr;  // p for now
+      pv = pr * v[tid];
+    }
+    for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o, 64);
+    if (lane == 0 && wave < 2) red[2 + wave] = pv;
+    __syncthreads();
+    if (tid < TT_MAX) {
+      const double a2 = -0.5 * tau * (red[2] + red[3]);
+      w[tid] += a2 * v[tid];
+    }
+    __syncthreads();
+    // S22 -= v w^T + w v^T
+    if (r >= k1 && r < m) {
+      const double vr = v[r], wr = w[r];
+      for (int c = k1 + ((cg - k1) % TT_CG + TT_CG) % TT_CG; c < m; c += TT_CG) S[c * TT_LD + r] -= vr * w[c] + wr * v[c];
+    }
+    __syncthreads();
+  }
+  // the last 2 x 2 block goes back to the matrix for k_trdb_finish
+  if (tid < 4) {
+    const int rr = m - 2 + (tid & 1), cc = m - 2 + (tid >> 1);
+    A[(size_t)(j0 + cc) * n + j0 + rr] = S[cc * TT_LD + rr];
+  }
+}
+
 // d, e of the last 2x2 block (after the final trailing update)
 __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
   const TrdBatch &b = *bp;
@@ -994,7 +1096,14 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     w.ptasks.upload(pt, s);
     HFG_HIP_CHECK(hipStreamSynchronize(s));  // pt lives on this stack frame
   }
-  for (int j0 = 0; j0 <= nmax - 3; j0 += TB_NB) {
+  // LDS-resident tail (k_trd_tail) from the first panel boundary where every trailing matrix has order <= TT_MAX
+  static const bool no_tail = (getenv("HELFEM_TRD_TAIL") && atoi(getenv("HELFEM_TRD_TAIL")) == 0);
+  int j_tail = nmax;  // no tail
+  if (fused && !no_tail && nmax >= 3) {
+    j_tail = std::max(0, ((nmax - TT_MAX + TB_NB - 1) / TB_NB) * TB_NB);
+    if (nmax - j_tail < 3) j_tail = nmax;
+  }
+  for (int j0 = 0; j0 <= nmax - 3 && j0 < j_tail; j0 += TB_NB) {
     if (fused) {
       const int jend = std::min(j0 + TB_NB, nmax - 2);
       // symmetric sweep (lower tiles only) for the panels whose full grid would not fit the chip in one round
@@ -1060,6 +1169,15 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
       gemm_dev(ctx, false, true, mt, mt, ncols, -1.0, w.V[k].p + (size_t)n * TB_NB + j1, n, w.V[k].p + j1, n, 1.0, A22, n);
     }
   }
+  if (j_tail < nmax) {
+    const size_t sht = (size_t)(TT_MAX * TT_LD + 2 * TT_MAX + TT_CG * TT_MAX + 32) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_trd_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sht));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_trd_tail, dim3(nblk), dim3(1024), sht, s, db, j_tail);
+  }
   hipLaunchKernelGGL(k_trdb_finish, dim3(nblk), dim3(64), 0, s, db);
   HFG_HIP_CHECK(hipGetLastError());
   w.last_ns.assign(ns, ns + nblk);
@@ -1085,7 +1203,12 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
   HFG_HIP_CHECK(hipEventCreate(&e1));
   HFG_HIP_CHECK(hipEventRecord(e0, s));
   int count = 0;
-  for (int i = 0; i <= nmax - 3; i++) {
+  int j_tail = nmax;  // the columns of the LDS-resident tail are not launches of this kernel
+  if (w.last_fused && !(getenv("HELFEM_TRD_TAIL") && atoi(getenv("HELFEM_TRD_TAIL")) == 0) && nmax >= 3) {
+    j_tail = std::max(0, ((nmax - TT_MAX + TB_NB - 1) / TB_NB) * TB_NB);
+    if (nmax - j_tail < 3) j_tail = nmax;
+  }
+  for (int i = 0; i <= nmax - 3 && i < j_tail; i++) {
     const int c = i % TB_NB;
     const int m = nmax - i - 1;
     if (w.last_fused) {
