@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -48,6 +49,21 @@ struct DevBuf {
     if (h.size()) HFG_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   }
 };
+
+// Uploads h into buf unless exactly these bytes are already there: the launch descriptors and GEMM task lists of the
+// eigensolver are identical from one SCF iteration to the next, and each "upload + stream synchronisation" (the source
+// used to live on the caller's stack) stalled the pipeline for 50-100 us.  The host copy `cache` is the source of the
+// asynchronous copy, so nothing has to be waited for after queuing it; before it is overwritten the stream is drained.
+template <typename T>
+bool upload_cached(DevBuf<T> &buf, std::vector<T> &cache, const std::vector<T> &h, hipStream_t s) {
+  if (buf.p && cache.size() == h.size() && buf.n >= h.size() &&
+      (h.empty() || memcmp((const void *)cache.data(), (const void *)h.data(), h.size() * sizeof(T)) == 0))
+    return false;
+  HFG_HIP_CHECK(hipStreamSynchronize(s));  // an earlier copy may still be reading the old contents of `cache`
+  cache = h;
+  buf.upload(cache, s);
+  return true;
+}
 
 struct ProfEntry {
   double ms = 0.0;
@@ -116,9 +132,11 @@ struct GemmTask {
   int M, N, K, lda, ldb, ldc;
   int tA = 0, tB = 0;  // op(A), op(B) transposed (k_dgemm_tasklist only)
   double alpha = 1.0, beta = 0.0;  // C = alpha op(A) op(B) + beta C (k_dgemm_tasklist only)
-  int sym = 0;  // the product is known to be symmetric (M == N, e.g. X^T (F X)): tiles above the diagonal are skipped and
-                // the tiles below it also store their transpose (k_dgemm_tasklist with beta == 0 only)
+  int sym = 0;  // the product is known to be symmetric (M == N, e.g. X^T (F X)): only the tiles on and below the diagonal
+                // are enumerated and computed (k_dgemm_tasklist with beta == 0), k_mirror_lower fills the rest
+  int pad_ = 0;  // no padding bytes: task lists are compared bytewise (upload_cached)
 };
+static_assert(sizeof(GemmTask) == 80, "GemmTask is compared bytewise: keep it free of padding");
 
 struct ProfScope {
   hfg_ctx *c;

@@ -524,6 +524,8 @@ struct EigWork {
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
   DevBuf<GemmTask> gtasks, bttasks, btslab, btgram;
+  std::vector<GemmTask> h_gtasks, h_bttasks, h_btslab, h_btgram;  // host copies (upload_cached)
+  std::vector<double *> h_btptr;
   DevBuf<double> Vx[MAXB], G[MAXB], T[MAXB], VT[MAXB], Wb[MAXB], Wp[MAXB];
   DevBuf<double *> btptr;
   bool used_dc = true;
@@ -569,7 +571,7 @@ static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, c
     ptrs[nblk + k] = w.G[k].p;
     ptrs[2 * nblk + k] = w.T[k].p;
   }
-  w.btptr.upload(ptrs, s);
+  upload_cached(w.btptr, w.h_btptr, ptrs, s);
   // task lists: [0, P*nblk) Gram, [P*nblk, 2P*nblk) VT = V T, then per block p two lists (W = V^T Z ; Z -= VT W)
   std::vector<GemmTask> t((size_t)(3 + BT_S) * P * nblk);
   for (int p = 0; p < P; p++)
@@ -645,12 +647,12 @@ static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, c
         }
       }
     }
-  w.bttasks.upload(t, s);
+  upload_cached(w.bttasks, w.h_bttasks, t, s);
   std::vector<GemmTask> slab((size_t)P * BT_S * nblk);
   for (int p = 0; p < P; p++)
     for (int sl = 0; sl < BT_S; sl++)
       for (int k = 0; k < nblk; k++) slab[((size_t)p * BT_S + sl) * nblk + k] = t[(((size_t)3 + sl) * P + p) * nblk + k];
-  w.btslab.upload(slab, s);
+  upload_cached(w.btslab, w.h_btslab, slab, s);
   // Gram products split over BT_GS row slabs (one 64 x 64 tile with K ~ n per reflector block kept 66 workgroups busy
   // for 170 us); k_bt_T adds the partial matrices
   std::vector<GemmTask> gram((size_t)BT_GS * P * nblk);
@@ -672,8 +674,7 @@ static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, c
         }
         gram[((size_t)sl * P + p) * nblk + k] = g;
       }
-  w.btgram.upload(gram, s);
-  HFG_HIP_CHECK(hipStreamSynchronize(s));  // ptrs, t, slab and gram live on this stack frame
+  upload_cached(w.btgram, w.h_btgram, gram, s);
 }
 
 static bool bt_use_side() {
@@ -981,8 +982,7 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
       g.C = dBlockBuf + (size_t)ib * slot;
       gt[2 * nb + k] = g;
     }
-    w.gtasks.upload(gt, s);
-    HFG_HIP_CHECK(hipStreamSynchronize(s));  // gt lives on this stack frame
+    upload_cached(w.gtasks, w.h_gtasks, gt, s);
     {
       ProfScope ps(ctx, "eig_reduce");
       for (int k = 0; k < nb; k++) {

@@ -994,6 +994,8 @@ struct TrdWork {
   DevBuf<double> V[TB_MAXB], col[TB_MAXB], normp[TB_MAXB], pp[TB_MAXB], dots[TB_MAXB], cpart[TB_MAXB];
   DevBuf<double> fx[TB_MAXB], fpp[TB_MAXB], fdots[TB_MAXB], fxn2[TB_MAXB], fcp[TB_MAXB];
   DevBuf<GemmTask> ptasks;  // panel updates of the fused variant, [panel][block]
+  std::vector<GemmTask> h_ptasks;  // host copies of what ptasks / desc hold (upload_cached)
+  std::vector<TrdBatch> h_desc;
   bool last_fused = false;
   DevBuf<TrdBatch> desc;
   std::vector<int> last_ns;  // sizes of the last batch (for the measurement replay)
@@ -1019,7 +1021,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
   } else
     wp = it->second;
   TrdWork &w = *wp;
-  TrdBatch b;
+  TrdBatch b{};
   int nmax = 0;
   for (int i = 0; i < nblk; i++) {
     int n = ns[i];
@@ -1055,9 +1057,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     b.fcp[i] = w.fcp[i].p;
   }
   hipStream_t s = ctx->stream;
-  w.desc.resize(1);
-  HFG_HIP_CHECK(hipMemcpyAsync(w.desc.p, &b, sizeof(TrdBatch), hipMemcpyHostToDevice, s));
-  HFG_HIP_CHECK(hipStreamSynchronize(s));  // b lives on this stack frame
+  upload_cached(w.desc, w.h_desc, std::vector<TrdBatch>(1, b), s);
   const TrdBatch *db = w.desc.p;
   size_t shb = (size_t)(nmax + 4 * 128 + 8) * sizeof(double);
   if (shb > 64 * 1024)
@@ -1093,8 +1093,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
         }
         pt[(size_t)pi * nblk + k] = g;
       }
-    w.ptasks.upload(pt, s);
-    HFG_HIP_CHECK(hipStreamSynchronize(s));  // pt lives on this stack frame
+    upload_cached(w.ptasks, w.h_ptasks, pt, s);
   }
   // LDS-resident tail (k_trd_tail) from the first panel boundary where every trailing matrix has order <= TT_MAX
   static const bool no_tail = (getenv("HELFEM_TRD_TAIL") && atoi(getenv("HELFEM_TRD_TAIL")) == 0);
