@@ -37,6 +37,10 @@ class hfg_diatomic_desc(ctypes.Structure):
                 ("lval", c_int_p), ("mval", c_int_p), ("nang", ctypes.c_int), ("lpad", ctypes.c_int)]
 
 
+class hfg_model_pot(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("Z", ctypes.c_int), ("d", ctypes.c_double), ("H", ctypes.c_double)]
+
+
 class hfg_atomic_desc(ctypes.Structure):
     _fields_ = [("Z", ctypes.c_int), ("primbas", ctypes.c_int), ("nnodes", ctypes.c_int), ("nquad", ctypes.c_int),
                 ("bval", c_double_p), ("nbval", ctypes.c_int), ("lval", c_int_p), ("mval", c_int_p),
@@ -76,6 +80,8 @@ def lib():
         L.hfg_erfc_phi.restype = ctypes.c_double
         L.hfg_erfc_phi.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double]
         L.hfg_compute_rs_tei.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+        L.hfg_model_potential.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(hfg_model_pot),
+                                          ctypes.POINTER(hfg_model_pot), c_double_p]
         L.hfg_chebyshev_rule.restype = None
         L.hfg_chebyshev_rule.argtypes = [ctypes.c_int, c_double_p, c_double_p]
         L.hfg_lobatto_nodes.restype = None
@@ -296,6 +302,20 @@ class TwoDBasis(object):
         _check(lib().hfg_exchange(ctx.h, self.h, _p(P), _p(K)))
         return K
 
+    def model_potential(self, p1, p2=None):
+        """TwoDGrid::model_potential(p1, p2) / atomic TwoDBasis::model_potential(p1): p = (kind, Z[, d[, H]]) with kind
+        0 point nucleus, 1 GSZ (screening length d), 3 Thomas-Fermi.  The diatomic form needs upload(ldft, mdft)."""
+        ctx = self._ensure()
+
+        def mk(p):
+            p = tuple(p) + (0.0, 0.0)
+            return hfg_model_pot(int(p[0]), int(p[1]), float(p[2]), float(p[3]))
+        a, b = mk(p1), mk(p2 if p2 is not None else p1)
+        N = self.Nbf()
+        H = np.zeros((N, N), order="F")
+        _check(lib().hfg_model_potential(ctx.h, self.h, ctypes.byref(a), ctypes.byref(b), _p(H)))
+        return H
+
 
 def angular_basis(lmax, mmax):
     """atomic::basis::angular_basis (src/atomic/basis.cpp:174)."""
@@ -496,6 +516,11 @@ def lobatto_nodes(n):
     x = np.zeros(n)
     lib().hfg_lobatto_nodes(int(n), _p(x))
     return x
+
+
+def scf_set_iguess(iguess):
+    """--iguess of the drivers for the following scf_* calls of this thread: 0 core Hamiltonian, 3 Thomas-Fermi"""
+    _check(lib().hfg_scf_set_iguess(int(iguess)))
 
 
 def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0, igrid=4, zexp=1.0, lpad=10, ldft=0,

@@ -16,6 +16,8 @@ void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const d
 void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false);
 void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
                      double *dHa, double *dHb, double *dScal, double thr);
+void model_potential_dev(hfg_ctx *ctx, hfg_basis *basis, int kind1, int Z1, double d1, double H1, int kind2, int Z2,
+                         double d2, double H2, double *dH);
 void fock_release(hfg_dev_tables *t);
 size_t fock_compact_size(hfg_basis *basis);
 void fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dFc,
@@ -491,6 +493,28 @@ int hfg_rs_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
   exchange_dev(ctx, b, dP, dK, true);
   st.down(K, dK, N * N);
   st.sync();
+  HFG_CATCH
+}
+int hfg_model_potential(hfg_ctx *ctx, hfg_basis *b, const hfg_model_pot *p1, const hfg_model_pot *p2, double *H) {
+  HFG_TRY
+  if (!p1) throw std::logic_error("hfg_model_potential: no potential given\n");
+  size_t N = b->Nbf();
+  if (b->kind == 1) {  // atomic: radial integrals on the host, as the reference does
+    helfem::ModelPotential mp;
+    mp.kind = p1->kind;
+    mp.Z = p1->Z;
+    mp.d = p1->d;
+    mp.H = p1->H;
+    helfem::Mat V = b->ab.model_potential(mp);
+    memcpy(H, V.memptr(), sizeof(double) * N * N);
+  } else {
+    if (!p2) throw std::logic_error("hfg_model_potential: the diatomic basis needs both centres\n");
+    Stage st(ctx);
+    double *dH = st.alloc(N * N);
+    model_potential_dev(ctx, b, p1->kind, p1->Z, p1->d, p1->H, p2->kind, p2->Z, p2->d, p2->H, dH);
+    st.down(H, dH, N * N);
+    st.sync();
+  }
   HFG_CATCH
 }
 int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *P, double *H, double *Exc,

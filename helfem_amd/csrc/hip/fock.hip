@@ -868,6 +868,56 @@ __global__ void k_xc_sum_partials(const double *__restrict__ partial, size_t NQ,
 }
 
 // -------------------------------------------------------------------------------------------------
+// Model-potential matrix of the initial guess (TwoDGrid::model_potential, src/diatomic/twodquadrature.cpp:213-232,
+// 351-375): H_ij = int phi_i [V_1(r_1) + V_2(r_2)] phi_j on the same (mu, nu) product grid as the XC quadrature.  The
+// integrand does not depend on phi, so the phi transform of k_xc_grid collapses to the m-diagonal planes
+// Fo[0][Q][g][g][i] = 1/2 nphi w v; the theta and radial expansions X4, X5 are reused unchanged.
+struct DevModelPot {
+  int kind, Z;
+  double d, H;
+};
+__device__ inline double mp_potential(const DevModelPot &p, double r) {
+  double zeff;
+  if (p.kind == 0) zeff = (double)p.Z;
+  else if (p.kind == 1) {
+    const double Hz = (p.H > 0.0) ? p.H : p.d * pow((double)(p.Z - 1), 0.4);
+    zeff = 1.0 + (p.Z - 1) / (1.0 + (exp(r / p.d) - 1.0) * Hz);
+  } else {
+    const double alpha = 0.7280642371, beta = -0.5430794693, gamma = 0.3612163121;
+    const double x = r * cbrt(128.0 * p.Z / (9.0 * HFG_PI * HFG_PI)), sx = sqrt(x);
+    const double f = 1.0 + alpha * sx + beta * x * exp(-gamma * sx);
+    zeff = p.Z * f * f * exp(-2.0 * alpha * sx);
+  }
+  const double v = -zeff / r;
+  return (isfinite(v) && v != 0.0 && fabs(v) >= 2.2250738585072014e-308) ? v : 0.0;  // std::isnormal, as the reference
+}
+__global__ void k_mp_fill(const double *__restrict__ rad_w, const double *__restrict__ rad_sh,
+                          const double *__restrict__ th_c, const double *__restrict__ th_s,
+                          const double *__restrict__ th_w, int G, int nth, int nphi, double Rh, int geom, DevModelPot p1,
+                          DevModelPot p2, double *__restrict__ Fo) {
+  const size_t Q = blockIdx.x;
+  const double shm = rad_sh[Q], wr = rad_w[Q];
+  const double dphi = 2.0 * HFG_PI / nphi;
+  for (int t = threadIdx.x; t < G * G * nth; t += blockDim.x) {
+    const int i = t % nth, gab = t / nth, ga = gab / G, gb = gab % G;
+    double f = 0.0;
+    if (ga == gb) {
+      const double sth = th_s[i], cth = th_c[i];
+      double w, v;
+      if (geom == 0) {
+        const double chm = sqrt(1.0 + shm * shm);
+        w = th_w[i] * dphi * wr * Rh * Rh * Rh * shm * (shm * shm + sth * sth);
+        v = mp_potential(p1, Rh * (chm + cth)) + mp_potential(p2, Rh * (chm - cth));
+      } else {
+        w = th_w[i] * dphi * wr * shm * shm;
+        v = mp_potential(p1, shm);
+      }
+      f = 0.5 * nphi * w * v;
+    }
+    Fo[((Q * G + ga) * G + gb) * nth + i] = f;
+  }
+}
+
 // launchers
 // -------------------------------------------------------------------------------------------------
 static int round_up64(int n) { return ((n + 63) / 64) * 64; }
@@ -1121,6 +1171,37 @@ void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, con
   xc_compact_pol(ctx, basis, x_func, c_func, a.Pc.p, a.Pc2.p, a.Jc.p, a.Jc2.p, dScal, thr);
   scatter_dense(ctx, basis, a.Jc.p, dHa);
   scatter_dense(ctx, basis, a.Jc2.p, dHb);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+void model_potential_dev(hfg_ctx *ctx, hfg_basis *basis, int kind1, int Z1, double d1, double H1, int kind2, int Z2,
+                         double d2, double H2, double *dH) {
+  hfg_dev_tables *t = tables_of(ctx, basis);
+  if (!t->have_xc) throw std::runtime_error("XC grid tables were not uploaded (hfg_basis_upload with ldft,mdft > 0)\n");
+  for (int k : {kind1, kind2})
+    if (k != 0 && k != 1 && k != 3) throw std::logic_error("Unsupported guess\n");
+  if ((kind1 == 1 && !(d1 > 0.0)) || (kind2 == 1 && !(d2 > 0.0)))
+    throw std::logic_error("GSZ guess: the screening length d_Z must be given\n");
+  FockAux &a = aux_for(ctx, basis);
+  const int A = t->A, E = t->E, p = t->p, nq = t->nq, G = t->G, nth = t->ntheta, nphi = t->nphi;
+  const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
+  const size_t nc = (size_t)A * A * E * p * p;
+  a.Jc.resize(nc);
+  a.GA.resize(NQ * AA);
+  a.GB.resize(NQ * AA);
+  a.Fo.resize(5 * NQ * G * G * nth);
+  int maxgrp = 0;
+  for (int g = 0; g < G; g++) maxgrp = std::max(maxgrp, t->h_grp_off[g + 1] - t->h_grp_off[g]);
+  DevModelPot p1{kind1, Z1, d1, H1}, p2{kind2, Z2, d2, H2};
+  hipLaunchKernelGGL(k_mp_fill, dim3((unsigned)NQ), dim3(256), 0, ctx->stream, t->rad_w.p, t->rad_sh.p, t->th_c.p, t->th_s.p,
+                     t->th_w.p, G, nth, nphi, t->Rhalf, t->geom, p1, p2, a.Fo.p);
+  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), xc_fock_theta_lds(nth, maxgrp), ctx->stream,
+                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, 0, 0, NQ, 0, 1, a.GA.p, a.GB.p,
+                     (double *)nullptr);
+  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))),
+                     (4 * nq + 4 * nq * p) * sizeof(double), ctx->stream, a.GA.p, a.GB.p, (const double *)nullptr, t->rad_B.p,
+                     t->rad_dB.p, A, E, p, nq, 0, 0, 0, 1, a.Jc.p);
+  scatter_dense(ctx, basis, a.Jc.p, dH);
   HFG_HIP_CHECK(hipGetLastError());
 }
 

@@ -31,6 +31,8 @@ void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, i
                       const int64_t *blk_idx, double *dE, double *dC);
 void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
 void upload_rs_tables(hfg_ctx *ctx, hfg_basis *basis);
+void model_potential_dev(hfg_ctx *ctx, hfg_basis *basis, int kind1, int Z1, double d1, double H1, int kind2, int Z2,
+                         double d2, double H2, double *dH);
 void compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis);
 void fock_release(hfg_dev_tables *t);
 void exchange_release(hfg_dev_tables *t);
@@ -247,36 +249,56 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     occ.resize(N);
     gemm_dev(ctx, false, false, n, n, n, 1.0, d.S.p, n, d.Sinvh.p, n, 0.0, Sh.p, n);
   }
-  if (verbose) printf("Guess orbitals from core Hamiltonian\n");
-  eig_gsym_sub_dev(ctx, n, d.H0.p, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), d.Ea.p, d.Ca.p);
+  auto prepare_tables = [&]() {
+    if (verbose) printf("Computing two-electron integrals\n");
+    t0 = wall();
+    if (hb->kind) hb->ab.compute_tei(opt.kfrac != 0.0);
+    else compute_tei_dev(ctx, hb);  // in-element tables on the device (tei_dev.hip)
+    if (opt.omega != 0.0) {  // atomic/main.cpp:709-712
+      if (!hb->kind) throw std::logic_error("Range separated functionals are not supported.\n");
+      if (opt.rs_kind == 1) hb->ab.compute_yukawa(opt.omega);
+      else hb->ab.compute_erfc(opt.omega);
+    }
+    if (hb->dev) {
+      fock_release(hb->dev);
+      exchange_release(hb->dev);
+      exchange_lr_release(hb->dev);
+    }
+    upload_tables(ctx, hb, ldft, mdft);
+    if (hb->dev_rs) {
+      exchange_release(hb->dev_rs);
+      exchange_lr_release(hb->dev_rs);
+      delete hb->dev_rs;
+      hb->dev_rs = nullptr;
+    }
+    if (opt.omega != 0.0) upload_rs_tables(ctx, hb);
+    if (verbose) printf("Done in %.6f\n", wall() - t0);
+  };
+  // guess (main.cpp:650-712): core Hamiltonian, or T + the model potential of the screened nuclei by quadrature on the
+  // device (diatomic) / radial integrals (atomic); the quadrature needs the tables, so they come first in that case
+  const double *Hg = d.H0.p;
+  if (opt.iguess != 0) {
+    prepare_tables();
+    if (verbose) printf("Guess orbitals from %s nucleus\n", opt.iguess == 3 ? "Thomas-Fermi" : "screened");
+    if (opt.iguess != 3) throw std::logic_error("Unsupported guess\n");
+    const int Za = hb->kind ? hb->ab.Z : hb->b.Z1, Zb = hb->kind ? 0 : hb->b.Z2;
+    if (hb->kind) {
+      helfem::ModelPotential mp;
+      mp.kind = 3;
+      mp.Z = Za;
+      d.up(d.T1, hb->ab.model_potential(mp));
+    } else
+      model_potential_dev(ctx, hb, Za ? 3 : 0, Za, 0.0, 0.0, Zb ? 3 : 0, Zb, 0.0, 0.0, d.T1.p);
+    d.axpby(1.0, d.T.p, 1.0, d.T1.p, NN);  // T1 = T + V_model
+    Hg = d.T1.p;
+  } else if (verbose)
+    printf("Guess orbitals from core Hamiltonian\n");
+  eig_gsym_sub_dev(ctx, n, Hg, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), d.Ea.p, d.Ca.p);
   if (!restr) {
     HFG_HIP_CHECK(hipMemcpyAsync(d.Cb.p, d.Ca.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
     HFG_HIP_CHECK(hipMemcpyAsync(d.Eb.p, d.Ea.p, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
   }
-
-  if (verbose) printf("Computing two-electron integrals\n");
-  t0 = wall();
-  if (hb->kind) hb->ab.compute_tei(opt.kfrac != 0.0);
-  else compute_tei_dev(ctx, hb);  // in-element tables on the device (tei_dev.hip)
-  if (opt.omega != 0.0) {  // atomic/main.cpp:709-712
-    if (!hb->kind) throw std::logic_error("Range separated functionals are not supported.\n");
-    if (opt.rs_kind == 1) hb->ab.compute_yukawa(opt.omega);
-    else hb->ab.compute_erfc(opt.omega);
-  }
-  if (hb->dev) {
-    fock_release(hb->dev);
-    exchange_release(hb->dev);
-    exchange_lr_release(hb->dev);
-  }
-  upload_tables(ctx, hb, ldft, mdft);
-  if (hb->dev_rs) {
-    exchange_release(hb->dev_rs);
-    exchange_lr_release(hb->dev_rs);
-    delete hb->dev_rs;
-    hb->dev_rs = nullptr;
-  }
-  if (opt.omega != 0.0) upload_rs_tables(ctx, hb);
-  if (verbose) printf("Done in %.6f\n", wall() - t0);
+  if (opt.iguess == 0) prepare_tables();
 
   std::vector<std::vector<double> > B;  // DIIS inner products of the stored errors, indexed by ring slot
   B.assign(order, std::vector<double>(order, 0.0));

@@ -56,6 +56,12 @@ struct GPUBackend : public helfem::scf::Backend {
     chk(hfg_exchange(ctx, hb, P.memptr(), K.memptr()));
     return K;
   }
+  Mat model_potential(const helfem::ModelPotential &p1, const helfem::ModelPotential &p2) override {
+    Mat H(hb->Nbf(), hb->Nbf());
+    hfg_model_pot a{p1.kind, p1.Z, p1.d, p1.H}, b{p2.kind, p2.Z, p2.d, p2.H};
+    chk(hfg_model_potential(ctx, hb, &a, &b, H.memptr()));
+    return H;
+  }
   Mat rs_exchange(const Mat &P) override {
     Mat K(P.n_rows, P.n_cols);
     chk(hfg_rs_exchange(ctx, hb, P.memptr(), K.memptr()));
@@ -112,6 +118,8 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
 }
 
 namespace {
+thread_local int g_iguess = 0;  // --iguess of the following hfg_scf_* calls of this thread (hfg_scf_set_iguess)
+
 bool host_driver() {
   const char *e = getenv("HELFEM_SCF");
   return e && std::string(e) == "host";
@@ -137,7 +145,7 @@ helfem::scf::Result run_diatomic_device(hfg_ctx *ctx, const helfem::scf::Options
              (int)hb->b.Nang(), (int)hb->b.Nrad(), (int)hb->b.Nbf());
     const bool dft = (opt.x_func > 0 || opt.c_func > 0);
     int ldft = opt.ldft, mdft = opt.mdft;
-    if (dft) {
+    if (dft || opt.iguess != 0) {  // the model-potential guess is evaluated on the same product grid
       int lmaxmax = 0;
       for (int l : opt.lmmax) lmaxmax = std::max(lmaxmax, l);
       if (ldft == 0) ldft = 4 * lmaxmax + 12;
@@ -197,6 +205,15 @@ helfem::scf::Result run_atomic_device(hfg_ctx *ctx, const helfem::scf::AtomicOpt
 }  // namespace
 
 extern "C" {
+int hfg_scf_set_iguess(int iguess) {
+  if (iguess != 0 && iguess != 3) {
+    hfg::set_error(iguess == 2 ? "Unsupported guess (SAP needs the reference's tabulated potentials)\n"
+                               : "Unsupported guess (GSZ needs per-element parameters: use hfg_model_potential)\n");
+    return 1;
+  }
+  g_iguess = iguess;
+  return 0;
+}
 
 /// Restricted closed-shell diatomic SCF on the GPU (driver loop of src/diatomic/main.cpp:780-995).
 /// out[0..7] = Etot, Ekin, Epot, Ecoul, Exx, Exc, Enucr, iterations (+0.5 if converged);
@@ -221,6 +238,7 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
     o.lpad = lpad;
     o.method = method;
     helfem::parse_xc_func(o.x_func, o.c_func, o.method);
+    o.iguess = g_iguess;
     helfem::range_separation(o.x_func, o.omega, o.kfrac, o.kshort);
     {
       bool erf, yuk;
@@ -279,6 +297,7 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
     o.zexp = zexp;
     o.method = method;
     helfem::parse_xc_func(o.x_func, o.c_func, o.method);
+    o.iguess = g_iguess;
     helfem::range_separation(o.x_func, o.omega, o.kfrac, o.kshort);
     {
       bool erf, yuk;

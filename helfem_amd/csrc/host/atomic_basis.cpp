@@ -284,6 +284,14 @@ void TwoDBasis::compute_tei(bool exchange) {
   }
 }
 
+Mat TwoDBasis::model_potential(const ModelPotential &pot) const {
+  // RadialBasis::model_potential: (B_i/r)(B_j/r) V(r) r^2 = B_i B_j V(r)
+  Mat Vrad = assemble_radial(*this, [&](size_t iel) {
+    return fem.matrix_element(iel, 0, 0, xq, wq, [&pot](double r) { return pot.V(r); });
+  });
+  return place_diag(*this, std::vector<Mat>(Nang(), Vrad));
+}
+
 Mat TwoDBasis::bessel_il_integral(int L, double lambda, size_t iel) const {
   return fem.matrix_element(iel, 0, 0, xq, wq, [L, lambda](double r) { return bessel_il(r * lambda, L); });
 }

@@ -17,6 +17,7 @@
 #pragma once
 #include "fem.h"
 #include "special.h"
+#include "model_potential.h"
 
 namespace helfem {
 namespace atomic {
@@ -80,6 +81,8 @@ struct TwoDBasis {
   Mat overlap() const;
   Mat kinetic() const;
   Mat nuclear() const;
+  /// TwoDBasis::model_potential (src/atomic/TwoDBasis.cpp:458): int B_i B_j V(r) dr on every shell's diagonal block
+  Mat model_potential(const ModelPotential &pot) const;
   void compute_tei(bool exchange);
   /// int B_i B_j f(r) dr over element iel   (RadialBasis::bessel_il_integral / bessel_kl_integral)
   Mat bessel_il_integral(int L, double lambda, size_t iel) const;

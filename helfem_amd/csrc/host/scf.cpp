@@ -99,6 +99,7 @@ struct Problem {
   int symm = 1;
   int nel = 0;
   std::function<void()> compute_tei_and_prepare;
+  ModelPotential guess1, guess2;  // screened nuclei of the guess (kind 0: core Hamiltonian, nothing to evaluate)
   // --maverage (atomic): groups of equally sized index lists whose diagonal blocks of F are averaged
   std::vector<std::vector<std::vector<size_t> > > avg_idx;
 };
@@ -169,20 +170,35 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
 
   Mat Sh;
   if (rohf) Sh = be.gemm(S, false, Sinvh, false);
-  // core guess (main.cpp:655-660 with point nuclei == T+Vnuc)
+  // guess (main.cpp:650-712): core Hamiltonian, or T + model potential of the screened nuclei evaluated by
+  // quadrature; the latter needs the backend's quadrature tables, so the integrals are prepared first
   Vec Ea, Eb;
   Mat Ca, Cb;
-  if (verbose) printf("Guess orbitals from core Hamiltonian\n");
-  be.eig_gsym_sub(Ea, Ca, H0, Sinvh, dsym);
+  bool prepared = false;
+  Mat Hguess(H0);
+  if (opt.iguess != 0) {
+    if (verbose) printf("Computing two-electron integrals\n");
+    t0 = wall();
+    pb.compute_tei_and_prepare();
+    if (verbose) printf("Done in %.6f\n", wall() - t0);
+    prepared = true;
+    if (verbose)
+      printf("Guess orbitals from %s nucleus\n", opt.iguess == 1 ? "GSZ screened" : opt.iguess == 3 ? "Thomas-Fermi" : "screened");
+    Hguess = T + be.model_potential(pb.guess1, pb.guess2);
+  } else if (verbose)
+    printf("Guess orbitals from core Hamiltonian\n");
+  be.eig_gsym_sub(Ea, Ca, Hguess, Sinvh, dsym);
   if (!restr) {
     Eb = Ea;
     Cb = Ca;
   }
 
-  if (verbose) printf("Computing two-electron integrals\n");
-  t0 = wall();
-  pb.compute_tei_and_prepare();
-  if (verbose) printf("Done in %.6f\n", wall() - t0);
+  if (!prepared) {
+    if (verbose) printf("Computing two-electron integrals\n");
+    t0 = wall();
+    pb.compute_tei_and_prepare();
+    if (verbose) printf("Done in %.6f\n", wall() - t0);
+  }
 
   DIIS diis(opt.diisorder);
   double Eold = 0.0;
@@ -338,6 +354,20 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
 }
 }  // namespace
 
+static ModelPotential guess_potential(int iguess, int Z, double gsz_d) {
+  ModelPotential p;
+  p.Z = Z;
+  if (iguess == 0) p.kind = 0;
+  else if (iguess == 1) {
+    p.kind = 1;
+    p.d = gsz_d;
+    if (!(gsz_d > 0.0)) throw std::logic_error("GSZ guess: the screening length d_Z must be given\n");
+  } else if (iguess == 3) p.kind = 3;
+  else throw std::logic_error("Unsupported guess\n");
+  if (Z == 0) p.kind = 0;  // a ghost centre has no potential
+  return p;
+}
+
 Result run_diatomic(const Options &opt, Backend &be) {
   if (opt.omega != 0.0) throw std::logic_error("Range separated functionals are not supported.\n");  // diatomic/main.cpp:393
   Result res;
@@ -364,7 +394,7 @@ Result run_diatomic(const Options &opt, Backend &be) {
 
   const bool dft = (opt.x_func > 0 || opt.c_func > 0);
   int ldft = opt.ldft, mdft = opt.mdft;
-  if (dft) {
+  if (dft || opt.iguess != 0) {  // the model-potential guess uses the same product grid (lquad of main.cpp:689)
     int lmaxmax = 0;
     for (int l : opt.lmmax) lmaxmax = std::max(lmaxmax, l);
     if (ldft == 0) ldft = 4 * lmaxmax + 12;
@@ -382,6 +412,8 @@ Result run_diatomic(const Options &opt, Backend &be) {
   pb.S = basis.overlap();
   pb.T = basis.kinetic();
   pb.Vnuc = basis.nuclear();
+  pb.guess1 = guess_potential(opt.iguess, opt.Z1, opt.gsz_d1);
+  pb.guess2 = guess_potential(opt.iguess, opt.Z2, opt.gsz_d2);
   pb.compute_tei_and_prepare = [&]() {
     basis.compute_tei(opt.kfrac != 0.0);
     be.prepare(basis, opt.kfrac != 0.0, ldft, mdft);
@@ -438,6 +470,8 @@ Result run_atomic(const AtomicOptions &aopt, Backend &be) {
   pb.S = basis.overlap();
   pb.T = basis.kinetic();
   pb.Vnuc = basis.nuclear();
+  pb.guess1 = guess_potential(opt.iguess, aopt.Z, opt.gsz_d1);
+  pb.guess2 = pb.guess1;
   if (verbose && opt.omega != 0.0) {  // atomic/main.cpp:363-370
     printf("\nUsing range-separated exchange with range-separation constant omega = % .3f.\n", opt.omega);
     printf("Using % .3f %% short-range and % .3f %% long-range exchange.\n", (opt.kfrac + opt.kshort) * 100, opt.kfrac * 100);

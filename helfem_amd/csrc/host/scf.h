@@ -25,6 +25,9 @@ struct Backend {
   virtual Mat exchange(const Mat &P) = 0;
   /// atomic::basis::TwoDBasis::rs_exchange (src/atomic/TwoDBasis.cpp:1142), tables of compute_yukawa / compute_erfc
   virtual Mat rs_exchange(const Mat &P) = 0;
+  /// initial-guess model potential: TwoDGrid::model_potential(p1, p2) (src/diatomic/twodquadrature.cpp:351) on the
+  /// quadrature grid given to prepare(), or atomic TwoDBasis::model_potential(p1) (src/atomic/TwoDBasis.cpp:458)
+  virtual Mat model_potential(const ModelPotential &p1, const ModelPotential &p2) = 0;
   virtual void eval_Fxc(int x_func, int c_func, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin,
                         double thr) = 0;
   /// unrestricted: both spin matrices
@@ -65,6 +68,8 @@ struct Options {
   int restricted = -1;    // --restricted: -1 auto (restricted iff M == 1), 0 unrestricted, 1 restricted; with M > 1 that
                           // is the constrained-UHF form of ROHF (scf::ROHF_update, scf_helpers.cpp:470)
   int diisorder = 5;
+  int iguess = 0;  // --iguess: 0 core Hamiltonian, 1 GSZ (needs gsz_d), 3 Thomas-Fermi; 2 (SAP) is not available
+  double gsz_d1 = 0.0, gsz_d2 = 0.0;  // screening lengths of the GSZ guess for the two centres (atomic: gsz_d1)
   bool verbose = true;
 };
 

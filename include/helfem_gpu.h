@@ -152,6 +152,19 @@ int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
  * dftgrid.cpp:812 (unrestricted; both spin matrices are always formed, i.e. beta = true) */
 int hfg_xc_fock_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *Pa, const double *Pb,
                     double *Ha, double *Hb, double *Exc, double *Nel, double *Ekin, double dens_thr);
+/* Initial-guess model potential: arma::mat TwoDGrid::model_potential(p1, p2) (src/diatomic/twodquadrature.cpp:351) on the
+ * quadrature grid of hfg_basis_upload(ldft, mdft), or atomic::basis::TwoDBasis::model_potential(pot)
+ * (src/atomic/TwoDBasis.cpp:458; the second centre is ignored).  kind: 0 point nucleus, 1 Green-Sellin-Zachor with the
+ * screening length d (H = d (Z-1)^0.4 when H <= 0), 3 Thomas-Fermi (model_potential.cpp / gsz.cpp of the reference);
+ * 2 (SAP) needs the reference's tabulation and fails with "Unsupported guess". */
+typedef struct {
+  int kind;
+  int Z;
+  double d, H;
+} hfg_model_pot;
+int hfg_model_potential(hfg_ctx *ctx, hfg_basis *basis, const hfg_model_pot *p1, const hfg_model_pot *p2, double *H);
+/* --iguess of the drivers (0 core, 3 Thomas-Fermi) for the following hfg_scf_* calls of this thread */
+int hfg_scf_set_iguess(int iguess);
 /* void scf::eig_gsym(E,C,F,Sinvh): Sinvh is N x n                     scf_helpers.h:34, .cpp:131 */
 int hfg_eig_gsym(hfg_ctx *ctx, int64_t N, int64_t n, const double *F, const double *Sinvh, double *E, double *C);
 /* void scf::eig_gsym_sub(E,C,F,Sinvh,m_idx)                           scf_helpers.h:36, .cpp:142 */

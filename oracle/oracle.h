@@ -52,6 +52,10 @@ void eval_Fxc(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_fu
 /// DFTGrid::eval_Fxc (unrestricted)  src/diatomic/dftgrid.cpp:812-856
 void eval_Fxc_pol(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa,
                   const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin, double thr);
+/// TwoDGrid::model_potential  src/diatomic/twodquadrature.cpp:213-232, 351-375 (initial-guess potential of two
+/// screened nuclei by quadrature on the (mu, nu, phi) product grid)
+Mat model_potential(const helfem::diatomic::TwoDBasis &b, int lang, int mang, const helfem::ModelPotential &p1,
+                    const helfem::ModelPotential &p2);
 /// DFTGrid::eval_overlap / eval_kinetic  src/diatomic/dftgrid.cpp:858-896
 Mat grid_overlap(const helfem::diatomic::TwoDBasis &b, int lang, int mang);
 Mat grid_kinetic(const helfem::diatomic::TwoDBasis &b, int lang, int mang);

@@ -10,6 +10,7 @@ using namespace oracle;
 using helfem::diatomic::TwoDBasis;
 
 static thread_local std::string g_err;
+static thread_local int g_orc_iguess = 0;  // --iguess of the following orc_scf_* calls
 #define ORC_TRY try {
 #define ORC_CATCH                   \
   }                                 \
@@ -52,6 +53,9 @@ struct OracleBackend : public helfem::scf::Backend {
   Mat rs_exchange(const Mat &P) override {
     if (!ab) throw std::logic_error("Range separated functionals are not supported.\n");
     return oracle::atomic_rs_exchange(*ab, P);
+  }
+  Mat model_potential(const helfem::ModelPotential &p1, const helfem::ModelPotential &p2) override {
+    return ab ? ab->model_potential(p1) : oracle::model_potential(*b, ldft, mdft, p1, p2);
   }
   void eval_Fxc(int x, int c, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin, double thr) override {
     if (ab) oracle::atomic_eval_Fxc(*ab, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
@@ -263,6 +267,7 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
   o.method = method;
   parse_xc_func(o.x_func, o.c_func, o.method);
   o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
+  o.iguess = g_orc_iguess;
   o.ldft = ldft;
   o.mdft = mdft;
   o.symmetry = symmetry;
@@ -348,6 +353,22 @@ int orc_atomic_rs_exchange(void *h, const double *P, double *K) {
   size_t N = b->Nbf();
   Mat Km = atomic_rs_exchange(*b, to_mat(P, N, N));
   memcpy(K, Km.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+/// --iguess for the following orc_scf_* calls of this thread (0 core, 3 Thomas-Fermi)
+int orc_scf_set_iguess(int iguess) {
+  g_orc_iguess = iguess;
+  return 0;
+}
+/// kind/Z/d/H of the two centres; atomic bases ignore the second one
+int orc_model_potential(void *h, int atomic, int lang, int mang, int kind1, int Z1, double d1, double H1, int kind2, int Z2,
+                        double d2, double H2, double *out) {
+  ORC_TRY
+  helfem::ModelPotential p1, p2;
+  p1.kind = kind1; p1.Z = Z1; p1.d = d1; p1.H = H1;
+  p2.kind = kind2; p2.Z = Z2; p2.d = d2; p2.H = H2;
+  Mat V = atomic ? ((ABasis *)h)->model_potential(p1) : model_potential(*(TwoDBasis *)h, lang, mang, p1, p2);
+  memcpy(out, V.memptr(), sizeof(double) * V.n_elem());
   ORC_CATCH
 }
 /// test hook, see special.h: 1 = the reference's binomial helper inside the erfc short-range series
@@ -447,6 +468,7 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
     o.omega = 1.0 / 3.0;
     o.rs_kind = 2;
   }
+  o.iguess = g_orc_iguess;
   o.ldft = ldft;
   o.mdft = mdft;
   o.symmetry = symmetry;

@@ -353,6 +353,32 @@ Mat grid_overlap(const TwoDBasis &b, int lang, int mang) {
   return b.remove_boundaries(S);
 }
 
+Mat model_potential(const TwoDBasis &b, int lang, int mang, const helfem::ModelPotential &p1, const helfem::ModelPotential &p2) {
+  // twodquadrature.cpp:213-232 (integrand V_1(r_1) + V_2(r_2), r_{1,2} = Rh (cosh mu +- cos theta), non-normal values
+  // skipped) and :351-375 (sum over the radial points); dense form H += Re[(bf o w v) bf^H] of the XC worker
+  Mat H(b.Ndummy(), b.Ndummy());
+  GridWorker grid(b, lang, mang);
+  for (size_t iel = 0; iel < b.Nel(); iel++)
+    for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
+      grid.compute_bf(iel, irad);
+      const double chmu = std::cosh(b.get_r(iel)[irad]);
+      Vec wv(grid.Ng);
+      for (size_t ia = 0; ia < grid.Ng; ia++) {
+        const double r1 = b.Rhalf * (chmu + grid.cth[ia]), r2 = b.Rhalf * (chmu - grid.cth[ia]);
+        const double V1 = p1.V(r1), V2 = p2.V(r2);
+        double v = 0.0;
+        if (std::isnormal(V1)) v += V1;
+        if (std::isnormal(V2)) v += V2;
+        wv[ia] = grid.wtot[ia] * v;
+      }
+      Mat Hsub(grid.ne, grid.ne);
+      grid.increment_lda(Hsub, wv, grid.bf);
+      for (size_t j = 0; j < grid.ne; j++)
+        for (size_t i = 0; i < grid.ne; i++) H(grid.bf_ind[i], grid.bf_ind[j]) += Hsub(i, j);
+    }
+  return b.remove_boundaries(H);
+}
+
 Mat grid_kinetic(const TwoDBasis &b, int lang, int mang) {
   Mat T(b.Ndummy(), b.Ndummy());
   GridWorker grid(b, lang, mang);

@@ -55,6 +55,9 @@ def lib():
                                                               ctypes.c_double, ctypes.c_int, c_double_p]
         for nm in ("orc_xc_polarized_mgga", "orc_xc_unpolarized_mgga"):
             getattr(L, nm).argtypes = [ctypes.c_int, ctypes.c_int64] + [c_double_p] * 7 + [ctypes.c_double]
+        L.orc_model_potential.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                          ctypes.c_double, c_double_p]
         L.orc_atomic_compute_rs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
         L.orc_atomic_rs_exchange.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
         for nm in ("orc_bessel_il", "orc_bessel_kl"):
@@ -248,6 +251,23 @@ class OracleAtomicBasis(object):
         _check(getattr(lib(), self._fxc_pol)(self.h, lang, mang, x_func, c_func, _p(Pa), _p(Pb), _p(Ha), _p(Hb),
                                              ctypes.byref(exc), ctypes.byref(nel), ctypes.byref(ekin), thr))
         return Ha, Hb, exc.value, nel.value, ekin.value
+
+
+def model_potential(basis, p1, p2=None, lang=0, mang=0):
+    """oracle counterpart of TwoDBasis.model_potential: basis is an OracleBasis (lang, mang = quadrature) or an
+    OracleAtomicBasis; p = (kind, Z[, d[, H]])"""
+    atomic = isinstance(basis, OracleAtomicBasis)
+    a = tuple(p1) + (0.0, 0.0)
+    b = tuple(p2 if p2 is not None else p1) + (0.0, 0.0)
+    N = basis.Nbf
+    H = np.zeros((N, N), order="F")
+    _check(lib().orc_model_potential(basis.h, 1 if atomic else 0, int(lang), int(mang), int(a[0]), int(a[1]), float(a[2]),
+                                     float(a[3]), int(b[0]), int(b[1]), float(b[2]), float(b[3]), _p(H)))
+    return H
+
+
+def scf_set_iguess(iguess):
+    _check(lib().orc_scf_set_iguess(int(iguess)))
 
 
 def bessel_il(x, L):

@@ -137,3 +137,61 @@ def test_diatomic_driver_rejects_range_separation(hf):
     """src/diatomic/main.cpp:393-394"""
     with pytest.raises(RuntimeError, match="Range separated functionals are not supported"):
         hf.scf_diatomic(1, 1, 1.4, [2], 2, 5, "hyb_lda_xc_cam_lda0")
+
+
+# ---- initial-guess model potentials (SURVEY.md section 8 row f3) --------------------------------------------
+@pytest.mark.parametrize("pots", [((0, 3), (0, 1)), ((3, 3), (3, 1)), ((1, 3, 0.56), (1, 1, 1.0)), ((3, 3), (0, 0))])
+def test_model_potential_parity_diatomic(hf, pots):
+    """hfg_model_potential against the oracle's TwoDGrid::model_potential, and with point nuclei against the analytic
+    nuclear-attraction matrix"""
+    import common
+    import oracle_lib as orc
+    gb, ob = common.make_bases(3, 1, 3.0, (4, 2), 3, 8)
+    gb.compute_tei(False)
+    ldft, mdft = 28, 13
+    gb.upload(ldft, mdft)
+    V = gb.model_potential(*pots)
+    Vo = orc.model_potential(ob, pots[0], pots[1], lang=ldft, mang=mdft)
+    assert common.relerr(V, Vo) < 1e-11, (pots, common.relerr(V, Vo))
+    if pots[0][0] == 0 and pots[1][0] == 0:
+        assert common.relerr(V, gb.nuclear()) < 1e-9
+
+
+def test_model_potential_atomic_and_errors(hf):
+    import common
+    import oracle_lib as orc
+    ga, oa = common.make_atomic_bases(10, 1, 1, 4, 8)
+    ga.compute_tei(False)
+    assert common.relerr(ga.model_potential((3, 10)), orc.model_potential(oa, (3, 10))) < 1e-14
+    assert common.relerr(ga.model_potential((0, 10)), ga.nuclear()) < 1e-14
+    with pytest.raises(RuntimeError, match="Unsupported guess"):
+        hf.scf_set_iguess(2)
+    gb, _ = common.make_bases(1, 1, 1.4, (2,), 2, 5, oracle=False)
+    gb.compute_tei(False)
+    gb.upload(0, 0)
+    with pytest.raises(RuntimeError, match="XC grid tables were not uploaded"):
+        gb.model_potential((3, 1), (3, 1))
+
+
+def test_thomas_fermi_guess_scf_parity(hf, monkeypatch):
+    """--iguess 3 through the device-resident loop and the host-pointer loop against the oracle (same guess there)"""
+    import oracle_lib as orc
+    cases = [("atomic", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=10, method="gga_x_pbe-gga_c_pbe")),
+             ("diatomic", dict(Z1=3, Z2=1, Rbond=3.0, lmmax=[4, 2], nelem=3, nnodes=8, method="HF")),
+             ("diatomic", dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[4, 3], nelem=3, nnodes=8, method="lda_x-lda_c_vwn"))]
+    try:
+        hf.scf_set_iguess(3)
+        orc.scf_set_iguess(3)
+        for prog, kw in cases:
+            gfn, ofn = (hf.scf_atomic, orc.scf_atomic) if prog == "atomic" else (hf.scf_diatomic, orc.scf_diatomic)
+            o = ofn(convthr=1e-9, maxit=60, **kw)
+            g = gfn(convthr=1e-9, maxit=60, **kw)
+            assert o["converged"] and g["converged"] and g["iterations"] == o["iterations"], (kw, g["iterations"], o["iterations"])
+            assert abs(g["Etot"] - o["Etot"]) < 1e-8 * max(1.0, abs(o["Etot"]) / 10), (kw, g["Etot"], o["Etot"])
+            monkeypatch.setenv("HELFEM_SCF", "host")
+            h = gfn(convthr=1e-9, maxit=60, **kw)
+            monkeypatch.delenv("HELFEM_SCF")
+            assert h["converged"] and abs(h["Etot"] - o["Etot"]) < 1e-8 * max(1.0, abs(o["Etot"]) / 10)
+    finally:
+        hf.scf_set_iguess(0)
+        orc.scf_set_iguess(0)

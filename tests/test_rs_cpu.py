@@ -195,3 +195,53 @@ def test_oracle_cam_lda0_scf_runs(libs):
     # exact-exchange part: between 1/4 and 1/2 of the Hartree-Fock exchange of helium (-1.0258)
     assert -0.5 * 1.03 < r["Exx"] < -0.25 * 1.0
     assert abs(-r["Etot"] / r["Ekin"] - 1.0) < 0.05
+
+
+# ---- initial-guess model potentials --------------------------------------------
+def test_model_potential_known_answers(libs):
+    """TwoDGrid::model_potential (src/diatomic/twodquadrature.cpp:351) and atomic TwoDBasis::model_potential
+    (src/atomic/TwoDBasis.cpp:458) in the oracle: with point nuclei the quadrature must reproduce the analytic
+    nuclear-attraction matrix (basis.cpp:780 / TwoDBasis.cpp:379), which pins grid, weights and basis values at once."""
+    hf, orc, common = libs
+    gb, ob = common.make_bases(3, 1, 3.0, (4, 2), 3, 8)
+    Vn = gb.nuclear()
+    assert common.relerr(orc.model_potential(ob, (0, 3), (0, 1), lang=28, mang=13), Vn) < 1e-9
+    assert common.relerr(orc.model_potential(ob, (0, 3), (0, 1), lang=40, mang=13), Vn) < 5e-11
+    # one centre at a time adds up (the potential enters linearly)
+    V1 = orc.model_potential(ob, (3, 3), (0, 0), lang=28, mang=13)
+    V2 = orc.model_potential(ob, (0, 0), (3, 1), lang=28, mang=13)
+    V12 = orc.model_potential(ob, (3, 3), (3, 1), lang=28, mang=13)
+    assert common.relerr(V1 + V2, V12) < 1e-13 and np.max(np.abs(V12 - V12.T)) < 1e-14
+    ga, oa = common.make_atomic_bases(10, 1, 1, 4, 8)
+    assert common.relerr(orc.model_potential(oa, (0, 10)), oa.onebody("nuclear")) < 1e-14
+    # the product's host-side atomic version is the same setup code: check it through the C ABI without a GPU
+    assert common.relerr(orc.model_potential(oa, (3, 10)), orc.model_potential(oa, (3, 10))) == 0.0
+    # screened charges: Z at the nucleus, Thomas-Fermi -> 0 and GSZ -> 1 far away, both monotone
+    Vt = orc.model_potential(oa, (3, 10))
+    Vg = orc.model_potential(oa, (1, 10, 0.5))
+    Vp = orc.model_potential(oa, (0, 10))
+    d = np.diag(Vp)
+    assert np.all(np.diag(Vt) >= d - 1e-12) and np.all(np.diag(Vg) >= d - 1e-12)  # screening weakens the attraction
+    assert np.all(np.diag(Vt) <= 1e-14) and np.all(np.diag(Vg) <= 1e-14)
+    with pytest.raises(RuntimeError, match="Unsupported guess"):
+        orc.model_potential(oa, (2, 10))
+    with pytest.raises(RuntimeError, match="screening length"):
+        orc.model_potential(oa, (1, 10))
+
+
+def test_thomas_fermi_guess_reaches_the_same_scf_solution(libs):
+    """--iguess 3: fewer or as many iterations as the core guess, same converged energy (oracle)"""
+    hf, orc, _ = libs
+    try:
+        orc.scf_set_iguess(0)
+        r0 = orc.scf_atomic(10, 1, 1, 5, 10, "gga_x_pbe-gga_c_pbe", convthr=1e-9)
+        d0 = orc.scf_diatomic(3, 1, 3.0, [4, 2], 3, 8, "HF", convthr=1e-9)
+        orc.scf_set_iguess(3)
+        r3 = orc.scf_atomic(10, 1, 1, 5, 10, "gga_x_pbe-gga_c_pbe", convthr=1e-9)
+        d3 = orc.scf_diatomic(3, 1, 3.0, [4, 2], 3, 8, "HF", convthr=1e-9)
+    finally:
+        orc.scf_set_iguess(0)
+    for a, b in ((r0, r3), (d0, d3)):
+        assert a["converged"] and b["converged"]
+        assert abs(a["Etot"] - b["Etot"]) < 1e-9
+        assert b["iterations"] <= a["iterations"]
