@@ -23,7 +23,7 @@
 
 namespace hfg {
 
-constexpr int DC_LEAF = 32;
+constexpr int DC_LEAF = 16;  // measured at 3 x n ~ 1400: 32 -> 1.96 ms, 16 -> 1.81 ms, 8 -> 1.85 ms for the whole stage
 constexpr int DC_MAXB = 8;
 #define DC_EPS 2.220446049250313e-16
 
@@ -41,6 +41,7 @@ struct DCBatch {
   double *Ds[DC_MAXB], *zs[DC_MAXB], *dnd[DC_MAXB], *znd[DC_MAXB], *mu[DC_MAXB], *lam[DC_MAXB], *zhat[DC_MAXB];
   double *rotc[DC_MAXB], *rots[DC_MAXB];
   int *src[DC_MAXB], *flag[DC_MAXB], *nd[DC_MAXB], *org[DC_MAXB], *roti[DC_MAXB], *rotj[DC_MAXB], *rank[DC_MAXB];
+  int *ndpos[DC_MAXB];  // position of a non-deflated sorted slot in the nd list (written by k_dc_prepare for k_dc_rank)
 };
 
 // ---- tear ------------------------------------------------------------------------------------------
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
   }
   for (int c = threadIdx.x; c < k; c += blockDim.x) {
     int sidx = snd[c];
+    b.ndpos[blk][lo + sidx] = c;
     b.nd[blk][lo + c] = sidx;
     b.dnd[blk][lo + c] = sD[sidx];
     b.znd[blk][lo + c] = sz[sidx];
@@ -489,23 +491,10 @@ __global__ __launch_bounds__(256) void k_dc_rank(DCBatch b, const DCNode *__rest
   const DCNode nd = nodes[ni];
   const int blk = nd.blk, lo = nd.lo, n = nd.hi - nd.lo;
   if ((int)blockIdx.y * 256 >= n) return;
-  const int k = kcount[ni];
-  // value of sorted slot s: the new root if s is non-deflated (position c in the nd list), else the deflated Ds[s]
-  const int *ndl = b.nd[blk] + lo;
+  // value of sorted slot s: the new root if s is non-deflated (position ndpos[s] in the nd list), else the deflated Ds[s]
   const int *flag = b.flag[blk] + lo;
   for (int s = threadIdx.x; s < n; s += blockDim.x) {
-    double v;
-    if (flag[s]) v = b.Ds[blk][lo + s];
-    else {
-      int a = 0, c = k;  // nd list is increasing: find a with ndl[a] == s
-      while (a < c) {
-        int h = (a + c) >> 1;
-        if (ndl[h] < s) a = h + 1;
-        else c = h;
-      }
-      v = b.lam[blk][lo + a];
-    }
-    sh[s] = v;
+    sh[s] = flag[s] ? b.Ds[blk][lo + s] : b.lam[blk][lo + b.ndpos[blk][lo + s]];
   }
   __syncthreads();
   const int s = blockIdx.y * 256 + threadIdx.x;
@@ -727,7 +716,7 @@ void tridiag_dc_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, d
     w.Qg[i].resize(nn);
     w.Qn[i].resize(nn);
     w.vec[i].resize((size_t)9 * n);
-    w.ivec[i].resize((size_t)7 * n);
+    w.ivec[i].resize((size_t)8 * n);
     b.n[i] = n;
     b.d[i] = d[i];
     b.d2[i] = w.d2[i].p;
@@ -755,6 +744,7 @@ void tridiag_dc_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, d
     b.roti[i] = iv + 4 * n;
     b.rotj[i] = iv + 5 * n;
     b.rank[i] = iv + 6 * n;
+    b.ndpos[i] = iv + 7 * n;
     HFG_HIP_CHECK(hipMemsetAsync(Z[i], 0, sizeof(double) * nn, s));
   }
   HFG_HIP_CHECK(hipMemsetAsync(w.status.p, 0, sizeof(int) * 4, s));
