@@ -469,16 +469,49 @@ __global__ void k_bt_extract(EigBatch b, double *const *__restrict__ Vx) {
   Vx[blk][(size_t)j * n + g] = v;
 }
 
-// W = sum of the split-K partial products (S slabs of ldw x n each, only the first kb rows are used)
-__global__ void k_bt_wsum(EigBatch b, double *const *__restrict__ Wpart, double *const *__restrict__ W, int S) {
+// Two consecutive reflector blocks are applied in one pass over Z:  Q_p Q_{p+1} Z = Z - [VT_p | VT_{p+1}] [W0; W1] with
+//   W1 = V_{p+1}^T Z,   W0 = V_p^T Z - (V_p^T VT_{p+1}) W1.
+// The split-K product delivers S = [V_p | V_{p+1}]^T Z in BT_S slabs (2 BT_KB x n each, ld 2 BT_KB); this kernel adds the
+// slabs and applies the coupling C = V_p^T VT_{p+1} (itself the sum of BT_GS partial products).  Workgroup = 4 columns.
+constexpr int BT_PW = 2 * BT_KB;  // rows of the pair's W
+__global__ __launch_bounds__(256) void k_bt_wpair(EigBatch b, double *const *__restrict__ Wpart, double *const *__restrict__ W,
+                                                  double *const *__restrict__ Cc, int S, int GS, int npair, int pair,
+                                                  int kb1_ofblk0) {
+  __shared__ double sC[BT_KB][BT_KB + 1];
+  __shared__ double s1[4][BT_KB];
   const int blk = blockIdx.y;
   const int n = b.n[blk];
-  const size_t tot = (size_t)BT_KB * n;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
-    double a = 0.0;
-    for (int k = 0; k < S; k++) a += Wpart[blk][(size_t)k * tot + t];
-    W[blk][t] = a;
+  const int j0 = pair * BT_PW;
+  if (j0 > n - 3) return;
+  const int kb1 = min(BT_KB, n - 2 - (j0 + BT_KB));  // reflectors of the pair's second block (<= 0: there is none)
+  (void)kb1_ofblk0;
+  const int tid = threadIdx.x, cl = tid >> 6, i = tid & 63;
+  if (kb1 > 0) {
+    for (int t = tid; t < BT_KB * BT_KB; t += 256) {
+      double c = 0.0;
+      for (int sl = 0; sl < GS; sl++) c += Cc[blk][((size_t)sl * npair + pair) * BT_KB * BT_KB + t];
+      sC[t % BT_KB][t / BT_KB] = c;  // C is column-major, ld BT_KB: element (row t % KB, col t / KB)
+    }
   }
+  const int col = blockIdx.x * 4 + cl;
+  const size_t tot = (size_t)BT_PW * n;
+  double a0 = 0.0, a1 = 0.0;
+  if (col < n) {
+    for (int sl = 0; sl < S; sl++) {
+      a0 += Wpart[blk][(size_t)sl * tot + (size_t)col * BT_PW + i];
+      a1 += Wpart[blk][(size_t)sl * tot + (size_t)col * BT_PW + BT_KB + i];
+    }
+  }
+  s1[cl][i] = (kb1 > 0 && i < kb1) ? a1 : 0.0;
+  __syncthreads();
+  if (col >= n) return;
+  if (kb1 > 0) {
+    double corr = 0.0;
+    for (int j = 0; j < kb1; j++) corr += sC[i][j] * s1[cl][j];
+    a0 -= corr;
+  }
+  W[blk][(size_t)col * BT_PW + i] = a0;
+  W[blk][(size_t)col * BT_PW + BT_KB + i] = (kb1 > 0 && i < kb1) ? a1 : 0.0;
 }
 
 // T_p from the Gram matrix G_p = V_p^T V_p and tau (one workgroup per block p of one matrix):
@@ -523,10 +556,10 @@ struct EigWork {
   DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
-  DevBuf<GemmTask> gtasks, bttasks, btslab, btgram;
-  std::vector<GemmTask> h_gtasks, h_bttasks, h_btslab, h_btgram;  // host copies (upload_cached)
+  DevBuf<GemmTask> gtasks, bttasks, btslab, btgram, btcpl, btupd;
+  std::vector<GemmTask> h_gtasks, h_bttasks, h_btslab, h_btgram, h_btcpl, h_btupd;  // host copies (upload_cached)
   std::vector<double *> h_btptr;
-  DevBuf<double> Vx[MAXB], G[MAXB], T[MAXB], VT[MAXB], Wb[MAXB], Wp[MAXB];
+  DevBuf<double> Vx[MAXB], G[MAXB], T[MAXB], VT[MAXB], Wb[MAXB], Wp[MAXB], Cc[MAXB];
   DevBuf<double *> btptr;
   bool used_dc = true;
 };
@@ -555,126 +588,129 @@ void eig_release(hfg_ctx *ctx) {
 static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, const int *ns, int nmax) {
   hipStream_t s = ctx->stream;
   const int P = (nmax - 3) / BT_KB + 1;  // reflector blocks of the largest matrix
-  constexpr int BT_S = 6;                // split-K slabs of the skinny product W = V^T Z (few tiles, long K otherwise)
-  std::vector<double *> ptrs(5 * (size_t)nblk);
+  const int NP = (P + 1) / 2;            // pairs of blocks, applied together (k_bt_wpair)
+  constexpr int BT_S = 6;                // split-K slabs of the skinny product S = [V_p | V_p+1]^T Z
+  std::vector<double *> ptrs(6 * (size_t)nblk);
   for (int k = 0; k < nblk; k++) {
     const int n = ns[k];
     w.Vx[k].resize((size_t)n * n);
     w.G[k].resize((size_t)BT_GS * P * BT_KB * BT_KB);
     w.T[k].resize((size_t)P * BT_KB * BT_KB);
     w.VT[k].resize((size_t)n * P * BT_KB);
-    w.Wb[k].resize((size_t)BT_KB * n);
-    w.Wp[k].resize((size_t)BT_S * BT_KB * n);
-    ptrs[3 * nblk + k] = w.Wp[k].p;
-    ptrs[4 * nblk + k] = w.Wb[k].p;
+    w.Wb[k].resize((size_t)BT_PW * n);
+    w.Wp[k].resize((size_t)BT_S * BT_PW * n);
+    w.Cc[k].resize((size_t)BT_GS * NP * BT_KB * BT_KB);
     ptrs[k] = w.Vx[k].p;
     ptrs[nblk + k] = w.G[k].p;
     ptrs[2 * nblk + k] = w.T[k].p;
+    ptrs[3 * nblk + k] = w.Wp[k].p;
+    ptrs[4 * nblk + k] = w.Wb[k].p;
+    ptrs[5 * nblk + k] = w.Cc[k].p;
   }
   upload_cached(w.btptr, w.h_btptr, ptrs, s);
-  // task lists: [0, P*nblk) Gram, [P*nblk, 2P*nblk) VT = V T, then per block p two lists (W = V^T Z ; Z -= VT W)
-  std::vector<GemmTask> t((size_t)(3 + BT_S) * P * nblk);
+  GemmTask none;  // inactive
+  none.A = none.B = nullptr;
+  none.C = nullptr;
+  none.M = none.N = none.K = 0;
+  none.lda = none.ldb = none.ldc = 1;
+  auto kb_of = [&](int k, int p) { return std::max(0, std::min(BT_KB, ns[k] - 2 - p * BT_KB)); };
+  auto chunk_of = [](int len, int parts) { return ((len + parts - 1) / parts + 15) / 16 * 16; };
+
+  // ---- per block p: Gram products (split over BT_GS row slabs) and VT = V T.  The VT columns of an odd block are
+  //      formed from the first row of its PAIR on (V is zero there), so that [VT_p | VT_p+1] is one operand ----
+  std::vector<GemmTask> gram((size_t)BT_GS * P * nblk, none), vt((size_t)P * nblk, none);
   for (int p = 0; p < P; p++)
     for (int k = 0; k < nblk; k++) {
-      const int n = ns[k], j0 = p * BT_KB;
-      const int kb = std::min(BT_KB, n - 2 - j0);
-      GemmTask g;  // inactive by default
-      g.A = g.B = nullptr;
-      g.C = nullptr;
-      g.M = g.N = g.K = 0;
-      g.lda = g.ldb = g.ldc = 1;
-      GemmTask gram = g, vt = g, wz = g, upd = g;
-      if (kb > 0) {
-        const int r0 = j0 + 1;  // first row where the block's reflectors are non-zero
-        const int mr = n - r0;
-        const double *Vp = w.Vx[k].p + (size_t)j0 * n + r0;
-        gram.A = Vp;
-        gram.B = Vp;
-        gram.C = w.G[k].p + (size_t)p * BT_KB * BT_KB;
-        gram.tA = 1;
-        gram.M = gram.N = kb;
-        gram.K = mr;
-        gram.lda = gram.ldb = n;
-        gram.ldc = BT_KB;
-        vt.A = Vp;
-        vt.B = w.T[k].p + (size_t)p * BT_KB * BT_KB;
-        vt.C = w.VT[k].p + (size_t)j0 * n + r0;
-        vt.M = mr;
-        vt.N = vt.K = kb;
-        vt.lda = n;
-        vt.ldb = BT_KB;
-        vt.ldc = n;
-        wz.tA = 1;
-        wz.M = kb;
-        wz.N = n;
-        wz.lda = n;
-        wz.ldb = n;
-        wz.ldc = BT_KB;
-        upd.A = w.VT[k].p + (size_t)j0 * n + r0;
-        upd.B = w.Wb[k].p;
-        upd.C = b.Z[k] + r0;
-        upd.M = mr;
-        upd.N = n;
-        upd.K = kb;
-        upd.lda = n;
-        upd.ldb = BT_KB;
-        upd.ldc = n;
-        upd.alpha = -1.0;
-        upd.beta = 1.0;
-      }
-      t[(size_t)p * nblk + k] = gram;
-      t[((size_t)P + p) * nblk + k] = vt;
-      t[((size_t)2 * P + p) * nblk + k] = upd;
-      {
-        // split-K slabs of W = V_p^T Z: rows r0 + [sl*chunk, ...)
-        const int mr = (kb > 0) ? n - (j0 + 1) : 0;
-        const int chunk = ((mr + BT_S - 1) / BT_S + 15) / 16 * 16;
-        for (int sl = 0; sl < BT_S; sl++) {
-          GemmTask q = wz;
-          const int k0 = sl * chunk;
-          const int kk = std::max(0, std::min(chunk, mr - k0));
-          q.C = w.Wp[k].p + (size_t)sl * BT_KB * n;
-          if (kb > 0 && kk > 0) {
-            q.A = w.Vx[k].p + (size_t)j0 * n + (j0 + 1) + k0;
-            q.B = b.Z[k] + (j0 + 1) + k0;
-            q.K = kk;
-          } else if (kb > 0) {  // empty slab: its partial must still read as zero -> K = 0 writes alpha*0 + 0
-            q.A = w.Vx[k].p;
-            q.B = b.Z[k];
-            q.K = 0;
-          }
-          t[(((size_t)3 + sl) * P + p) * nblk + k] = q;
-        }
-      }
-    }
-  upload_cached(w.bttasks, w.h_bttasks, t, s);
-  std::vector<GemmTask> slab((size_t)P * BT_S * nblk);
-  for (int p = 0; p < P; p++)
-    for (int sl = 0; sl < BT_S; sl++)
-      for (int k = 0; k < nblk; k++) slab[((size_t)p * BT_S + sl) * nblk + k] = t[(((size_t)3 + sl) * P + p) * nblk + k];
-  upload_cached(w.btslab, w.h_btslab, slab, s);
-  // Gram products split over BT_GS row slabs (one 64 x 64 tile with K ~ n per reflector block kept 66 workgroups busy
-  // for 170 us); k_bt_T adds the partial matrices
-  std::vector<GemmTask> gram((size_t)BT_GS * P * nblk);
-  for (int sl = 0; sl < BT_GS; sl++)
-    for (int p = 0; p < P; p++)
-      for (int k = 0; k < nblk; k++) {
-        GemmTask g = t[(size_t)p * nblk + k];
-        if (g.M > 0) {
-          const int n = ns[k], mr = g.K;
-          const int chunk = ((mr + BT_GS - 1) / BT_GS + 15) / 16 * 16;
-          const int k0 = sl * chunk, kk = std::max(0, std::min(chunk, mr - k0));
-          g.C = w.G[k].p + ((size_t)sl * P + p) * BT_KB * BT_KB;
-          if (kk > 0) {
-            g.A += k0;
-            g.B += k0;
-          }
-          g.K = kk;  // K = 0 writes zeros
-          (void)n;
-        }
+      const int n = ns[k], j0 = p * BT_KB, kb = kb_of(k, p);
+      if (kb <= 0) continue;
+      const int r0 = j0 + 1, mr = n - r0;  // first row where the block's reflectors are non-zero
+      const double *Vp = w.Vx[k].p + (size_t)j0 * n + r0;
+      const int chunk = chunk_of(mr, BT_GS);
+      for (int sl = 0; sl < BT_GS; sl++) {
+        GemmTask g = none;
+        const int k0 = sl * chunk, kk = std::max(0, std::min(chunk, mr - k0));
+        g.A = g.B = Vp + (kk > 0 ? k0 : 0);
+        g.C = w.G[k].p + ((size_t)sl * P + p) * BT_KB * BT_KB;
+        g.tA = 1;
+        g.M = g.N = kb;
+        g.K = kk;  // K = 0 writes zeros
+        g.lda = g.ldb = n;
+        g.ldc = BT_KB;
         gram[((size_t)sl * P + p) * nblk + k] = g;
       }
+      const int rp = (p & ~1) * BT_KB + 1;  // first row of the pair
+      GemmTask g = none;
+      g.A = w.Vx[k].p + (size_t)j0 * n + rp;
+      g.B = w.T[k].p + (size_t)p * BT_KB * BT_KB;
+      g.C = w.VT[k].p + (size_t)j0 * n + rp;
+      g.M = n - rp;
+      g.N = g.K = kb;
+      g.lda = n;
+      g.ldb = BT_KB;
+      g.ldc = n;
+      vt[(size_t)p * nblk + k] = g;
+    }
   upload_cached(w.btgram, w.h_btgram, gram, s);
+  upload_cached(w.bttasks, w.h_bttasks, vt, s);
+
+  // ---- per pair: coupling C = V_p^T VT_p+1 (split over BT_GS slabs), S = [V_p | V_p+1]^T Z (BT_S slabs), the update ----
+  std::vector<GemmTask> cpl((size_t)BT_GS * NP * nblk, none), slab((size_t)NP * BT_S * nblk, none), upd((size_t)NP * nblk, none);
+  for (int g2 = 0; g2 < NP; g2++)
+    for (int k = 0; k < nblk; k++) {
+      const int n = ns[k], p0 = 2 * g2, j0 = p0 * BT_KB;
+      const int kb0 = kb_of(k, p0), kb1 = (p0 + 1 < P) ? kb_of(k, p0 + 1) : 0;
+      if (kb0 <= 0) continue;
+      const int r0 = j0 + 1, mr = n - r0, kbp = kb0 + kb1;
+      if (kb1 > 0) {
+        const int r1 = j0 + BT_KB + 1, m1 = n - r1;  // rows where V_p+1 (and VT_p+1) are non-zero
+        const int chunk = chunk_of(m1, BT_GS);
+        for (int sl = 0; sl < BT_GS; sl++) {
+          GemmTask c = none;
+          const int k0 = sl * chunk, kk = std::max(0, std::min(chunk, m1 - k0));
+          c.A = w.Vx[k].p + (size_t)j0 * n + r1 + (kk > 0 ? k0 : 0);
+          c.B = w.VT[k].p + (size_t)(j0 + BT_KB) * n + r1 + (kk > 0 ? k0 : 0);
+          c.C = w.Cc[k].p + ((size_t)sl * NP + g2) * BT_KB * BT_KB;
+          c.tA = 1;
+          c.M = kb0;
+          c.N = kb1;
+          c.K = kk;
+          c.lda = c.ldb = n;
+          c.ldc = BT_KB;
+          cpl[((size_t)sl * NP + g2) * nblk + k] = c;
+        }
+      }
+      const int chunk = chunk_of(mr, BT_S);
+      for (int sl = 0; sl < BT_S; sl++) {
+        GemmTask q = none;
+        const int k0 = sl * chunk, kk = std::max(0, std::min(chunk, mr - k0));
+        q.A = w.Vx[k].p + (size_t)j0 * n + r0 + (kk > 0 ? k0 : 0);
+        q.B = b.Z[k] + r0 + (kk > 0 ? k0 : 0);
+        q.C = w.Wp[k].p + (size_t)sl * BT_PW * n;
+        q.tA = 1;
+        q.M = kbp;
+        q.N = n;
+        q.K = kk;  // empty slab: K = 0 writes zeros
+        q.lda = q.ldb = n;
+        q.ldc = BT_PW;
+        slab[((size_t)g2 * BT_S + sl) * nblk + k] = q;
+      }
+      GemmTask u = none;
+      u.A = w.VT[k].p + (size_t)j0 * n + r0;
+      u.B = w.Wb[k].p;
+      u.C = b.Z[k] + r0;
+      u.M = mr;
+      u.N = n;
+      u.K = kbp;
+      u.lda = n;
+      u.ldb = BT_PW;
+      u.ldc = n;
+      u.alpha = -1.0;
+      u.beta = 1.0;
+      upd[(size_t)g2 * nblk + k] = u;
+    }
+  upload_cached(w.btcpl, w.h_btcpl, cpl, s);
+  upload_cached(w.btslab, w.h_btslab, slab, s);
+  upload_cached(w.btupd, w.h_btupd, upd, s);
 }
 
 static bool bt_use_side() {
@@ -702,7 +738,8 @@ static void bt_wy_prepare(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk,
     hipLaunchKernelGGL(k_bt_extract, dim3((nmax + 255) / 256, nmax, nblk), dim3(256), 0, q, b, dptr);
     gemm_tasklist64_dev(ctx, w.btgram.p, BT_GS * P * nblk, BT_KB, BT_KB);
     hipLaunchKernelGGL(k_bt_T, dim3(P, nblk), dim3(BT_KB), 0, q, b, dptr + nblk, dptr + 2 * nblk, P);
-    gemm_tasklist64_dev(ctx, w.bttasks.p + (size_t)P * nblk, P * nblk, nmax, BT_KB);
+    gemm_tasklist64_dev(ctx, w.bttasks.p, P * nblk, nmax, BT_KB);
+    gemm_tasklist64_dev(ctx, w.btcpl.p, BT_GS * ((P + 1) / 2) * nblk, BT_KB, BT_KB);
   } catch (...) {
     ctx->stream = main;
     ctx->profiling = prof;
@@ -715,17 +752,19 @@ static void bt_wy_prepare(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk,
 
 static void bt_wy_apply(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, int nmax) {
   hipStream_t s = ctx->stream;
-  const int P = (nmax - 3) / BT_KB + 1;
+  const int P = (nmax - 3) / BT_KB + 1, NP = (P + 1) / 2;
   constexpr int BT_S = 6;
   double *const *dptr = w.btptr.p;
   if (bt_use_side()) HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));
-  for (int p = P - 1; p >= 0; p--) {
-    gemm_tasklist64_dev(ctx, w.btslab.p + (size_t)p * BT_S * nblk, BT_S * nblk, BT_KB, nmax);
+  static const int acc_tile = getenv("HELFEM_ACC_TILE") ? atoi(getenv("HELFEM_ACC_TILE")) : 0;  // A/B runs: 64 or 128
+  // pairs of reflector blocks, last to first: three launches and one read-modify-write of Z per 128 reflectors
+  for (int g = NP - 1; g >= 0; g--) {
+    gemm_tasklist64_dev(ctx, w.btslab.p + (size_t)g * BT_S * nblk, BT_S * nblk, BT_PW, nmax);
     // (summing the slabs inside the update's operand loads instead was measured: 2.73 -> 3.11 ms, six times the operand
     // traffic on every tile's critical path)
-    hipLaunchKernelGGL(k_bt_wsum, dim3(64, nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk, BT_S);
-    static const int acc_tile = getenv("HELFEM_ACC_TILE") ? atoi(getenv("HELFEM_ACC_TILE")) : 0;  // A/B runs: 64 or 128
-    gemm_tasklist_acc_dev(ctx, w.bttasks.p + ((size_t)2 * P + p) * nblk, nblk, nmax, nmax, acc_tile != 128);
+    hipLaunchKernelGGL(k_bt_wpair, dim3((nmax + 3) / 4, nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk,
+                       dptr + 5 * nblk, BT_S, BT_GS, NP, g, 0);
+    gemm_tasklist_acc_dev(ctx, w.btupd.p + (size_t)g * nblk, nblk, nmax, nmax, acc_tile != 128);
   }
   HFG_HIP_CHECK(hipGetLastError());
 }
