@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: Z1, Z2, Rbond, lmmax, nelem, nnodes, method ids (x,c), nocc
     "n2_pbe_nbf4230": dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[20, 20], nelem=5, nnodes=15, x=101, c=130, nocc=7),
+    # BASELINE configs[4] sizing: LiF, lmmax=[29,29], 5 x 15 -> Nang 88, Nbf 6102; symmetry blocks 2100/2001/2001
+    "lif_pbe_nbf6102": dict(Z1=3, Z2=9, Rbond=2.955, lmmax=[29, 29], nelem=5, nnodes=15, x=101, c=130, nocc=6),
     "n2_pbe_small": dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[6, 6], nelem=3, nnodes=8, x=101, c=130, nocc=7),
 }
 
@@ -194,9 +196,11 @@ def main():
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "diatomic N2 R=2.068 PBE, nelem=5 nnodes=15 nquad=75 lmmax=[20,20] (Nbf=%d, "
+            "config": {"workload": "diatomic Z1=%d Z2=%d R=%.3f PBE, nelem=%d nnodes=%d nquad=%d lmmax=%s (Nbf=%d, "
                                    "Nang=%d, Nrad=%d), XC grid %dx%d, symmetry blocks %s: J+XC Fock build + "
-                                   "eig_gsym_sub + density per step" % (N, basis.Nang(), basis.Nrad(), ldft, mdft, sizes),
+                                   "eig_gsym_sub + density per step" % (
+                                       w["Z1"], w["Z2"], w["Rbond"], w["nelem"], w["nnodes"], 5 * w["nnodes"],
+                                       str(w["lmmax"]).replace(" ", ""), N, basis.Nang(), basis.Nrad(), ldft, mdft, sizes),
                        "name": args.workload, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
