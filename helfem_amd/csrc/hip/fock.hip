@@ -476,13 +476,14 @@ __global__ void k_xc_grid(const double *__restrict__ V, const double *__restrict
     }
     double exc = 0.0, vrho = 0.0, vsig = 0.0, vtau = 0.0;
     if (rho >= thr && rho > 0.0) {
+      const bool live = 0.5 * rho >= thr;  // the spin channels of the exchange sum carry rho/2 each
       if (x_func > 0) {
-        if (xc::is_mgga(x_func)) xc::eval_add_mgga(x_func, rho, sigma, tau, exc, vrho, vsig, vtau);
-        else xc::eval_add(x_func, rho, sigma, exc, vrho, vsig);
+        if (xc::is_mgga(x_func)) xc::eval_add_mgga(x_func, rho, sigma, tau, live, exc, vrho, vsig, vtau);
+        else xc::eval_add(x_func, rho, sigma, live, exc, vrho, vsig);
       }
       if (c_func > 0) {
-        if (xc::is_mgga(c_func)) xc::eval_add_mgga(c_func, rho, sigma, tau, exc, vrho, vsig, vtau);
-        else xc::eval_add(c_func, rho, sigma, exc, vrho, vsig);
+        if (xc::is_mgga(c_func)) xc::eval_add_mgga(c_func, rho, sigma, tau, live, exc, vrho, vsig, vtau);
+        else xc::eval_add(c_func, rho, sigma, live, exc, vrho, vsig);
       }
     }
     nel += w * rho;
@@ -651,7 +652,7 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
         const int id = f ? c_func : x_func;
         if (id <= 0) continue;
         if (xc::is_mgga(id)) xc::eval_add_mgga_pol(id, ra, rb, saa, sab, sbb, tau[0], tau[1], rho[0] >= thr, rho[1] >= thr, exc, va, vb, vsaa, vsab, vsbb, vta, vtb);
-        else xc::eval_add_pol(id, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+        else xc::eval_add_pol(id, ra, rb, saa, sab, sbb, rho[0] >= thr, rho[1] >= thr, exc, va, vb, vsaa, vsab, vsbb);
       }
     }
     nel += w * rt;

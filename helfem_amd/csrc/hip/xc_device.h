@@ -172,10 +172,21 @@ __host__ __device__ inline bool is_supported(int id) {
          id == 546 || id == 641 || id == 178;
 }
 
-/// adds functional id's exc (per particle), vrho, vsigma at one point; rho >= threshold assumed
-__host__ __device__ inline void eval_add(int id, double rho, double sigma, double &exc, double &vrho, double &vsigma) {
+__host__ __device__ inline bool is_exchange(int id) { return id == 1 || id == 101 || id == 546 || id == 641 || id == 202; }
+
+/// adds functional id's exc (per particle), vrho, vsigma at one point; rho >= threshold assumed.
+/// live: the density of one spin channel, rho/2, reaches the threshold.  Exchange is a sum over the spin channels and
+/// libxc (>= 5) leaves a channel below the threshold out of it, in the unpolarised evaluation too — which is what makes
+/// the restricted and the unrestricted build agree on a closed shell.
+__host__ __device__ inline void eval_add(int id, double rho, double sigma, bool live, double &exc, double &vrho,
+                                         double &vsigma) {
   Dual r = mk(rho, 1.0, 0.0), s = mk(sigma, 0.0, 1.0);
   Dual e;
+  if (!live) {
+    if (is_exchange(id)) return;
+    if (id == 178) id = 13;   // the hybrids keep their correlation part
+    if (id == 406) id = 130;
+  }
   switch (id) {
     case 1: e = eps_lda_x(r); break;
     case 7: e = eps_lda_c_vwn(r); break;
@@ -392,25 +403,27 @@ __host__ __device__ inline T pol_eps_pbe_c(T n, T rs, T z, T sig) {
 }
 
 /// adds functional id's exc (per particle of ra+rb), vrho[2], vsigma[3] (aa, ab, bb); ra + rb >= threshold assumed,
-/// ra, rb already raised to the threshold
-__host__ __device__ inline void eval_add_pol(int id, double ra, double rb, double saa, double sab, double sbb, double &exc,
-                                             double &va, double &vb, double &vsaa, double &vsab, double &vsbb) {
+/// ra, rb already raised to the threshold; live_a, live_b: the channel's own density reached the threshold (a channel
+/// below it is left out of the exchange sum, as libxc >= 5 does)
+__host__ __device__ inline void eval_add_pol(int id, double ra, double rb, double saa, double sab, double sbb, bool live_a,
+                                             bool live_b, double &exc, double &va, double &vb, double &vsaa, double &vsab,
+                                             double &vsbb) {
   const double rt = ra + rb;
   if (id == 406) {  // hyb_gga_xc_pbeh (PBE0), DFT part: 0.75 gga_x_pbe + gga_c_pbe
     double e = 0.0, a = 0.0, b = 0.0, saa2 = 0.0, sab2 = 0.0, sbb2 = 0.0;
-    eval_add_pol(101, ra, rb, saa, sab, sbb, e, a, b, saa2, sab2, sbb2);
+    eval_add_pol(101, ra, rb, saa, sab, sbb, live_a, live_b, e, a, b, saa2, sab2, sbb2);
     exc += 0.75 * e;
     va += 0.75 * a;
     vb += 0.75 * b;
     vsaa += 0.75 * saa2;
     vsab += 0.75 * sab2;
     vsbb += 0.75 * sbb2;
-    eval_add_pol(130, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+    eval_add_pol(130, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
     return;
   }
   if (id == 178) {  // hyb_lda_xc_cam_lda0, DFT part: spin-scaled exchange mixture + lda_c_pw_mod
-    eval_add_pol(-178, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
-    eval_add_pol(13, ra, rb, saa, sab, sbb, exc, va, vb, vsaa, vsab, vsbb);
+    eval_add_pol(-178, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
+    eval_add_pol(13, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
     return;
   }
   if (id == 1 || id == 101 || id == 546 || id == 641 || id == -178) {
@@ -425,6 +438,8 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
       default: ea = eps_gga_x_pbe(a, sa); eb = eps_gga_x_pbe(b, sb); break;
     }
     Dual na = a * ea, nb = b * eb;  // energy per volume of the doubled densities
+    if (!live_a) na = mk(0.0, 0.0, 0.0);
+    if (!live_b) nb = mk(0.0, 0.0, 0.0);
     exc += 0.5 * (na.v + nb.v) / rt;
     va += na.dr;          // d/d ra [ (1/2) n(2 ra) ] = n'(2 ra)
     vb += nb.dr;
@@ -545,8 +560,9 @@ __host__ __device__ inline T3 mg_eps_tpss_c(T3 rho, T3 sig, T3 tau) {
 __host__ __device__ inline bool is_mgga(int id) { return id == 202 || id == 231; }
 
 /// adds a meta-GGA's exc, vrho, vsigma, vtau at one point (rho >= threshold assumed)
-__host__ __device__ inline void eval_add_mgga(int id, double rho, double sigma, double tau, double &exc, double &vrho,
-                                              double &vsigma, double &vtau) {
+__host__ __device__ inline void eval_add_mgga(int id, double rho, double sigma, double tau, bool live, double &exc,
+                                              double &vrho, double &vsigma, double &vtau) {
+  if (id == 202 && !live) return;  // exchange channel rho/2 below the threshold, see eval_add
   T3 r = t3(rho, 1.0, 0.0, 0.0), s = t3(fmax(sigma, 1e-40), 0.0, 1.0, 0.0), t = t3(fmax(tau, 1e-40), 0.0, 0.0, 1.0);
   T3 e = (id == 202) ? mg_eps_tpss_x(r, s, t) : mg_eps_tpss_c(r, s, t);
   T3 en = r * e;

@@ -186,7 +186,17 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
     double r = rho[i];
     if (!(r >= thr) || r <= 0.0) continue;
     double e = 0, v = 0, vs = 0;
-    switch (id) {
+    // Exchange is a sum over the two spin channels, each carrying r/2; libxc (>= 5) leaves a channel whose density is
+    // below the threshold out of the sum, in the unpolarised evaluation too (its generated code tests
+    // rho/2 <= dens_threshold), so that restricted and unrestricted builds agree on a closed shell.
+    const bool live = 0.5 * r >= thr;
+    int idl = id;
+    if (!live) {
+      if (id == 1 || id == 101 || id == 546 || id == 641) continue;
+      if (id == 178) idl = 13;  // the hybrids keep their correlation part
+      if (id == 406) idl = 130;
+    }
+    switch (idl) {
       case 1: lda_x(r, e, v); break;
       case 7: lda_c_vwn(r, e, v); break;
       case 12: lda_c_pw(r, e, v); break;
@@ -230,7 +240,8 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
 // applied to the hand-derived unpolarised formulas above.  Correlation depends on (rs, zeta, sigma_total);
 // its derivatives are taken with a small forward-mode differentiation type over (rho_a, rho_b, sigma_tot).
 // Densities of one spin channel below the threshold are raised to it (libxc >= 5 does the same before
-// evaluating a polarised functional), which keeps (1 -+ zeta) away from the non-analytic end points.
+// evaluating a polarised functional), which keeps (1 -+ zeta) away from the non-analytic end points; such a
+// channel is left out of the exchange sum (the generated exchange code tests rho_s <= dens_threshold).
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int ND = 7;  // derivative slots: (rho_a, rho_b, sigma_tot) for the GGAs, (rho, sigma, tau) for the unpolarised
@@ -376,6 +387,7 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
     if (vsigma) vsigma[3 * i] = vsigma[3 * i + 1] = vsigma[3 * i + 2] = 0.0;
     double ra = rho[2 * i], rb = rho[2 * i + 1];
     if (!(ra + rb >= thr) || ra + rb <= 0.0) continue;
+    const bool live_a = ra >= thr, live_b = rb >= thr;  // exchange: a channel below the threshold is left out
     ra = std::max(ra, thr);
     rb = std::max(rb, thr);
     const double rt = ra + rb;
@@ -406,6 +418,8 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
           gga_x_pbe(2.0 * ra, 4.0 * saa, ea, va, vsa);
           gga_x_pbe(2.0 * rb, 4.0 * sbb, eb, vb, vsb);
         }
+        if (!live_a) ea = va = vsa = 0.0;
+        if (!live_b) eb = vb = vsb = 0.0;
         exc[i] = (ra * ea + rb * eb) / rt;  // (1/2)(2 ra ea + 2 rb eb) per particle of the total density
         vrho[2 * i] = va;
         vrho[2 * i + 1] = vb;
@@ -592,6 +606,7 @@ void xc_unpolarized_mgga(int id, size_t N, const double *rho, const double *sigm
     exc[i] = vrho[i] = vsigma[i] = vtau[i] = 0.0;
     double r = rho[i];
     if (!(r >= thr) || r <= 0.0) continue;
+    if (id == 202 && !(0.5 * r >= thr)) continue;  // exchange channel r/2 below the threshold, see xc_unpolarized
     D3 R = var(r, 0), S = var(std::max(sigma[i], 1e-40), 1), T = var(std::max(tau[i], 1e-40), 2);
     D3 e = (id == 202) ? eps_tpss_x(R, S, T) : eps_tpss_c(R, S, T);
     D3 en = R * e;

@@ -460,6 +460,40 @@ def test_polarized_functionals_reduce_to_unpolarized_and_match_finite_difference
             assert np.max(np.abs(fd - vs[:, k]) / (np.abs(vs[:, k]) + 1e-8 * np.abs(vs).max())) < 1e-4, (fid, k)
 
 
+@pytest.mark.parametrize("fid", [1, 101, 546, 641, 178, 406, 202])
+def test_exchange_channel_screening_at_the_density_threshold(fid):
+    """libxc (>= 5) leaves a spin channel whose density is below dens_threshold out of the exchange sum, in the
+    unpolarised evaluation (rho/2) as in the polarised one, so that both agree on a closed shell through the whole
+    threshold window; the correlation part of a hybrid survives."""
+    thr = 1e-12
+    rt = np.array([0.5e-12, 1.0e-12, 1.5e-12, 1.99e-12, 2.0e-12, 2.5e-12, 1e-9, 1e-3])
+    g = 0.3 * rt ** (4.0 / 3.0)
+    t = 0.4 * rt ** (5.0 / 3.0) + g * g / (8 * rt)
+    if fid == 202:
+        eu, vu, vsu, vtu = orc.xc_unpolarized_mgga(fid, rt, g * g, t, thr)
+        e, v, vs, vt = orc.xc_polarized_mgga(fid, np.stack([rt / 2, rt / 2], 1), np.stack([g * g / 4] * 3, 1),
+                                             np.stack([t / 2, t / 2], 1), thr)
+        assert np.max(np.abs(vt[:, 0] - vtu)) <= 1e-12 * np.max(np.abs(vtu))
+    else:
+        eu, vu, vsu = orc.xc_unpolarized(fid, rt, g * g, thr)
+        e, v, vs = orc.xc_polarized(fid, np.stack([rt / 2, rt / 2], 1), np.stack([g * g / 4] * 3, 1), thr)
+    dead = rt < 2 * thr
+    pure_x = fid in (1, 101, 546, 641, 202)
+    if pure_x:
+        assert np.all(eu[dead] == 0.0) and np.all(vu[dead] == 0.0) and np.all(e[dead] == 0.0) and np.all(v[dead] == 0.0)
+    else:  # the hybrids: below 2 thr only the correlation part is left (libxc id 13 / 130)
+        cid = 13 if fid == 178 else 130
+        ec, vc, _ = orc.xc_unpolarized(cid, rt, g * g, thr)
+        assert np.all(eu[dead] == ec[dead]) and np.all(vu[dead] == vc[dead])
+        assert np.all(eu[0:1] == 0.0)  # rho < thr: nothing at all
+    live = ~dead
+    assert np.all(eu[live] < 0.0)
+    assert np.max(np.abs(e[live] - eu[live]) / np.abs(eu[live])) < 1e-12
+    assert np.max(np.abs(v[live, 0] - vu[live]) / np.abs(vu[live])) < 1e-11
+    if pure_x:  # dead channels agree too (both zero); for correlation the polarised call clamps rho_s to thr
+        assert np.all(e[dead] == eu[dead])
+
+
 def test_polarized_correlation_textbook_values():
     """uniform-gas correlation energies per particle at rs = 2 (Perdew-Wang 1992, Table; VWN fit of the same data)"""
     rs = 2.0
