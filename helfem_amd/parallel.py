@@ -22,7 +22,9 @@ def env_world():
 def init(backend=None):
     """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # HELFEM_DIST_FORCE=1: initialise the process group for a single rank too, so that the RCCL code path (group set-up,
+    # all-reduce of the step's device buffers, barrier) can be exercised on a one-GPU box
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -36,6 +38,14 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def forced():
+    return os.environ.get("HELFEM_DIST_FORCE") == "1"
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def owner(unit, nranks):
     """round-robin ownership used by the kernels (fock.hip, eig.hip)"""
     return unit % nranks
@@ -47,18 +57,18 @@ def owned_units(nunits, rank, nranks):
 
 def allreduce_sum_(t):
     """in-place sum all-reduce (no-op for a single process)"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
 def max_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
