@@ -51,6 +51,13 @@ __host__ __device__ inline Dual dcbrt(Dual a) {
   return mk(c, a.dr * f, a.ds * f);
 }
 __host__ __device__ inline Dual dlog(Dual a) { return mk(log(a.v), a.dr / a.v, a.ds / a.v); }
+// log(1 + a) and exp(a) - 1 without the cancellation: at densities below ~1e-28 (reached in the far field when the
+// density threshold is lowered to zero) log(1 + 1/den) of PW92 rounds to 0, exp(-ec/gamma) - 1 with it, and PBE's A = inf
+__host__ __device__ inline Dual dlog1p(Dual a) { return mk(log1p(a.v), a.dr / (1.0 + a.v), a.ds / (1.0 + a.v)); }
+__host__ __device__ inline Dual dexpm1(Dual a) {
+  double e = exp(a.v);
+  return mk(expm1(a.v), a.dr * e, a.ds * e);
+}
 __host__ __device__ inline Dual dexp(Dual a) {
   double e = exp(a.v);
   return mk(e, a.dr * e, a.ds * e);
@@ -134,7 +141,7 @@ __host__ __device__ inline Dual eps_pw92(Dual rs, bool mod) {
   const double a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
   Dual srs = dsqrt(rs);
   Dual den = (2.0 * a) * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
-  return (-2.0 * a) * (1.0 + a1 * rs) * dlog(1.0 + 1.0 / den);
+  return (-2.0 * a) * (1.0 + a1 * rs) * dlog1p(1.0 / den);
 }
 
 __host__ __device__ inline Dual eps_lda_c_pw(Dual rho) {
@@ -160,9 +167,9 @@ __host__ __device__ inline Dual eps_gga_c_pbe(Dual rho, Dual sigma) {
   Dual kf = dcbrt((3.0 * HFG_PI * HFG_PI) * rho);
   Dual ks2 = (4.0 / HFG_PI) * kf;
   Dual t2 = sigma / (4.0 * ks2 * rho * rho);
-  Dual Aa = B / (dexp(-ec / gamma) - 1.0);
+  Dual Aa = B / dexpm1(-ec / gamma);
   Dual At2 = Aa * t2;
-  Dual H = gamma * dlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  Dual H = gamma * dlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
   return ec + H;
 }
 
@@ -250,6 +257,8 @@ __host__ __device__ inline T3 tcbrt(T3 x) {
   return t3f(x, c, c / (3.0 * x.v));
 }
 __host__ __device__ inline T3 tlog(T3 x) { return t3f(x, log(x.v), 1.0 / x.v); }
+__host__ __device__ inline T3 tlog1p(T3 x) { return t3f(x, log1p(x.v), 1.0 / (1.0 + x.v)); }
+__host__ __device__ inline T3 texpm1(T3 x) { return t3f(x, expm1(x.v), exp(x.v)); }
 __host__ __device__ inline T3 texp(T3 x) {
   double e = exp(x.v);
   return t3f(x, e, e);
@@ -335,6 +344,8 @@ __host__ __device__ inline T7 tcbrt(T7 x) {
   return t7f(x, c, c / (3.0 * x.v));
 }
 __host__ __device__ inline T7 tlog(T7 x) { return t7f(x, log(x.v), 1.0 / x.v); }
+__host__ __device__ inline T7 tlog1p(T7 x) { return t7f(x, log1p(x.v), 1.0 / (1.0 + x.v)); }
+__host__ __device__ inline T7 texpm1(T7 x) { return t7f(x, expm1(x.v), exp(x.v)); }
 __host__ __device__ inline T7 texp(T7 x) {
   double e = exp(x.v);
   return t7f(x, e, e);
@@ -374,7 +385,7 @@ template <class T>
 __host__ __device__ inline T pol_pw_G(T rs, double A, double a1, double b1, double b2, double b3, double b4) {
   T s = tsqrt(rs);
   T den = (2.0 * A) * (b1 * s + b2 * rs + b3 * rs * s + b4 * rs * rs);
-  return (-2.0 * A) * (1.0 + a1 * rs) * tlog(1.0 + 1.0 / den);
+  return (-2.0 * A) * (1.0 + a1 * rs) * tlog1p(1.0 / den);
 }
 template <class T>
 __host__ __device__ inline T pol_eps_pw(T rs, T z, bool mod) {
@@ -397,9 +408,9 @@ __host__ __device__ inline T pol_eps_pbe_c(T n, T rs, T z, T sig) {
   T kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
   T ks2 = (4.0 / HFG_PI) * kf;
   T t2 = sig / (4.0 * phi * phi * ks2 * n * n);
-  T Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
+  T Aa = B / texpm1(-ec / (gamma * phi3));
   T At2 = Aa * t2;
-  return ec + gamma * phi3 * tlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  return ec + gamma * phi3 * tlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
 }
 
 /// adds functional id's exc (per particle of ra+rb), vrho[2], vsigma[3] (aa, ab, bb); ra + rb >= threshold assumed,
@@ -508,9 +519,9 @@ __host__ __device__ inline T mg_eps_pbe_c_fullpol(T n, T sig) {
   T kf = tcbrt((3.0 * HFG_PI * HFG_PI) * n);
   T ks2 = (4.0 / HFG_PI) * kf;
   T t2 = sig / ((4.0 * phi * phi) * ks2 * n * n);
-  T Aa = B / (texp(-ec / (gamma * phi3)) - 1.0);
+  T Aa = B / texpm1(-ec / (gamma * phi3));
   T At2 = Aa * t2;
-  return ec + (gamma * phi3) * tlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  return ec + (gamma * phi3) * tlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
 }
 
 // TPSS correlation for a spin-polarised density (Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 (2003), eqs 11-14):

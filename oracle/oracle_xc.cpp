@@ -111,7 +111,7 @@ void pw92(double rs, bool mod, double &ec, double &decdrs) {
   double q0 = -2.0 * a * (1.0 + a1 * rs);
   double q1 = 2.0 * a * (b1 * srs + b2 * rs + b3 * rs * srs + b4 * rs * rs);
   double q1p = a * (b1 / srs + 2.0 * b2 + 3.0 * b3 * srs + 4.0 * b4 * rs);
-  double lg = log(1.0 + 1.0 / q1);
+  double lg = log1p(1.0 / q1);  // log(1 + 1/q1) rounds to 0 for rs > ~1e9 (rho < 1e-28) and PBE's A = beta/gamma/(exp(-ec/gamma) - 1) to inf
   ec = q0 * lg;
   decdrs = -2.0 * a * a1 * lg - q0 * q1p / (q1 * q1 + q1);
 }
@@ -158,11 +158,11 @@ void gga_c_pbe(double rho, double sigma, double &exc, double &vrho, double &vsig
   double ks2 = 4.0 * kf / PI;
   double u = sigma / (4.0 * ks2 * rho * rho);  // t^2
   double E = exp(-ec / gamma);
-  double A = B / (E - 1.0);
+  double A = B / expm1(-ec / gamma);
   double N = B * u * (1.0 + A * u);
   double D = 1.0 + A * u + A * A * u * u;
   double arg = 1.0 + N / D;
-  double H = gamma * log(arg);
+  double H = gamma * log1p(N / D);
   double dN_du = B * (1.0 + 2.0 * A * u), dD_du = A + 2.0 * A * A * u;
   double dN_dA = B * u * u, dD_dA = u + 2.0 * A * u * u;
   double dH_du = gamma * (dN_du * D - N * dD_du) / (D * D * arg);
@@ -303,6 +303,8 @@ inline D3 Dsqrt(D3 a) { double s = sqrt(a.v); return chain(a, s, 0.5 / s); }
 inline D3 Dcbrt(D3 a) { double c = cbrt(a.v); return chain(a, c, c / (3.0 * a.v)); }
 inline D3 Dlog(D3 a) { return chain(a, log(a.v), 1.0 / a.v); }
 inline D3 Dexp(D3 a) { double e = exp(a.v); return chain(a, e, e); }
+inline D3 Dlog1p(D3 a) { return chain(a, log1p(a.v), 1.0 / (1.0 + a.v)); }
+inline D3 Dexpm1(D3 a) { return chain(a, expm1(a.v), exp(a.v)); }
 inline D3 Datan(D3 a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
 inline D3 Dpow43(D3 a) { double c = cbrt(a.v); return chain(a, a.v * c, 4.0 / 3.0 * c); }
 inline D3 Dpow23(D3 a) { double c = cbrt(a.v); return chain(a, c * c, 2.0 / (3.0 * c)); }
@@ -333,7 +335,7 @@ D3 eps_vwn(D3 rs, D3 z) {
 D3 pw_G(D3 rs, double A, double a1, double b1, double b2, double b3, double b4) {
   D3 s = Dsqrt(rs);
   D3 den = (2.0 * A) * (b1 * s + b2 * rs + b3 * rs * s + b4 * rs * rs);
-  return (-2.0 * A) * (1.0 + a1 * rs) * Dlog(1.0 + 1.0 / den);
+  return (-2.0 * A) * (1.0 + a1 * rs) * Dlog1p(1.0 / den);
 }
 
 // PW92 (libxc lda_c_pw / lda_c_pw_mod): e0 + alpha_c f(z)(1-z^4)/f''(0) + (e1-e0) f(z) z^4, alpha_c = -G(third set)
@@ -355,9 +357,9 @@ D3 eps_pbe_c(D3 rho, D3 rs, D3 z, D3 sig) {
   D3 kf = Dcbrt((3.0 * PI * PI) * rho);
   D3 ks2 = (4.0 / PI) * kf;
   D3 t2 = sig / (4.0 * phi * phi * ks2 * rho * rho);
-  D3 A = B / (Dexp(-ec / (gamma * phi3)) - 1.0);
+  D3 A = B / Dexpm1(-ec / (gamma * phi3));
   D3 At2 = A * t2;
-  return ec + gamma * phi3 * Dlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  return ec + gamma * phi3 * Dlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
 }
 }  // namespace
 
@@ -496,9 +498,9 @@ D3 eps_pbe_c_fullpol(D3 n, D3 sig) {
   D3 kf = Dcbrt((3.0 * PI * PI) * n);
   D3 ks2 = (4.0 / PI) * kf;
   D3 t2 = sig / ((4.0 * phi * phi) * ks2 * n * n);
-  D3 A = B / (Dexp(-ec / (gamma * phi3)) - 1.0);
+  D3 A = B / Dexpm1(-ec / (gamma * phi3));
   D3 At2 = A * t2;
-  return ec + (gamma * phi3) * Dlog(1.0 + B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  return ec + (gamma * phi3) * Dlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
 }
 
 D3 eps_tpss_c(D3 rho, D3 sig, D3 tau) {

@@ -494,6 +494,32 @@ def test_exchange_channel_screening_at_the_density_threshold(fid):
         assert np.all(e[dead] == eu[dead])
 
 
+def test_functionals_stay_finite_in_the_far_field():
+    """With the density threshold lowered to zero the far field of the grid hands densities of 1e-30 and less to the
+    functionals; log(1 + 1/q) of PW92 and exp(-ec/gamma) - 1 of PBE must not round to 0 there (A = inf, NaN Fock matrix)."""
+    rt = 10.0 ** np.arange(-36.0, -8.0, 2.0)
+    for sc in (0.0, 1e-3, 1.0, 30.0):
+        g = sc * rt ** (4.0 / 3.0)
+        t = 0.3 * rt ** (5.0 / 3.0) + g * g / (8 * rt)
+        for fid in (1, 7, 12, 13, 101, 130, 406, 178, 546, 641):
+            out = orc.xc_unpolarized(fid, rt, g * g, 0.0)
+            assert all(np.all(np.isfinite(o)) for o in out), (fid, sc)
+            out = orc.xc_polarized(fid, np.stack([0.7 * rt, 0.3 * rt], 1), np.stack([0.49 * g * g, 0.21 * g * g, 0.09 * g * g], 1), 0.0)
+            assert all(np.all(np.isfinite(o)) for o in out), (fid, sc, "pol")
+        for fid in (202, 231):
+            out = orc.xc_unpolarized_mgga(fid, rt, g * g, t, 0.0)
+            assert all(np.all(np.isfinite(o)) for o in out), (fid, sc)
+            out = orc.xc_polarized_mgga(fid, np.stack([0.7 * rt, 0.3 * rt], 1), np.stack([0.49 * g * g, 0.21 * g * g, 0.09 * g * g], 1),
+                                        np.stack([0.7 * t, 0.3 * t], 1), 0.0)
+            assert all(np.all(np.isfinite(o)) for o in out), (fid, sc, "pol")
+    # PW92 keeps its leading far-field behaviour ec -> -2a a1/b4 / rs ... i.e. ec rs -> const
+    e, _, _ = orc.xc_unpolarized(12, rt, 0 * rt, 0.0)
+    rs = (3.0 / (4 * np.pi * rt)) ** (1.0 / 3.0)
+    lim = -0.031091 * 2 * 0.21370 / (2 * 0.031091 * 0.49294)
+    far = rt < 1e-24
+    assert np.max(np.abs(e[far] * rs[far] / lim - 1.0)) < 1e-3
+
+
 def test_polarized_correlation_textbook_values():
     """uniform-gas correlation energies per particle at rs = 2 (Perdew-Wang 1992, Table; VWN fit of the same data)"""
     rs = 2.0

@@ -110,3 +110,19 @@ def test_fullsize_xc_quadrature(full):
     Vq = basis.model_potential((0, 7), (0, 7))
     Vn = basis.nuclear()
     assert np.max(np.abs(Vq - Vn)) < 1e-8 * np.max(np.abs(Vn))
+
+
+def test_fullsize_xc_without_density_threshold(full):
+    """--dftthr 0: the far field of the 40 a.u. grid holds densities below 1e-30; every functional stays finite there
+    and the matrices do not move beyond what the screened tail carries."""
+    hf, basis, C = full["hf"], full["basis"], full["C"]
+    grid = hf.DFTGrid(basis, full["ldft"], full["mdft"])
+    P = np.asfortranarray(2.0 * hf.scf.form_density(C, full["w"]["nocc"]))
+    half = np.asfortranarray(0.5 * P)
+    for x, c in ((101, 130), (1, 7), (202, 231)):
+        H0, E0, N0, _ = grid.eval_Fxc(x, c, P, 1e-12)
+        H, E, N, _ = grid.eval_Fxc(x, c, P, 0.0)
+        assert np.all(np.isfinite(H)) and np.isfinite(E), (x, c)
+        assert abs(E - E0) < 1e-9 * abs(E0) and abs(N - N0) < 1e-9 * N0
+        Ha, Hb, Ep, _, _ = grid.eval_Fxc_pol(x, c, half, half, 0.0)
+        assert np.all(np.isfinite(Ha)) and np.all(np.isfinite(Hb)) and abs(Ep - E) < 1e-11 * abs(E), (x, c)
