@@ -324,6 +324,101 @@ __global__ void k_exl_RB(const double *__restrict__ V0, const double *__restrict
   }
 }
 
+// Element-pair variant for kernels that do not factorise over elements (erfc, TwoDBasis.cpp:1262): one block per
+// (e >= f) and ORDERED shell pair,
+//   RB_tau,ef[(tt, i', l'), (pj, pk)] = sign_tt sum_{c in tau} sum_o w V^t[(c,o)][(j,e,i')] V^t'[(c,o)][(k,f,l')]
+__device__ inline void exl_unpack_tri(int n, int &hi, int &lo) {  // n = hi (hi + 1) / 2 + lo, lo <= hi
+  hi = (int)((sqrt(8.0 * n + 1.0) - 1.0) * 0.5);
+  while ((hi + 1) * (hi + 2) / 2 <= n) hi++;
+  while (hi * (hi + 1) / 2 > n) hi--;
+  lo = n - hi * (hi + 1) / 2;
+}
+
+__global__ void k_exl_RB_pair(const double *__restrict__ V0, const double *__restrict__ V2,
+                              const int *__restrict__ tab_ch_off, const int *__restrict__ tab_ch,
+                              const double *__restrict__ LM_fac, const double *__restrict__ sgn,
+                              const int *__restrict__ S_off, const int *__restrict__ S_list,
+                              const long long *__restrict__ rb_off, int tau, int Nd, int R, int E, int p, int r, int ntt,
+                              double *__restrict__ RB) {
+  extern __shared__ double sh[];  // vj[2][nco][p], vk[2][nco][p], w[nco]
+  const int ef = blockIdx.y;
+  int e, f;
+  exl_unpack_tri(ef, e, f);
+  const int ns = S_off[tau + 1] - S_off[tau];
+  const int n = blockIdx.x;  // n = pk ns + pj
+  if (n >= ns * ns) return;
+  const int pj = n % ns, pk = n / ns;
+  const int j = S_list[S_off[tau] + pj], k = S_list[S_off[tau] + pk];
+  const int c0 = tab_ch_off[tau], nch = tab_ch_off[tau + 1] - c0;
+  const int nco = nch * r;
+  double *vj = sh, *vk = sh + 2 * nco * p, *w = sh + 4 * nco * p;
+  const bool two = (ntt == 4);
+  for (int t = threadIdx.x; t < nco * p; t += blockDim.x) {
+    int ii = t % p, co = t / p;
+    int c = tab_ch[c0 + co / r], o = co % r;
+    int nj = e * (p - 1) + ii, nk = f * (p - 1) + ii;
+    size_t col = (size_t)c * r + o;
+    bool okj = nj < R, okk = nk < R;
+    vj[t] = okj ? V0[col * Nd + (size_t)j * R + nj] : 0.0;
+    vk[t] = okk ? V0[col * Nd + (size_t)k * R + nk] : 0.0;
+    vj[nco * p + t] = (okj && two) ? V2[col * Nd + (size_t)j * R + nj] : 0.0;
+    vk[nco * p + t] = (okk && two) ? V2[col * Nd + (size_t)k * R + nk] : 0.0;
+    if (ii == 0) w[co] = LM_fac[c] * sgn[o];
+  }
+  __syncthreads();
+  const int pp = p * p;
+  const int Kt = ntt * pp;
+  double *out = RB + rb_off[tau] + ((size_t)ef * ns * ns + n) * Kt;
+  for (int il = threadIdx.x; il < pp; il += blockDim.x) {
+    int ip = il % p, lp = il / p;
+    const double *a0 = vj, *a2 = vj + (size_t)nco * p, *b0 = vk, *b2 = vk + (size_t)nco * p;
+    double s00 = 0.0, s02 = 0.0, s20 = 0.0, s22 = 0.0;
+    if (two) {
+      for (int co = 0; co < nco; co++) {
+        double wa0 = w[co] * a0[co * p + ip], wa2 = w[co] * a2[co * p + ip];
+        double x0 = b0[co * p + lp], x2 = b2[co * p + lp];
+        s00 += wa0 * x0;
+        s02 += wa0 * x2;
+        s20 += wa2 * x0;
+        s22 += wa2 * x2;
+      }
+      out[il] = s00;
+      out[pp + il] = -s02;
+      out[2 * pp + il] = -s20;
+      out[3 * pp + il] = s22;
+    } else {
+      for (int co = 0; co < nco; co++) s00 += w[co] * a0[co * p + ip] * b0[co * p + lp];
+      out[il] = s00;
+    }
+  }
+}
+
+// sums the slots of the element-pair products: e == f goes to Kin (as k_exl_reduce), e > f to the cross-element block
+// G_ef[(j,a),(k,b)] that k_exl_assemble reads (the e < f half of K is its transpose)
+__global__ void k_exl_reduce_pair(const double *__restrict__ C, const long long *__restrict__ c_off,
+                                  const int *__restrict__ S_off, const int *__restrict__ pos, int A, int E, int p, int Ntab,
+                                  double *__restrict__ Kin, double *__restrict__ G) {
+  const int jk = blockIdx.x, ef = blockIdx.y;
+  int e, f;
+  exl_unpack_tri(ef, e, f);
+  const int j = jk / A, k = jk % A;
+  const int pp = p * p;
+  const size_t Ap = (size_t)A * p;
+  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+    const int a = t % p, b = t / p;
+    double s = 0.0;
+    for (int tau = 0; tau < Ntab; tau++) {
+      if (c_off[tau] < 0) continue;
+      int pj = pos[tau * A + j], pk = pos[tau * A + k];
+      if (pj < 0 || pk < 0) continue;
+      int ns = S_off[tau + 1] - S_off[tau];
+      s += C[c_off[tau] + (((size_t)ef * ns + pk) * ns + pj) * pp + t];
+    }
+    if (e == f) Kin[((size_t)jk * E + e) * pp + t] = s;
+    else G[((size_t)e * (e - 1) / 2 + f) * Ap * Ap + ((size_t)k * p + b) * Ap + ((size_t)j * p + a)] = s;
+  }
+}
+
 // Kin[(j,k)][e][(a + p b)] = sum over the table slots that contain both shells of C_tau,e[(a b),(pj,pk)]; the GEMMs
 // only cover pj <= pk, the other half is the transpose
 __global__ void k_exl_reduce(const double *__restrict__ C, const long long *__restrict__ c_off,
@@ -459,9 +554,11 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
   a->pure_shell.upload(ps, s);
   a->pure_n.upload(pn, s);
   // exchange-ordered primitive tables
+  // (pair tables, erfc: one block per ordered element pair, the permutation is the same with E^2 "elements")
   const size_t pp = (size_t)t->p * t->p;
-  a->ktei.resize((size_t)t->ntt * Ntab * t->E * pp * pp);
-  hipLaunchKernelGGL(k_exl_permute_tei, dim3(t->ntt * Ntab * t->E, t->p), dim3(256), 0, s, t->tei.p, Ntab, t->E, t->p,
+  const int nper = t->pair_tei ? t->E * t->E : t->E;
+  a->ktei.resize((size_t)t->ntt * Ntab * nper * pp * pp);
+  hipLaunchKernelGGL(k_exl_permute_tei, dim3(t->ntt * Ntab * nper, t->p), dim3(256), 0, s, t->tei.p, Ntab, nper, t->p,
                      t->ntt, a->ktei.p);
   HFG_HIP_CHECK(hipStreamSynchronize(s));
   g_exlr[t] = a;
@@ -471,9 +568,13 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
 /// K from P through the low-rank factors.  Returns false (nothing written) when P is not reproduced by at most
 /// EXL_RMAX factors; the caller then runs the general kernels.
 bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, double *dK) {
-  if (t->pair_tei) return false;  // erfc kernel: no factorisation over elements, general kernels (exchange.hip)
   const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, NLM = t->NLM, Ntab = t->Ntab, ntt = t->ntt;
   if (N > 1024 * EXL_QMAX) return false;
+  // erfc kernel (pair_tei): no factorisation over elements; the element-pair products below need an exchange-ordered
+  // copy of the pair tables
+  if (t->pair_tei && (double)ntt * Ntab * E * E * p * p * p * p * sizeof(double) > 32e9) return false;
+  static const bool pair_off = getenv("HELFEM_EXL_PAIR") && atoi(getenv("HELFEM_EXL_PAIR")) == 0;
+  if (t->pair_tei && pair_off) return false;
   ExLRAux &a = exlr_for(ctx, t);
   hipStream_t s = ctx->stream;
   const int two = (ntt == 4) ? 1 : 0;
@@ -508,16 +609,18 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   a.aP.resize(ncol * Na);
   a.aQw.resize(ncol * Na);
   const size_t Ap = (size_t)A * p;
+  const bool pair = t->pair_tei != 0;
   a.G.resize(std::max<size_t>((size_t)E * (E - 1) / 2 * Ap * Ap, 1));
   hipLaunchKernelGGL(k_exl_expand, dim3((Nd + 255) / 256, r), dim3(256), 0, s, a.L.p, N, Nd, R, r, t->shell_off.p,
                      t->shell_skip.p, a.Ld.p);
   hipLaunchKernelGGL(k_exl_V, dim3(NLM, A), dim3(256), 0, s, a.Ld.p, Nd, R, A, r, a.LM_L.p, a.LM_M.p, t->shell_m.p,
                      a.c0tab.p, a.c2tab.p, t->Lp1, two, a.V0.p, a.V2.p);
-  hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol, A), dim3(128), 0, s, a.V0.p, a.V2.p, t->disj.p, t->LM_tab.p,
-                     t->LM_ilm.p, t->LM_fac.p, a.sgn.p, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
-                     a.aQw.p);
+  if (!pair)
+    hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol, A), dim3(128), 0, s, a.V0.p, a.V2.p, t->disj.p, t->LM_tab.p,
+                       t->LM_ilm.p, t->LM_fac.p, a.sgn.p, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
+                       a.aQw.p);
   // ---- cross-element part: G_ef = aQw_e aP_f^T for e > f (the other half of K is its transpose) ----
-  {
+  if (!pair) {
     std::vector<GemmTask> ct;
     for (int e = 1; e < E; e++)
       for (int f = 0; f < e; f++) {
@@ -550,15 +653,36 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     if (ns == 0 || (tau % ctx->shard_n) != ctx->shard_rank) continue;
     rb_off[tau] = (long long)rb_tot;
     c_off[tau] = (long long)c_tot;
-    rb_tot += (size_t)E * (ns * (ns + 1) / 2) * Kt;
-    c_tot += (size_t)E * (ns * (ns + 1) / 2) * pp;
-    maxN = std::max(maxN, ns * (ns + 1) / 2);
+    // blocks per slot: elements x unordered shell pairs, or (pair tables) element pairs e >= f x ordered shell pairs
+    const size_t nblk = pair ? (size_t)E * (E + 1) / 2 : (size_t)E, ncols = pair ? (size_t)ns * ns : (size_t)ns * (ns + 1) / 2;
+    rb_tot += nblk * ncols * Kt;
+    c_tot += nblk * ncols * pp;
+    maxN = std::max(maxN, (int)ncols);
   }
   a.RB.resize(std::max<size_t>(rb_tot, 1));
   a.C.resize(std::max<size_t>(c_tot, 1));
   for (int tau = 0; tau < Ntab; tau++) {
     if (rb_off[tau] < 0) continue;
     int ns = a.hS_off[tau + 1] - a.hS_off[tau];
+    if (pair) {
+      const size_t ncols = (size_t)ns * ns;
+      for (int e = 0; e < E; e++)
+        for (int f = 0; f <= e; f++) {
+          const size_t ef = (size_t)e * (e + 1) / 2 + f;
+          GemmTask g;
+          g.A = a.ktei.p + ((((size_t)tau * E + e) * E + f) * ntt) * (size_t)pp * pp;
+          g.B = a.RB.p + rb_off[tau] + ef * ncols * Kt;
+          g.C = a.C.p + c_off[tau] + ef * ncols * pp;
+          g.M = pp;
+          g.N = (int)ncols;
+          g.K = Kt;
+          g.lda = pp;
+          g.ldb = Kt;
+          g.ldc = pp;
+          tasks.push_back(g);
+        }
+      continue;
+    }
     const size_t npair = (size_t)ns * (ns + 1) / 2;
     for (int e = 0; e < E; e++) {
       GemmTask g;
@@ -580,18 +704,29 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   if (!tasks.empty()) {
     a.tasks.upload(tasks, s);
     size_t shb = (size_t)(4 * a.max_nch * r * p + a.max_nch * r) * sizeof(double);
-    if (shb > 64 * 1024)
+    if (shb > 64 * 1024) {
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_RB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+      HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_RB_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+    }
     for (int tau = 0; tau < Ntab; tau++) {
       if (rb_off[tau] < 0) continue;
       int ns = a.hS_off[tau + 1] - a.hS_off[tau];
-      hipLaunchKernelGGL(k_exl_RB, dim3(ns * (ns + 1) / 2, E), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p, a.tab_ch.p,
-                         t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau, Nd, R, E, p, r, ntt, a.RB.p);
+      if (pair)
+        hipLaunchKernelGGL(k_exl_RB_pair, dim3(ns * ns, E * (E + 1) / 2), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
+                           a.tab_ch.p, t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau, Nd, R, E, p, r, ntt,
+                           a.RB.p);
+      else
+        hipLaunchKernelGGL(k_exl_RB, dim3(ns * (ns + 1) / 2, E), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p, a.tab_ch.p,
+                           t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau, Nd, R, E, p, r, ntt, a.RB.p);
     }
     gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
   }
-  hipLaunchKernelGGL(k_exl_reduce, dim3(A * A, E), dim3(256), 0, s, a.C.p, a.c_off.p, a.S_off.p, a.pos.p, A, E, p, Ntab,
-                     a.Kin.p);
+  if (pair)
+    hipLaunchKernelGGL(k_exl_reduce_pair, dim3(A * A, E * (E + 1) / 2), dim3(256), 0, s, a.C.p, a.c_off.p, a.S_off.p, a.pos.p,
+                       A, E, p, Ntab, a.Kin.p, a.G.p);
+  else
+    hipLaunchKernelGGL(k_exl_reduce, dim3(A * A, E), dim3(256), 0, s, a.C.p, a.c_off.p, a.S_off.p, a.pos.p, A, E, p, Ntab,
+                       a.Kin.p);
   dim3 grid((N + 63) / 64, (N + 3) / 4);
   hipLaunchKernelGGL(k_exl_assemble, grid, dim3(256), 0, s, a.Kin.p, a.G.p, N, A, E, p, a.pure_shell.p, a.pure_n.p, dK);
   HFG_HIP_CHECK(hipGetLastError());

@@ -76,6 +76,13 @@ def test_rs_exchange_general_kernels_parity(rcase, monkeypatch):
     ob.compute_yukawa(0.7)
     tag, P = list(_densities(gb))[1]
     assert common.relerr(gb.rs_exchange(P), ob.rs_exchange(P)) < 1e-12, name
+    # and for the pair tables of the erfc kernel, whose fast path is a different set of kernels (element-pair products)
+    gb.compute_erfc(0.7)
+    ob.compute_erfc(0.7)
+    Kgen = gb.rs_exchange(P)
+    assert common.relerr(Kgen, ob.rs_exchange(P)) < 1e-12, name
+    monkeypatch.delenv("HELFEM_EXCHANGE")
+    assert common.relerr(gb.rs_exchange(P), Kgen) < 1e-12, name
 
 
 def test_rs_exchange_requires_tables(hf):
