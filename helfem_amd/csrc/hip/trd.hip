@@ -16,6 +16,7 @@
 //                                          together with the partial norms its Householder vector needs.
 // No atomics; all reductions have a fixed order, so the factorisation is bitwise reproducible.
 #include "common.h"
+#include "wave.h"
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64) void k_trdb_loadcol(const TrdBatch *__restrict_
     b.normp[blk][nrs] = 0.0;  // consumers sum one slot more (the slab count of k_trdb_w at the previous column)
   }
   double s = (lr >= 1 && lr < m) ? v * v : 0.0;
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  s = wave_sum(s);
   if (lane == 0) b.normp[blk][rs] = s;
 }
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
     const int np = (m + 1 + 63) / 64;
     double t = 0.0;
     for (int k = tid; k < np; k += 256) t += b.normp[blk][k];
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+    t = wave_sum(t);
     if (lane == 0) nsum[wave] = t;
   }
   double xv[4];  // up to 1024 rows per pass; longer columns loop below
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
     double p = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     if (okr) b.pp[blk][(size_t)cs * n + r] = p;
     double dv = okr ? p * vsh[r] : 0.0;
-    for (int o = 32; o > 0; o >>= 1) dv += __shfl_down(dv, o, 64);
+    dv = wave_sum(dv);
     if ((tid & 63) == 0) b.dots[blk][blockIdx.x * 2 + (tid >> 6)] = dv;
   }
   // partial V^T v and W^T v of this row slab (done once per row slab): each wave takes columns cc = wave, wave+4, ...
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
         int r = rs * 128 + h * 64 + lane;
         if (r < m) t += M[i + 1 + r] * vsh[r];
       }
-      for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+      t = wave_sum(t);
       if (lane == 0) b.cpart[blk][(size_t)rs * 2 * TB_NB + cc] = t;
     }
   }
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void k_trdb_w(const TrdBatch *__restrict__ bp,
       if (k < nd) s += b.dots[blk][k];
     }
     for (int k = tid + 2048; k < nd; k += 256) s += b.dots[blk][k];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    s = wave_sum(s);
     if (lane == 0) scal[4 + wave] = s;
   }
   __syncthreads();
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void k_trdb_w(const TrdBatch *__restrict__ bp,
   if (next) {
     // row 0 of the trailing block (global row i+1), needed by every workgroup for the next column
     if (tid < c) p0 -= v0r * Wv[tid] + w0r * Vv[tid];
-    for (int o = 32; o > 0; o >>= 1) p0 += __shfl_down(p0, o, 64);
+    p0 = wave_sum(p0);
     if (lane == 0) scal[8 + wave] = p0;
   }
   __syncthreads();
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256) void k_trdb_w(const TrdBatch *__restrict__ bp,
       b.col[blk][g] = a;
       nv = (lr >= 2) ? a * a : 0.0;  // x = col[i+2:], its tail x[1:] starts at local row 2
     }
-    for (int o = 32; o > 0; o >>= 1) nv += __shfl_down(nv, o, 64);
+    nv = wave_sum(nv);
     if (lane == 0) b.normp[blk][rs] = nv;
   }
 }
@@ -597,11 +598,9 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
       }
       if (live && grp == 0)
         for (int k = PU; k < pncs; k++) qraw += ppv[(size_t)k * n + g];
-      for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_down(s, o, 64);
-        t2 += __shfl_down(t2, o, 64);
-        qi += __shfl_down(qi, o, 64);
-      }
+      s = wave_sum(s);
+      t2 = wave_sum(t2);
+      qi = wave_sum(qi);
       if (lane == 0) {
         sred[wave] = s;
         if (wave == 0) {
@@ -631,11 +630,9 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
       double vi = (lane < TB_NB) ? sVi[lane & (TB_NB - 1)] : 0.0, wi = (lane < TB_NB) ? sWi[lane & (TB_NB - 1)] : 0.0;
       double vx = (lane < TB_NB) ? sVtX[lane & (TB_NB - 1)] : 0.0, wx = (lane < TB_NB) ? sWtX[lane & (TB_NB - 1)] : 0.0;
       double dq = vi * wx + wi * vx, dz = 2.0 * vi * wi, dx = 2.0 * vx * wx;
-      for (int o = 32; o > 0; o >>= 1) {
-        dq += __shfl_down(dq, o, 64);
-        dz += __shfl_down(dz, o, 64);
-        dx += __shfl_down(dx, o, 64);
-      }
+      dq = wave_sum(dq);
+      dz = wave_sum(dz);
+      dx = wave_sum(dx);
       if (lane == 0) {
         double xAx = 0.0;
         for (int k = 0; k < TF_NW; k++) xAx += sred[k];
@@ -800,7 +797,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     if (okr) fppw[((size_t)par * TF_MAXS + cs) * n + gr] = pq;
     dv = okr ? pq * xR[tid] : 0.0;
     if (symm && rs > cs) dv *= 2.0;  // x_r^T T x_c + x_c^T T^T x_r
-    for (int o = 32; o > 0; o >>= 1) dv += __shfl_down(dv, o, 64);
+    dv = wave_sum(dv);
     if (lane == 0) sred[48 + wave] = dv;
   }
   // ---- per column slab (first row slab only): |x[1:]|^2, V^T x, W^T x over the slab ----
@@ -811,7 +808,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
       int h = gC0 + k;
       double xv = (h >= i + 2 && h < n) ? xC[k] : 0.0;
       double s2 = xv * xv;
-      for (int o = 32; o > 0; o >>= 1) s2 += __shfl_down(s2, o, 64);
+      s2 = wave_sum(s2);
       if (lane == 0) sred[50 + (wave - 2)] = s2;
     }
     // panel columns cc < c (cc = c-1 is the reflector just finished: v, w of the slab are in LDS).  Wave q takes
@@ -844,7 +841,7 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
         int q2 = wave + TF_NW * u;
         if (q2 < 2 * c) {  // wave-uniform
           double t = m0[u] * x0 + m1[u] * x1;
-          for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+          t = wave_sum(t);
           int cc = (q2 < c) ? q2 : q2 - c;
           if (lane == 0) fcpw[((size_t)par * TF_MAXS + cs) * 2 * TB_NB + ((q2 < c) ? cc : TB_NB + cc)] = t;
         }
@@ -891,7 +888,7 @@ __global__ __launch_bounds__(1024) void k_trd_tail(const TrdBatch *__restrict__ 
       double xv = S[k * TT_LD + tid];
       sq = xv * xv;
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o, 64);
+    sq = wave_sum(sq);
     if (lane == 0 && wave < 2) red[wave] = sq;
     __syncthreads();
     double tau, beta, scale;
@@ -941,7 +938,7 @@ __global__ __launch_bounds__(1024) void k_trd_tail(const TrdBatch *__restrict__ 
       w[tid] = pr;  // p for now
       pv = pr * v[tid];
     }
-    for (int o = 32; o > 0; o >>= 1) pv += __shfl_down(pv, o, 64);
+    pv = wave_sum(pv);
     if (lane == 0 && wave < 2) red[2 + wave] = pv;
     __syncthreads();
     if (tid < TT_MAX) {
@@ -963,6 +960,149 @@ __global__ __launch_bounds__(1024) void k_trd_tail(const TrdBatch *__restrict__ 
   }
 }
 
+// Register-resident variant of the tail for orders up to TR_MAX = 192: the trailing matrix lives in the register file of
+// ONE workgroup (768 threads; thread (rg, cg) holds the 4 x 12 elements of rows 4 rg .. 4 rg + 3 and columns
+// cg, cg + 16, ...: 96 VGPRs), only vectors go through LDS.  A 4 x 12 register tile needs 12 + 24 LDS reads of v / p per
+// column where a thread that owns a strided set of one row needs 144 (the LDS port, 2 clk per ds_read_b64 per wave, was
+// the bound of that layout); the partial products of a row are summed over the 16 lanes of its column groups by DPP
+// shuffles, so a column costs three workgroup barriers.  Same algebra, reflector convention and outputs as k_trd_tail.
+constexpr int TR_MAX = 192;
+constexpr int TR_RT = 4;                        // rows per thread
+constexpr int TR_NCG = 16;                      // column groups
+constexpr int TR_NU = TR_MAX / TR_NCG;          // columns per thread
+constexpr int TR_NTH = (TR_MAX / TR_RT) * TR_NCG;  // 768
+constexpr int TR_NW = TR_NTH / 64;
+__global__ __launch_bounds__(TR_NTH) void k_trd_tail_reg(const TrdBatch *__restrict__ bp, int j0) {
+  __shared__ double xs[TR_MAX], vs[TR_MAX], ps[TR_MAX], red[TR_NW], red2[TR_NW];
+  const TrdBatch &b = *bp;
+  const int blk = blockIdx.x;
+  const int n = b.n[blk];
+  const int m = n - j0;  // order of the trailing matrix (rows/cols j0 .. n-1)
+  if (m < 3 || m > TR_MAX) return;
+  gdouble *A = HFG_G(b.A[blk]);
+  const int tid = threadIdx.x, cg = tid & (TR_NCG - 1), rg = tid >> 4, wave = tid >> 6, lane = tid & 63;
+  const int r0 = TR_RT * rg;
+  double a[TR_RT][TR_NU];
+#pragma unroll
+  for (int u = 0; u < TR_NU; u++) {
+    const int c = cg + TR_NCG * u;
+#pragma unroll
+    for (int i = 0; i < TR_RT; i++) a[i][u] = (c < m && r0 + i < m) ? A[(size_t)(j0 + c) * n + j0 + r0 + i] : 0.0;
+  }
+  for (int k = 0; k <= m - 3; k++) {
+    const int j = j0 + k;
+    const int k1 = k + 1;  // first row/col of the trailing block of this step
+    const int kc = k & (TR_NCG - 1), ku = k >> 4;
+    // ---- column k from the registers of the threads that own it ----
+    double xv[TR_RT] = {0.0, 0.0, 0.0, 0.0};
+    double sq = 0.0;
+    if (cg == kc) {
+#pragma unroll
+      for (int u = 0; u < TR_NU; u++)
+        if (u == ku) {
+#pragma unroll
+          for (int i = 0; i < TR_RT; i++) xv[i] = a[i][u];
+        }
+#pragma unroll
+      for (int i = 0; i < TR_RT; i++) {
+        const int r = r0 + i;
+        xs[r] = xv[i];
+        if (r > k1 && r < m) sq += xv[i] * xv[i];
+        if (r == k) b.d[blk][j] = xv[i];
+      }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    double tau, beta, scale;
+    {
+      double xn2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < TR_NW; q++) xn2 += red[q];
+      const double alpha = xs[k1];
+      if (xn2 == 0.0) {
+        tau = 0.0;
+        beta = alpha;
+        scale = 0.0;
+      } else {
+        const double nrm = sqrt(alpha * alpha + xn2);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+    }
+    if (cg == kc) {
+#pragma unroll
+      for (int i = 0; i < TR_RT; i++) {
+        const int r = r0 + i;
+        double vv = 0.0;
+        if (r == k1) vv = 1.0;
+        else if (r > k1 && r < m) vv = xv[i] * scale;
+        vs[r] = vv;
+        if (r > k1 && r < m) A[(size_t)j * n + j0 + r] = vv;  // reflector for the back-transformation
+      }
+    }
+    if (tid == 0) {
+      b.e[blk][j] = beta;
+      b.tau[blk][j] = tau;
+    }
+    __syncthreads();
+    // ---- p = tau S22 v ----
+    double acc[TR_RT] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < TR_NU; u++) {
+      if (TR_NCG * u + TR_NCG - 1 < k1) continue;  // columns already reduced (workgroup-uniform)
+      const double vc = vs[cg + TR_NCG * u];      // 0 for c < k1 and c >= m
+#pragma unroll
+      for (int i = 0; i < TR_RT; i++) acc[i] += a[i][u] * vc;
+    }
+    double vr[TR_RT], pr[TR_RT];
+    double pv = 0.0;
+#pragma unroll
+    for (int i = 0; i < TR_RT; i++) {
+      const double t = row16_sum(acc[i]);
+      const int r = r0 + i;
+      vr[i] = vs[r];
+      pr[i] = (r >= k1 && r < m) ? tau * t : 0.0;
+      pv += pr[i] * vr[i];
+    }
+    if (cg == 0) {
+#pragma unroll
+      for (int i = 0; i < TR_RT; i++) ps[r0 + i] = pr[i];
+    } else {
+      pv = 0.0;
+    }
+    pv = wave_sum(pv);
+    if (lane == 0) red2[wave] = pv;
+    __syncthreads();
+    double a2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < TR_NW; q++) a2 += red2[q];
+    a2 *= -0.5 * tau;
+    // ---- S22 -= v w^T + w v^T,  w = p + a2 v:  S_rc -= v_r p_c + (a2 v_r + w_r) v_c ----
+    double cf[TR_RT];
+#pragma unroll
+    for (int i = 0; i < TR_RT; i++) cf[i] = 2.0 * a2 * vr[i] + pr[i];
+#pragma unroll
+    for (int u = 0; u < TR_NU; u++) {
+      if (TR_NCG * u + TR_NCG - 1 < k1) continue;
+      const double pc = ps[cg + TR_NCG * u], vc = vs[cg + TR_NCG * u];
+#pragma unroll
+      for (int i = 0; i < TR_RT; i++) a[i][u] -= vr[i] * pc + cf[i] * vc;
+    }
+  }
+  // the last 2 x 2 block goes back to the matrix for k_trdb_finish
+#pragma unroll
+  for (int u = 0; u < TR_NU; u++) {
+    const int c = cg + TR_NCG * u;
+#pragma unroll
+    for (int i = 0; i < TR_RT; i++) {
+      const int r = r0 + i;
+      if (c >= m - 2 && c < m && r >= m - 2 && r < m) A[(size_t)(j0 + c) * n + j0 + r] = a[i][u];
+    }
+  }
+}
+
 // d, e of the last 2x2 block (after the final trailing update)
 __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
   const TrdBatch &b = *bp;
@@ -978,6 +1118,13 @@ __global__ void k_trdb_finish(const TrdBatch *__restrict__ bp) {
   b.d[blk][n - 1] = A[(size_t)(n - 1) * n + (n - 1)];
   b.e[blk][n - 1] = 0.0;
   if (n >= 1) b.tau[blk][n - 1] = 0.0;
+}
+
+/// order from which the remaining columns are reduced inside one launch: HELFEM_TRD_TAIL = 0 none, 1 the LDS-resident
+/// kernel (128), 2 (default) the register-resident kernel (192)
+static int trd_tail_order() {
+  static const int mode = getenv("HELFEM_TRD_TAIL") ? atoi(getenv("HELFEM_TRD_TAIL")) : 2;
+  return mode == 0 ? 0 : (mode == 1 ? TT_MAX : TR_MAX);
 }
 
 static int trd_num_cus(hfg_ctx *ctx) {
@@ -1096,10 +1243,10 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     upload_cached(w.ptasks, w.h_ptasks, pt, s);
   }
   // LDS-resident tail (k_trd_tail) from the first panel boundary where every trailing matrix has order <= TT_MAX
-  static const bool no_tail = (getenv("HELFEM_TRD_TAIL") && atoi(getenv("HELFEM_TRD_TAIL")) == 0);
+  const int tail_max = trd_tail_order();
   int j_tail = nmax;  // no tail
-  if (fused && !no_tail && nmax >= 3) {
-    j_tail = std::max(0, ((nmax - TT_MAX + TB_NB - 1) / TB_NB) * TB_NB);
+  if (fused && tail_max > 0 && nmax >= 3) {
+    j_tail = std::max(0, ((nmax - tail_max + TB_NB - 1) / TB_NB) * TB_NB);
     if (nmax - j_tail < 3) j_tail = nmax;
   }
   for (int j0 = 0; j0 <= nmax - 3 && j0 < j_tail; j0 += TB_NB) {
@@ -1168,7 +1315,9 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
       gemm_dev(ctx, false, true, mt, mt, ncols, -1.0, w.V[k].p + (size_t)n * TB_NB + j1, n, w.V[k].p + j1, n, 1.0, A22, n);
     }
   }
-  if (j_tail < nmax) {
+  if (j_tail < nmax && tail_max == TR_MAX) {
+    hipLaunchKernelGGL(k_trd_tail_reg, dim3(nblk), dim3(TR_NTH), 0, s, db, j_tail);
+  } else if (j_tail < nmax) {
     const size_t sht = (size_t)(TT_MAX * TT_LD + 2 * TT_MAX + TT_CG * TT_MAX + 32) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1203,8 +1352,8 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
   HFG_HIP_CHECK(hipEventRecord(e0, s));
   int count = 0;
   int j_tail = nmax;  // the columns of the LDS-resident tail are not launches of this kernel
-  if (w.last_fused && !(getenv("HELFEM_TRD_TAIL") && atoi(getenv("HELFEM_TRD_TAIL")) == 0) && nmax >= 3) {
-    j_tail = std::max(0, ((nmax - TT_MAX + TB_NB - 1) / TB_NB) * TB_NB);
+  if (w.last_fused && trd_tail_order() > 0 && nmax >= 3) {
+    j_tail = std::max(0, ((nmax - trd_tail_order() + TB_NB - 1) / TB_NB) * TB_NB);
     if (nmax - j_tail < 3) j_tail = nmax;
   }
   for (int i = 0; i <= nmax - 3 && i < j_tail; i++) {

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import helfem_amd as hf  # noqa: E402
 
 rng = np.random.RandomState(11)
-for n in (3, 5, 70, 128, 129, 131, 300, 641, 1000):
+for n in (3, 4, 5, 70, 128, 129, 131, 190, 191, 192, 193, 195, 208, 300, 641, 1000):
     A = rng.uniform(-1, 1, (n, n))
     A = A + A.T
     E, C = hf.scf.eig_sym(A)

@@ -227,10 +227,10 @@ def test_tei_tables_built_on_device_match_host_tables(hf):
 @pytest.mark.parametrize("env", [dict(HELFEM_TRD="twokernel"), dict(HELFEM_BT="column"),
                                  dict(HELFEM_TRD="unblocked", HELFEM_BT="column"), dict(HELFEM_TRDF_SYM="1"),
                                  dict(HELFEM_TRDF_SYM="0"), dict(HELFEM_TRDF_NTH="512", HELFEM_TRDF_SYM="1"),
-                                 dict(HELFEM_BT_SIDE="1"), dict(HELFEM_TRD_TAIL="0")],
+                                 dict(HELFEM_BT_SIDE="1"), dict(HELFEM_TRD_TAIL="0"), dict(HELFEM_TRD_TAIL="1")],
                          ids=["two_launches_per_column", "column_backtransform", "unblocked_tridiagonalisation",
                               "symmetric_sweep_everywhere", "full_sweep_everywhere", "symmetric_sweep_512_threads",
-                              "wy_setup_on_side_stream", "no_lds_tail"])
+                              "wy_setup_on_side_stream", "no_tail_kernel", "lds_tail_kernel"])
 def test_fallback_variants(native_libs, env):
     """the earlier kernel variants stay selectable (environment, read once per process) and stay correct"""
     import os
