@@ -20,6 +20,7 @@
 //           zhat_j^2 = prod_i (lam_i - d_j) / (rho prod_{i != j} (d_i - d_j));  U_ji = zhat_j / (d_j - lam_i)
 //           (columns normalised); Q <- [Q_nd U | Q_deflated] sorted by eigenvalue.
 #include "common.h"
+#include "wave.h"
 
 namespace hfg {
 
@@ -195,10 +196,8 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
     zmax = fmax(zmax, fabs(zj));
   }
   double m2 = fmax(dmax, zmax);
-  for (int o = 32; o > 0; o >>= 1) {
-    m2 = fmax(m2, __shfl_xor(m2, o, 64));
-    zmax = fmax(zmax, __shfl_xor(zmax, o, 64));
-  }
+  m2 = wave_max(m2);
+  zmax = wave_max(zmax);
   if ((threadIdx.x & 63) == 0) {
     red[threadIdx.x >> 6] = m2;
     red[4 + (threadIdx.x >> 6)] = zmax;
@@ -318,10 +317,6 @@ __global__ void k_dc_rotate(DCBatch b, const DCNode *__restrict__ nodes, int nod
 }
 
 // ---- step 3: secular equation, one wavefront per root -------------------------------------------------
-__device__ inline double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 __global__ __launch_bounds__(256) void k_dc_secular(DCBatch b, const DCNode *__restrict__ nodes, int node0,
                                                     const int *__restrict__ kcount,
@@ -433,7 +428,7 @@ __global__ __launch_bounds__(256) void k_dc_zhat(DCBatch b, const DCNode *__rest
     double num = (d[org[i]] - dj) + mu[i];  // lam_i - d_j
     prod *= (i == j) ? num : num / (d[i] - dj);
   }
-  for (int o = 32; o > 0; o >>= 1) prod *= __shfl_xor(prod, o, 64);
+  prod = wave_prod(prod);
   if (lane == 0) {
     double zh = sqrt(fabs(prod) / rho_eff[ni]);
     b.zhat[blk][lo + j] = (b.znd[blk][lo + j] >= 0.0) ? zh : -zh;

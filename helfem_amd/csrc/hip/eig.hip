@@ -16,6 +16,7 @@
 //                                                                inter-workgroup dependency at all)
 //   6. C = X Z                                                   GEMM, then rank sort + scatter
 #include "common.h"
+#include "wave.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -82,7 +83,7 @@ __device__ inline void householder_of_column(const double *__restrict__ A, int n
   const double *x = A + (size_t)k * n + k + 1;
   double s = 0.0;
   for (int i = 1 + threadIdx.x; i < m; i += blockDim.x) s += x[i] * x[i];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  s = wave_sum(s);
   int nwave = blockDim.x / 64;
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void k_trd_gemv(EigBatch b, int k) {
     double p = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
     if (row < m) b.pp[blk][(size_t)cs * n + row] = p;
     double dv = (row < m) ? p * vsh[row] : 0.0;
-    for (int o = 32; o > 0; o >>= 1) dv += __shfl_down(dv, o, 64);
+    dv = wave_sum(dv);
     if (lane == 0) b.dots[blk][blockIdx.x] = dv;
   }
 }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void k_backtransform(EigBatch b) {
       vr[r] = vi;
       s += vi * zr[r];
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = wave_sum(s);
     s *= t;
 #pragma unroll
     for (int r = 0; r < NR; r++) zr[r] -= s * vr[r];
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void k_backtransform_lds(EigBatch b) {
     const double *v = A + (size_t)k * n;
     double s = 0.0;
     for (int i = k + 1 + lane; i < n; i += 64) s += ((i == k + 1) ? 1.0 : v[i]) * zs[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = wave_sum(s);
     s *= t;
     for (int i = k + 1 + lane; i < n; i += 64) zs[i] -= s * ((i == k + 1) ? 1.0 : v[i]);
   }

@@ -756,28 +756,33 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
       double tv[NU];
 #pragma unroll
       for (int u = 0; u < NU; u++) tv[u] = r0[u] * xr0 + r1[u] * xr1;
-      int width = NU, lmask = 32;
-#pragma unroll
-      for (int st = 0; st < 6; st++) {
-        if (width > 1) {
-          const int half = width / 2;
-          const bool up = (lane & lmask) != 0;  // upper lanes keep the upper half of the values
-#pragma unroll
-          for (int u = 0; u < NU / 2; u++) {
-            if (u < half) {
-              const double send = up ? tv[u] : tv[u + half];
-              const double keep = up ? tv[u + half] : tv[u];
-              tv[u] = keep + __shfl_xor(send, lmask, 64);
-            }
-          }
-          width = half;
-        } else {
-          tv[0] += __shfl_xor(tv[0], lmask, 64);
-        }
-        lmask >>= 1;
-      }
       // lane bits 5.. select the column: after the NU-halving steps lane group (lane >> (6 - log2 NU)) holds column index
       constexpr int LG = (NU == 8) ? 3 : (NU == 16 ? 4 : 2);
+      int width = NU, lmask = 32;
+#pragma unroll
+      for (int st = 0; st < LG; st++) {
+        const int half = width / 2;
+        const bool up = (lane & lmask) != 0;  // upper lanes keep the upper half of the values
+#pragma unroll
+        for (int u = 0; u < NU / 2; u++) {
+          if (u < half) {
+            // exchanges without the LDS crossbar: permlane swaps across the wave halves / rows, DPP inside a row
+            if (lmask == 32) tv[u] = swap32_sum(tv[u], tv[u + half]);
+            else if (lmask == 16) tv[u] = swap16_sum(tv[u], tv[u + half]);
+            else {
+              const double send = up ? tv[u] : tv[u + half];
+              const double keep = up ? tv[u + half] : tv[u];
+              tv[u] = keep + ((lmask == 8) ? dpp_f64<0x128>(send) : __shfl_xor(send, lmask, 64));  // row_ror:8 = lane ^ 8
+            }
+          }
+        }
+        width = half;
+        lmask >>= 1;
+      }
+      // the remaining 6 - LG steps add within the lane group (any order)
+      if (LG == 3) tv[0] = oct_sum(tv[0]);
+      else if (LG == 4) tv[0] = quad_sum(tv[0]);
+      else tv[0] = row16_sum(tv[0]);
       if ((lane & ((64 >> LG) - 1)) == 0) {
         const int u = lane >> (6 - LG);
         const int h = gC0 + wave * NU + u;

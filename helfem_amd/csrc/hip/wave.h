@@ -32,6 +32,39 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(hi, lo);
 }
 
+/// dpp_f64 with a fill value: lanes of masked rows and lanes without a source lane receive `fill`
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64_fill(double x, double fill) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+/// product over the 64 lanes, in every lane
+__device__ __forceinline__ double wave_prod(double v) {
+  v *= dpp_f64_fill<0x111>(v, 1.0);
+  v *= dpp_f64_fill<0x112>(v, 1.0);
+  v *= dpp_f64_fill<0x114>(v, 1.0);
+  v *= dpp_f64_fill<0x118>(v, 1.0);
+  v *= dpp_f64_fill<0x142, 0xa>(v, 1.0);
+  v *= dpp_f64_fill<0x143, 0xc>(v, 1.0);
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+/// maximum over the 64 lanes, in every lane
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, dpp_f64_fill<0x111>(v, v));
+  v = fmax(v, dpp_f64_fill<0x112>(v, v));
+  v = fmax(v, dpp_f64_fill<0x114>(v, v));
+  v = fmax(v, dpp_f64_fill<0x118>(v, v));
+  v = fmax(v, dpp_f64_fill<0x142, 0xa>(v, v));
+  v = fmax(v, dpp_f64_fill<0x143, 0xc>(v, v));
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 /// sum over each aligned group of 16 lanes (one DPP row), returned in every lane of the group (a butterfly of
 /// commutative additions: bitwise the same in all 16 lanes)
 __device__ __forceinline__ double row16_sum(double v) {
@@ -40,6 +73,36 @@ __device__ __forceinline__ double row16_sum(double v) {
   v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the 8 (all four lanes of a quad hold the same value)
   v += dpp_f64<0x140>(v);  // row_mirror: the other half of the row
   return v;
+}
+
+/// sum over each aligned group of 8 lanes, in every lane of the group
+__device__ __forceinline__ double oct_sum(double v) {
+  v += dpp_f64<0xb1>(v);
+  v += dpp_f64<0x4e>(v);
+  v += dpp_f64<0x141>(v);
+  return v;
+}
+/// sum over each aligned group of 4 lanes, in every lane of the group
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dpp_f64<0xb1>(v);
+  v += dpp_f64<0x4e>(v);
+  return v;
+}
+
+/// One halving step of a transposing butterfly across the two halves of the wave: lanes 0-31 return x[l] + x[l + 32],
+/// lanes 32-63 return y[l - 32] + y[l]  (v_permlane32_swap_b32, gfx950; lane maps printed by
+/// tests/gpu_probe/permlane_probe.hip: swap(X, Y)[0] = {X.lo, Y.lo}, [1] = {X.hi, Y.hi})
+__device__ __forceinline__ double swap32_sum(double x, double y) {
+  auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+/// the same across the two rows of every 32 lanes: lanes with bit 4 clear return x[l] + x[l + 16], the others
+/// y[l - 16] + y[l]  (v_permlane16_swap_b32)
+__device__ __forceinline__ double swap16_sum(double x, double y) {
+  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
 }  // namespace hfg
