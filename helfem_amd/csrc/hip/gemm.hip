@@ -228,7 +228,7 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
+__global__ __launch_bounds__(256, 2) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
                                                const double *__restrict__ A, int lda, const double *__restrict__ B,
                                                int ldb, double beta, double *__restrict__ C, int ldc) {
   __shared__ double As[16][BM + 16];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_dgemm(int transA, int transB, int M, in
 
 // the same tile engine over a device-side task list: C_t = A_t B_t, grid (max tiles, tasks)
 template <int BM, int BN, bool ACC = false>
-__global__ __launch_bounds__(256) void k_dgemm_tasklist(const GemmTask *__restrict__ tasks) {
+__global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__restrict__ tasks) {
   __shared__ double As[16][BM + 16];
   __shared__ double Bs[16][BN + 16];
   const GemmTask t = tasks[blockIdx.y];
