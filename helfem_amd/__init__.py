@@ -152,6 +152,10 @@ class Context(object):
     def set_shard(self, rank, nranks):
         _check(lib().hfg_ctx_set_shard(self.h, int(rank), int(nranks)))
 
+    def fix_sinvh(self, device_ptr):
+        """declare the device matrix at this address constant (None withdraws): see hfg_ctx_fix_sinvh"""
+        _check(lib().hfg_ctx_fix_sinvh(self.h, ctypes.c_void_p(device_ptr or 0)))
+
     def profile(self, on=True):
         _check(lib().hfg_profile_enable(self.h, 1 if on else 0))
 
@@ -616,7 +620,9 @@ class DeviceSCFStep(object):
     def set_matrices(self, H0, Sinvh):
         t = self.torch
         self.H0 = t.from_numpy(np.asfortranarray(H0).ravel(order="F").copy()).to(self.dev)
+        self.ctx.fix_sinvh(None)
         self.Sinvh = t.from_numpy(np.asfortranarray(Sinvh).ravel(order="F").copy()).to(self.dev)
+        self.ctx.fix_sinvh(self.Sinvh.data_ptr())  # constant until the next set_matrices
 
     def set_density(self, P):
         self.P.copy_(self.torch.from_numpy(np.asfortranarray(P).ravel(order="F").copy()))

@@ -207,6 +207,12 @@ int hfg_ctx_synchronize(hfg_ctx *c) {
   HFG_CATCH
 }
 
+int hfg_ctx_fix_sinvh(hfg_ctx *c, const double *dSinvh) {
+  HFG_TRY
+  c->fix_sinvh(dSinvh);
+  HFG_CATCH
+}
+
 int hfg_ctx_set_shard(hfg_ctx *c, int rank, int nranks) {
   HFG_TRY
   if (nranks < 1 || rank < 0 || rank >= nranks) throw std::logic_error("invalid shard");

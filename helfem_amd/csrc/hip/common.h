@@ -86,6 +86,14 @@ struct hfg_ctx {
   hipEvent_t side_ev[2] = {nullptr, nullptr};
   hipStream_t side();
   int shard_rank = 0, shard_n = 1;
+  // hfg_ctx_fix_sinvh: the caller's promise that the device matrix at this address keeps its contents (S^{-1/2} of an
+  // SCF run); eig_blocks_dev then derives the blocks' column supports from it once instead of in every iteration
+  const double *fixed_sinvh = nullptr;
+  unsigned long fixed_gen = 0;  // bumped by every declaration: a new matrix at a recycled address is a new matrix
+  void fix_sinvh(const double *p) {
+    fixed_sinvh = p;
+    fixed_gen++;
+  }
   bool profiling = false;
   std::map<std::string, hfg::ProfEntry> prof;
   std::vector<hipEvent_t> event_pool;

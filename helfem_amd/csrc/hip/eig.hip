@@ -563,6 +563,12 @@ struct EigWork {
   DevBuf<double> Vx[MAXB], G[MAXB], T[MAXB], VT[MAXB], Wb[MAXB], Wp[MAXB], Cc[MAXB];
   DevBuf<double *> btptr;
   bool used_dc = true;
+  // block row / column index lists of the last eig_blocks_dev call, and what they were derived from (hfg_ctx_fix_sinvh)
+  DevBuf<double> idx;  // raw storage for int64 rows + cols
+  const double *sup_S = nullptr;
+  unsigned long sup_gen = 0;
+  int sup_N = 0;
+  std::vector<int64_t> sup_ptr, sup_idx;
 };
 static std::map<hfg_ctx *, EigWork *> g_work;
 static EigWork &work_for(hfg_ctx *ctx) {
@@ -941,37 +947,51 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
   hipStream_t s = ctx->stream;
   if (blk_ptr[nblk] != N) throw std::logic_error("Symmetry mismatch in eig_gsym_sub\n");
   // block row indices on the device
-  DevBuf<double> &idxbuf = ctx->ws[2];  // raw storage for int64 rows + cols
+  DevBuf<double> &idxbuf = w.idx;  // raw storage for int64 rows + cols
   idxbuf.resize(2 * (size_t)N + 16);
   int64_t *drows = (int64_t *)idxbuf.p;
   int64_t *dcols = drows + N;
-  HFG_HIP_CHECK(hipMemcpyAsync(drows, blk_idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
-
-  // column support of every block (scf_helpers.cpp:150-157)
-  DevBuf<int> &flag = w.ibuf2;
-  flag.resize((size_t)N * nblk + 8);
-  for (int ib = 0; ib < nblk; ib++) {
-    int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
-    if (n == 0) throw std::logic_error("eig_gsym_sub: empty symmetry block\n");
-    hipLaunchKernelGGL(k_col_support, dim3(N), dim3(256), 0, s, dS, N, drows + blk_ptr[ib], n, flag.p + (size_t)ib * N);
+  for (int ib = 0; ib < nblk; ib++)
+    if (blk_ptr[ib + 1] == blk_ptr[ib]) throw std::logic_error("eig_gsym_sub: empty symmetry block\n");
+  // column support of every block (scf_helpers.cpp:150-157).  It depends on Sinvh and the blocks only: when the caller
+  // has declared Sinvh fixed (hfg_ctx_fix_sinvh) the lists of the previous call are still on the device
+  const bool cached = ctx->fixed_sinvh && ctx->fixed_sinvh == dS && w.sup_S == dS && w.sup_gen == ctx->fixed_gen &&
+                      w.sup_N == N &&
+                      w.sup_ptr.size() == (size_t)nblk + 1 && std::equal(w.sup_ptr.begin(), w.sup_ptr.end(), blk_ptr) &&
+                      w.sup_idx.size() == (size_t)N && std::equal(w.sup_idx.begin(), w.sup_idx.end(), blk_idx);
+  if (!cached) {
+    w.sup_S = nullptr;
+    HFG_HIP_CHECK(hipMemcpyAsync(drows, blk_idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
+    DevBuf<int> &flag = w.ibuf2;
+    flag.resize((size_t)N * nblk + 8);
+    for (int ib = 0; ib < nblk; ib++) {
+      int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
+      hipLaunchKernelGGL(k_col_support, dim3(N), dim3(256), 0, s, dS, N, drows + blk_ptr[ib], n, flag.p + (size_t)ib * N);
+    }
+    std::vector<int> hflag((size_t)N * nblk);
+    HFG_HIP_CHECK(hipMemcpyAsync(hflag.data(), flag.p, sizeof(int) * hflag.size(), hipMemcpyDeviceToHost, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<int64_t> allcols;
+    for (int ib = 0; ib < nblk; ib++) {
+      int cnt = 0;
+      for (int c = 0; c < N; c++)
+        if (hflag[(size_t)ib * N + c]) {
+          allcols.push_back(c);
+          cnt++;
+        }
+      if (cnt != (int)(blk_ptr[ib + 1] - blk_ptr[ib]))
+        throw std::logic_error("eig_gsym_sub: Sinvh is not block structured (columns with support != block size)\n");
+    }
+    HFG_HIP_CHECK(hipMemcpyAsync(dcols, allcols.data(), sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));  // allcols lives on this stack frame
+    if (ctx->fixed_sinvh == dS) {
+      w.sup_S = dS;
+      w.sup_gen = ctx->fixed_gen;
+      w.sup_N = N;
+      w.sup_ptr.assign(blk_ptr, blk_ptr + nblk + 1);
+      w.sup_idx.assign(blk_idx, blk_idx + N);
+    }
   }
-  std::vector<int> hflag((size_t)N * nblk);
-  HFG_HIP_CHECK(hipMemcpyAsync(hflag.data(), flag.p, sizeof(int) * hflag.size(), hipMemcpyDeviceToHost, s));
-  HFG_HIP_CHECK(hipStreamSynchronize(s));
-  std::vector<int64_t> allcols;
-  std::vector<int> coff(nblk + 1, 0);
-  for (int ib = 0; ib < nblk; ib++) {
-    int cnt = 0;
-    for (int c = 0; c < N; c++)
-      if (hflag[(size_t)ib * N + c]) {
-        allcols.push_back(c);
-        cnt++;
-      }
-    coff[ib + 1] = coff[ib] + cnt;
-    if (cnt != (int)(blk_ptr[ib + 1] - blk_ptr[ib]))
-      throw std::logic_error("eig_gsym_sub: Sinvh is not block structured (columns with support != block size)\n");
-  }
-  HFG_HIP_CHECK(hipMemcpyAsync(dcols, allcols.data(), sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
 
   size_t nmax = 0;
   for (int ib = 0; ib < nblk; ib++) nmax = std::max<size_t>(nmax, blk_ptr[ib + 1] - blk_ptr[ib]);
@@ -1029,7 +1049,7 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
         int ib = mine[c0 + k];
         int n = ns[k];
         hipLaunchKernelGGL(k_gather_block, dim3((n + 255) / 256, n), dim3(256), 0, s, dF, dS, N, drows + blk_ptr[ib],
-                           dcols + coff[ib], n, Fb.p + (size_t)k * nmax * nmax, Xall.p + (size_t)k * nmax * nmax);
+                           dcols + blk_ptr[ib], n, Fb.p + (size_t)k * nmax * nmax, Xall.p + (size_t)k * nmax * nmax);
       }
       gemm_tasklist_dev(ctx, w.gtasks.p, nb, nm, nm);
       gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);      // lower tiles of X^T (F X) only (GemmTask::sym)

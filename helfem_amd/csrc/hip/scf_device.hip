@@ -241,6 +241,12 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   HFG_HIP_CHECK(hipStreamSynchronize(s));
   double t0 = wall();
   form_sinvh_dev(ctx, n, d.S.p, !opt.diag, (int)dsym.size(), ptr.data(), idx.data(), d.Sinvh.p);
+  // S^{-1/2} stays as it is until this run returns: the eigensolves derive the blocks' column supports once
+  struct FixSinvh {
+    hfg_ctx *c;
+    ~FixSinvh() { c->fix_sinvh(nullptr); }
+  } fix_sinvh_guard{ctx};
+  ctx->fix_sinvh(d.Sinvh.p);
   HFG_HIP_CHECK(hipStreamSynchronize(s));
   if (verbose) printf("Half-inverse formed in %.6f\n", wall() - t0);
   DevBuf<double> Sh, Pvec, A2N, ShPv, occ;

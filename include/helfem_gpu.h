@@ -53,6 +53,12 @@ int hfg_device_count(void);
  * RCCL).  Default (0,1) = everything. */
 int hfg_ctx_set_shard(hfg_ctx *ctx, int rank, int nranks);
 
+/* The caller's promise that the DEVICE matrix at dSinvh keeps its contents until the next call of this function
+ * (NULL withdraws it): S^{-1/2} is fixed through an SCF run (diatomic/main.cpp:470-479 forms it once), so
+ * hfg_eig_blocks_dev / hfg_eig_gsym_sub_dev derive the column supports of the symmetry blocks
+ * (scf_helpers.cpp:150-157) from it once instead of in every iteration.  Without it every call re-derives them. */
+int hfg_ctx_fix_sinvh(hfg_ctx *ctx, const double *dSinvh);
+
 /* ---- basis (host-side setup; no GPU needed) ------------------------------------------------
  * Constructor arguments of diatomic::basis::TwoDBasis (src/diatomic/basis.cpp:307):
  * Z1,Z2,Rhalf, primitive basis (only primbas 4 = LIP on Gauss-Lobatto nodes), n_quad, element

@@ -726,3 +726,75 @@ def test_sharded_step_sums_to_unsharded(hf, nranks):
     torch.cuda.synchronize()
     assert float((full.E - E_ref).abs().max()) < 1e-10 * max(1.0, float(E_ref.abs().max()))
     assert float((full.P - P_ref).abs().max()) < 1e-9 * max(1.0, float(P_ref.abs().max()))
+
+
+def test_fixed_sinvh_declaration_caches_block_supports_only_for_that_matrix(hf):
+    """hfg_ctx_fix_sinvh: the column supports of the blocks are derived once per declaration; a different matrix, a new
+    declaration of a matrix at the same address or other blocks are derived afresh"""
+    import torch
+    import oracle_lib as orc
+    rng = np.random.RandomState(8)
+    sizes = [40, 25, 35]
+    N = sum(sizes)
+
+    def problem(seed, perm):
+        r = np.random.RandomState(seed)
+        blocks, o = [], 0
+        for sz in sizes:
+            blocks.append(np.sort(perm[o:o + sz]))
+            o += sz
+        F = r.uniform(-1, 1, (N, N))
+        F = F + F.T
+        A = r.uniform(-1, 1, (N, N))
+        S = A @ A.T + N * np.eye(N)
+        for i, bi in enumerate(blocks):
+            for j, bj in enumerate(blocks):
+                if i != j:
+                    S[np.ix_(bi, bj)] = 0.0
+                    F[np.ix_(bi, bj)] = 0.0
+        return F, S, blocks
+
+    import ctypes
+    ctx = hf.default_context()
+    dev = torch.device("cuda", 0)
+    perm1, perm2 = rng.permutation(N), rng.permutation(N)
+    F1, S1, b1 = problem(1, perm1)
+    F2, S2, b2 = problem(2, perm2)
+    X1, X2 = orc.form_Sinvh(S1, False, b1), orc.form_Sinvh(S2, False, b2)
+
+    def up(M):
+        return torch.from_numpy(np.asfortranarray(M).ravel(order="F").copy()).to(dev)
+
+    def solve(Fd, Xd, blocks):
+        ptr, idx = hf.scf._blocks(blocks)
+        Ed, Cd = torch.zeros(N, dtype=torch.float64, device=dev), torch.zeros(N * N, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        rc = hf.lib().hfg_eig_gsym_sub_dev(ctx.h, ctypes.c_int64(N), ctypes.c_void_p(Fd.data_ptr()), ctypes.c_void_p(Xd.data_ptr()),
+                                           len(blocks), ptr.ctypes.data_as(i64p), idx.ctypes.data_as(i64p),
+                                           ctypes.c_void_p(Ed.data_ptr()), ctypes.c_void_p(Cd.data_ptr()))
+        assert rc == 0, hf.lib().hfg_last_error(ctx.h)
+        ctx.synchronize()
+        return Ed.cpu().numpy(), Cd.cpu().numpy().reshape((N, N), order="F")
+
+    Xd = up(X1)
+    try:
+        ctx.fix_sinvh(Xd.data_ptr())
+        for rep in range(2):  # second call: cached supports
+            E, C = solve(up(F1), Xd, b1)
+            assert np.max(np.abs(E - orc.eig_gsym_sub(F1, X1, b1)[0])) < 1e-10
+        # same address, new contents and blocks, declared again: nothing stale may be used
+        Xd.copy_(up(X2))
+        ctx.fix_sinvh(Xd.data_ptr())
+        E, C = solve(up(F2), Xd, b2)
+        assert np.max(np.abs(E - orc.eig_gsym_sub(F2, X2, b2)[0])) < 1e-10
+        assert np.max(np.abs(C.T @ S2 @ C - np.eye(N))) < 1e-10
+        # declared matrix, other blocks of the same sizes: the key holds the index lists
+        ctx.fix_sinvh(Xd.data_ptr())
+        E, C = solve(up(F2), Xd, b2)
+        Xd.copy_(up(X1))
+        ctx.fix_sinvh(Xd.data_ptr())
+        E, C = solve(up(F1), Xd, b1)
+        assert np.max(np.abs(E - orc.eig_gsym_sub(F1, X1, b1)[0])) < 1e-10
+    finally:
+        ctx.fix_sinvh(None)
