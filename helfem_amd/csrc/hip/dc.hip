@@ -610,35 +610,44 @@ __global__ void k_dc_gather(DCBatch b, const DCNode *__restrict__ nodes, int nod
 // ---- step 8: final order of the node's eigenvalues --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dc_rank(DCBatch b, const DCNode *__restrict__ nodes, int node0,
                                                  const int *__restrict__ kcount) {
-  // grid (node, slice): every workgroup stages the node's n values in LDS, then ranks its own slice of 256 of them
-  // (one workgroup per node left the top merges, n ~ 1400, with three busy CUs for 250 us)
+  // grid (node, slice): every workgroup stages the node's n values in LDS, then ranks its own slice of 32 of them, eight
+  // lanes per value (each counts over an eighth of the list, the counts are summed by DPP)
+  // (one workgroup per node left the top merges, n ~ 1400, with three busy CUs for 250 us; one thread per value and 256
+  // values per workgroup 104 us: every thread walked the whole list)
   extern __shared__ double sh[];  // values[n]
   const int ni = node0 + blockIdx.x;
   const DCNode nd = nodes[ni];
   const int blk = nd.blk, lo = nd.lo, n = nd.hi - nd.lo;
-  if ((int)blockIdx.y * 256 >= n) return;
+  if ((int)blockIdx.y * 32 >= n) return;
   // value of sorted slot s: the new root if s is non-deflated (position ndpos[s] in the nd list), else the deflated Ds[s]
   const int *flag = b.flag[blk] + lo;
   for (int s = threadIdx.x; s < n; s += blockDim.x) {
     sh[s] = flag[s] ? b.Ds[blk][lo + s] : b.lam[blk][lo + b.ndpos[blk][lo + s]];
   }
   __syncthreads();
-  const int s = blockIdx.y * 256 + threadIdx.x;
-  if (s < n) {
-    const double v = sh[s];
-    int rk = 0;
-    int j = 0;
-    for (; j + 8 <= n; j += 8) {
+  const int s = blockIdx.y * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+  const int per = (n + 7) >> 3, j0 = part * per, j1 = min(n, j0 + per);
+  const bool ok = s < n;
+  const double v = ok ? sh[s] : 0.0;
+  int rk = 0;
+  if (ok) {
+    int j = j0;
+    for (; j + 8 <= j1; j += 8) {
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const double x = sh[j + u];
         rk += (x < v) || (x == v && j + u < s);
       }
     }
-    for (; j < n; j++) {
+    for (; j < j1; j++) {
       const double x = sh[j];
       rk += (x < v) || (x == v && j < s);
     }
+  }
+  rk += __builtin_amdgcn_update_dpp(0, rk, 0xb1, 0xf, 0xf, true);   // lane ^ 1
+  rk += __builtin_amdgcn_update_dpp(0, rk, 0x4e, 0xf, 0xf, true);   // lane ^ 2
+  rk += __builtin_amdgcn_update_dpp(0, rk, 0x141, 0xf, 0xf, true);  // the other quad of the eight (row_half_mirror)
+  if (ok && part == 0) {
     b.rank[blk][lo + s] = rk;
     b.d2[blk][lo + rk] = v;
   }
@@ -899,7 +908,7 @@ void tridiag_dc_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, d
     size_t shr = (size_t)mx * sizeof(double);
     if (shr > 64 * 1024)
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_dc_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shr));
-    hipLaunchKernelGGL(k_dc_rank, dim3(nn, (mx + 255) / 256), dim3(256), shr, s, b, w.nodes.p, node0, w.kcount.p);
+    hipLaunchKernelGGL(k_dc_rank, dim3(nn, (mx + 31) / 32), dim3(256), shr, s, b, w.nodes.p, node0, w.kcount.p);
     hipLaunchKernelGGL(k_dc_scatter, dim3((mx + 255) / 256, mx, nn), dim3(256), 0, s, b, w.nodes.p, node0, w.kcount.p);
     hipLaunchKernelGGL(k_dc_copyback, dim3((mx + 255) / 256, mx, nn), dim3(256), 0, s, b, w.nodes.p, node0);
   }
