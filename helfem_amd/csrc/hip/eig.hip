@@ -475,6 +475,7 @@ __global__ void k_bt_extract(EigBatch b, double *const *__restrict__ Vx) {
 // The split-K product delivers S = [V_p | V_{p+1}]^T Z in BT_S slabs (2 BT_KB x n each, ld 2 BT_KB); this kernel adds the
 // slabs and applies the coupling C = V_p^T VT_{p+1} (itself the sum of BT_GS partial products).  Workgroup = 4 columns.
 constexpr int BT_PW = 2 * BT_KB;  // rows of the pair's W
+constexpr int BT_WREP = 4;         // passes of 4 columns per workgroup of k_bt_wpair
 __global__ __launch_bounds__(256) void k_bt_wpair(EigBatch b, double *const *__restrict__ Wpart, double *const *__restrict__ W,
                                                   double *const *__restrict__ Cc, int S, int GS, int npair, int pair,
                                                   int kb1_ofblk0) {
@@ -494,25 +495,31 @@ __global__ __launch_bounds__(256) void k_bt_wpair(EigBatch b, double *const *__r
       sC[t % BT_KB][t / BT_KB] = c;  // C is column-major, ld BT_KB: element (row t % KB, col t / KB)
     }
   }
-  const int col = blockIdx.x * 4 + cl;
+  // 16 columns per workgroup, four at a time: the 64 x 64 coupling (GS slabs to add) is staged once for all of them
+  // (with 4 columns per workgroup its 128 KB of loads per workgroup made this kernel 43 us per pair)
   const size_t tot = (size_t)BT_PW * n;
-  double a0 = 0.0, a1 = 0.0;
-  if (col < n) {
-    for (int sl = 0; sl < S; sl++) {
-      a0 += Wpart[blk][(size_t)sl * tot + (size_t)col * BT_PW + i];
-      a1 += Wpart[blk][(size_t)sl * tot + (size_t)col * BT_PW + BT_KB + i];
+  for (int rep = 0; rep < BT_WREP; rep++) {
+    const int col = (blockIdx.x * BT_WREP + rep) * 4 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (col < n) {
+      for (int sl = 0; sl < S; sl++) {
+        a0 += Wpart[blk][(size_t)sl * tot + (size_t)col * BT_PW + i];
+        a1 += Wpart[blk][(size_t)sl * tot + (size_t)col * BT_PW + BT_KB + i];
+      }
+    }
+    __syncthreads();  // s1 of the previous four columns has been read (first pass: sC is complete)
+    s1[cl][i] = (kb1 > 0 && i < kb1) ? a1 : 0.0;
+    __syncthreads();
+    if (col < n) {
+      if (kb1 > 0) {
+        double corr = 0.0;
+        for (int j = 0; j < kb1; j++) corr += sC[i][j] * s1[cl][j];
+        a0 -= corr;
+      }
+      W[blk][(size_t)col * BT_PW + i] = a0;
+      W[blk][(size_t)col * BT_PW + BT_KB + i] = (kb1 > 0 && i < kb1) ? a1 : 0.0;
     }
   }
-  s1[cl][i] = (kb1 > 0 && i < kb1) ? a1 : 0.0;
-  __syncthreads();
-  if (col >= n) return;
-  if (kb1 > 0) {
-    double corr = 0.0;
-    for (int j = 0; j < kb1; j++) corr += sC[i][j] * s1[cl][j];
-    a0 -= corr;
-  }
-  W[blk][(size_t)col * BT_PW + i] = a0;
-  W[blk][(size_t)col * BT_PW + BT_KB + i] = (kb1 > 0 && i < kb1) ? a1 : 0.0;
 }
 
 // T_p from the Gram matrix G_p = V_p^T V_p and tau (one workgroup per block p of one matrix):
@@ -769,7 +776,7 @@ static void bt_wy_apply(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, i
     gemm_tasklist64_dev(ctx, w.btslab.p + (size_t)g * BT_S * nblk, BT_S * nblk, BT_PW, nmax);
     // (summing the slabs inside the update's operand loads instead was measured: 2.73 -> 3.11 ms, six times the operand
     // traffic on every tile's critical path)
-    hipLaunchKernelGGL(k_bt_wpair, dim3((nmax + 3) / 4, nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk,
+    hipLaunchKernelGGL(k_bt_wpair, dim3((nmax + 4 * BT_WREP - 1) / (4 * BT_WREP), nblk), dim3(256), 0, s, b, dptr + 3 * nblk, dptr + 4 * nblk,
                        dptr + 5 * nblk, BT_S, BT_GS, NP, g, 0);
     gemm_tasklist_acc_dev(ctx, w.btupd.p + (size_t)g * nblk, nblk, nmax, nmax, acc_tile != 128);
   }
