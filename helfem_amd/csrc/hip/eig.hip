@@ -584,9 +584,18 @@ __global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restri
     sg[t] = (t < i) ? sG[i][t] : 0.0;
     __syncthreads();
     if (t < i) {
-      double acc = 0.0;
-      for (int k = t; k < i; k++) acc += sT[t][k] * sg[k];  // row t of the triangle times G(0:i, i)
-      sT[t][i] = -ti * acc;
+      // row t of the triangle times G(0:i, i).  Full-length and unrolled: T(t, k) is still zero for k < t and for the
+      // columns >= i not built yet, sg is zero from i on; the rolled loop over k = t .. i-1 was bound by the latency of
+      // its two LDS reads per term (2016 dependent terms per block: 85 of the kernel's 100 us)
+      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < BT_KB; k += 4) {
+        acc0 += sT[t][k] * sg[k];
+        acc1 += sT[t][k + 1] * sg[k + 1];
+        acc2 += sT[t][k + 2] * sg[k + 2];
+        acc3 += sT[t][k + 3] * sg[k + 3];
+      }
+      sT[t][i] = -ti * ((acc0 + acc1) + (acc2 + acc3));
     }
     if (t == i) sT[i][i] = ti;
     __syncthreads();
