@@ -266,10 +266,12 @@ __global__ void k_exl_permute_tei(const double *__restrict__ tei, int Ntab, int 
 __global__ void k_exl_RB(const double *__restrict__ V0, const double *__restrict__ V2, const int *__restrict__ tab_ch_off,
                          const int *__restrict__ tab_ch, const double *__restrict__ LM_fac,
                          const double *__restrict__ sgn, const int *__restrict__ S_off, const int *__restrict__ S_list,
-                         const long long *__restrict__ rb_off, int tau, int Nd, int R, int E, int p, int r, int ntt,
+                         const long long *__restrict__ rb_off, int tau0, int Nd, int R, int E, int p, int r, int ntt,
                          double *__restrict__ RB) {
   extern __shared__ double sh[];  // vj[2][nco][p], vk[2][nco][p], w[nco]
   const int e = blockIdx.y;
+  const int tau = tau0 + blockIdx.z;  // one launch covers all table slots (grid.z); slots of other ranks have no offset
+  if (rb_off[tau] < 0) return;
   const int ns = S_off[tau + 1] - S_off[tau];
   const int n = blockIdx.x;  // pair pj <= pk, n = pk (pk + 1) / 2 + pj  (K is symmetric: K_kj = K_jk^T)
   const int npair = ns * (ns + 1) / 2;
@@ -338,9 +340,11 @@ __global__ void k_exl_RB_pair(const double *__restrict__ V0, const double *__res
                               const int *__restrict__ tab_ch_off, const int *__restrict__ tab_ch,
                               const double *__restrict__ LM_fac, const double *__restrict__ sgn,
                               const int *__restrict__ S_off, const int *__restrict__ S_list,
-                              const long long *__restrict__ rb_off, int tau, int Nd, int R, int E, int p, int r, int ntt,
+                              const long long *__restrict__ rb_off, int tau0, int Nd, int R, int E, int p, int r, int ntt,
                               double *__restrict__ RB) {
   extern __shared__ double sh[];  // vj[2][nco][p], vk[2][nco][p], w[nco]
+  const int tau = tau0 + blockIdx.z;
+  if (rb_off[tau] < 0) return;
   const int ef = blockIdx.y;
   int e, f;
   exl_unpack_tri(ef, e, f);
@@ -708,16 +712,20 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_RB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_RB_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
     }
-    for (int tau = 0; tau < Ntab; tau++) {
-      if (rb_off[tau] < 0) continue;
-      int ns = a.hS_off[tau + 1] - a.hS_off[tau];
+    // one launch for all table slots (grid.z, at most 65535 per launch): 126 launches of ~40 us each before
+    int max_ns = 0;
+    for (int tau = 0; tau < Ntab; tau++)
+      if (rb_off[tau] >= 0) max_ns = std::max(max_ns, a.hS_off[tau + 1] - a.hS_off[tau]);
+    for (int tau0 = 0; tau0 < Ntab; tau0 += 65535) {
+      const int nz = std::min(65535, Ntab - tau0);
       if (pair)
-        hipLaunchKernelGGL(k_exl_RB_pair, dim3(ns * ns, E * (E + 1) / 2), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
-                           a.tab_ch.p, t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau, Nd, R, E, p, r, ntt,
-                           a.RB.p);
+        hipLaunchKernelGGL(k_exl_RB_pair, dim3(max_ns * max_ns, E * (E + 1) / 2, nz), dim3(256), shb, s, a.V0.p, a.V2.p,
+                           a.tab_ch_off.p, a.tab_ch.p, t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E,
+                           p, r, ntt, a.RB.p);
       else
-        hipLaunchKernelGGL(k_exl_RB, dim3(ns * (ns + 1) / 2, E), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p, a.tab_ch.p,
-                           t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau, Nd, R, E, p, r, ntt, a.RB.p);
+        hipLaunchKernelGGL(k_exl_RB, dim3(max_ns * (max_ns + 1) / 2, E, nz), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
+                           a.tab_ch.p, t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,
+                           a.RB.p);
     }
     gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
   }
