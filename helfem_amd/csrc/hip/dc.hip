@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64) void k_dc_leaf(DCBatch b, const DCNode *__restr
 }
 
 // ---- merge, step 1: z vector, merged sort, deflation ---------------------------------------------------
+constexpr int DC_SQZ = 20;  // candidate-list entries per thread in the parallel squeeze of k_dc_prepare: merges up to 5120
 __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__restrict__ nodes,
                                                     const double *__restrict__ rho_all, int node0,
                                                     int *__restrict__ kcount, int *__restrict__ nrot,
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
       for (int j = 0; j < n; j++) sflag[j] = 1;
     } else if (fast) {
       k = fast_k;  // sflag and the candidate list are already in place
-    } else if (n <= 2048) {
+    } else if (n <= 256 * DC_SQZ) {
       // Rotations exist, but they are sparse (64-73 among ~620 candidates in the top merges of the 3 x 1400 bench
       // problem).  Only the chains that start at a flagged pair are sequential: the lane jumps from flagged pair to
       // flagged pair through the bit words, follows a chain while its running (modified) candidate keeps rotating with
@@ -383,10 +384,10 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
   __syncthreads();
   if (nrm_sh > 0) {  // squeeze the deflated positions out of the candidate list (uniform branch)
     const int K = candk_sh, nrm = nrm_sh;
-    const int chunk = (K + 255) / 256, c0 = threadIdx.x * chunk;  // <= 8 entries per thread (n <= 2048)
-    int vals[8], newi[8];
+    const int chunk = (K + 255) / 256, c0 = threadIdx.x * chunk;  // <= DC_SQZ entries per thread
+    int vals[DC_SQZ], newi[DC_SQZ];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
+    for (int e = 0; e < DC_SQZ; e++) {
       const int q = c0 + e;
       newi[e] = -1;
       vals[e] = 0;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; e++)
+    for (int e = 0; e < DC_SQZ; e++)
       if (newi[e] >= 0) snd[newi[e]] = vals[e];
     __syncthreads();
   }
