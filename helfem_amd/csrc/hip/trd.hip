@@ -623,6 +623,8 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
         else sWi[cc] = cpl;
       }
     }
+    if ((dbg & 4) && blockIdx.x == 0 && blk == 0 && lane == 0)  // arrival of every wave at the first barrier
+      ((gu64 *)(b.fcp[blk] + (size_t)2 * TF_MAXS * 2 * TB_NB))[(size_t)8 * n + (size_t)i * 16 + wave] = wall_clock64() - tk0;
     TRDF_LDS_BARRIER();
     TRDF_STAMP(1)
     if (wave == 0) {
@@ -1201,7 +1203,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
     w.fpp[i].resize((size_t)2 * TF_MAXS * n);
     w.fdots[i].resize((size_t)2 * TF_MAXS * TF_MAXS);
     w.fxn2[i].resize((size_t)2 * TF_MAXS);
-    w.fcp[i].resize((size_t)2 * TF_MAXS * 2 * TB_NB + (size_t)8 * n + 64);  // + phase stamps of the measurement replay
+    w.fcp[i].resize((size_t)2 * TF_MAXS * 2 * TB_NB + (size_t)24 * n + 64);  // + phase stamps of the measurement replay (8 per column, then 16 per-wave arrival times per column)
     b.fx[i] = w.fx[i].p;
     b.fpp[i] = w.fpp[i].p;
     b.fdots[i] = w.fdots[i].p;
@@ -1398,6 +1400,20 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
   *launches = count;
   if (w.last_fused && getenv("HELFEM_TRDF_DBG") && (atoi(getenv("HELFEM_TRDF_DBG")) & 4)) {
     const int n0 = w.last_ns[0];
+    {
+      std::vector<unsigned long long> wv((size_t)16 * n0);
+      HFG_HIP_CHECK(hipMemcpy(wv.data(), w.fcp[0].p + (size_t)2 * TF_MAXS * 2 * TB_NB + (size_t)8 * n0, wv.size() * 8, hipMemcpyDeviceToHost));
+      double aw[16] = {0};
+      int cn = 0;
+      for (int i = 40; i < n0 - 200; i++) {
+        if (i % TB_NB == 0) continue;
+        for (int k = 0; k < 16; k++) aw[k] += (double)wv[(size_t)i * 16 + k];
+        cn++;
+      }
+      printf("  arrival at barrier 1 by wave (us):");
+      for (int k = 0; k < 16; k++) printf(" %.2f", aw[k] / std::max(cn, 1) * 0.01);
+      printf("\n");
+    }
     std::vector<unsigned long long> st((size_t)8 * n0);
     HFG_HIP_CHECK(hipMemcpy(st.data(), w.fcp[0].p + (size_t)2 * TF_MAXS * 2 * TB_NB, st.size() * 8, hipMemcpyDeviceToHost));
     double acc[6] = {0, 0, 0, 0, 0, 0};
