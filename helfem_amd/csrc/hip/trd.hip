@@ -483,8 +483,8 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
   constexpr int NU = TF_T / TF_NW;  // columns per wave
   double r0[NU], r1[NU];
   const int row = gR0 - (i + 1) + 2 * lane;  // local row (relative to i+1) of this lane's pair
-  // (B, early) the loads of the trailing-matrix tile are independent of everything else; they are issued right
-  // BEHIND the small phase-A loads so that those return first (vmcnt is in order)
+  // (B, early) the loads of the trailing-matrix tile are independent of everything else; they are issued BEHIND the
+  // small phase-A loads of ALL waves (after the first barrier, see there) so that those return first
   auto issue_tile = [&]() {
     if (!has_cur) return;
     // 32-bit element offsets from the (uniform) base pointer: n^2 < 2^31 for every n the launcher admits, and the
@@ -587,7 +587,6 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
         if (cc < cp) cpl = (t < TB_NB) ? Vb[(unsigned)cc * un + (unsigned)i] : Wb[(unsigned)cc * un + (unsigned)i];
       }
       TRDF_STAMP(6)
-      issue_tile();
       TRDF_STAMP(7)
       double s = s0 + s1;
       for (int k = tid + 2 * TF_NTH; k < nd; k += TF_NTH) s += pdots[k];
@@ -626,6 +625,11 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     if ((dbg & 4) && blockIdx.x == 0 && blk == 0 && lane == 0)  // arrival of every wave at the first barrier
       ((gu64 *)(b.fcp[blk] + (size_t)2 * TF_MAXS * 2 * TB_NB))[(size_t)8 * n + (size_t)i * 16 + wave] = wall_clock64() - tk0;
     TRDF_LDS_BARRIER();
+    // (B, early) the tile loads are issued HERE, behind the first barrier, not right behind this wave's phase-A loads:
+    // the CU serves vector-memory instructions in issue order, and 8 KB of tile requests per wave in front of the
+    // small phase-A loads of the waves after it delayed their arrival at the barrier (last group of waves: 3.4 -> 2.8 us
+    // after entry; the tile is not needed before the row stage two barriers later and still arrives in time)
+    issue_tile();
     TRDF_STAMP(1)
     if (wave == 0) {
       // lanes 0..31 hold one panel column each: three small dot products by shuffles, then lane 0 finishes
