@@ -539,7 +539,8 @@ __global__ __launch_bounds__(TF_NTH) void k_trdf(const TrdBatch *__restrict__ bp
     const gdouble *Vb = Vw, *Wb = Ww;
     // per-row loads (all independent): group grp holds the panel columns cc = grp + 4u
     double aii = 0.0, alpha = 0.0;
-    if (tid == 0) {
+    if (wave == 0) {  // wave-uniform (all 64 lanes read the same two words): a load under a divergent branch makes the
+                      // compiler fall back to vmcnt(0) at the next use of any load
       aii = A[(size_t)i * n + i];
       alpha = px[i];
     }
