@@ -427,24 +427,41 @@ __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__r
 }
 
 // ---- step 2: Givens rotations of the deflation on the columns of Q -----------------------------------
-__global__ void k_dc_rotate(DCBatch b, const DCNode *__restrict__ nodes, int node0,
-                            const int *__restrict__ nrot) {
+__global__ __launch_bounds__(256) void k_dc_rotate(DCBatch b, const DCNode *__restrict__ nodes, int node0,
+                                                   const int *__restrict__ nrot) {
   const int ni = node0 + blockIdx.y;
   const DCNode nd = nodes[ni];
   const int nr = nrot[ni];
   if (nr == 0) return;
   const int lo = nd.lo, n = nd.hi - nd.lo, blk = nd.blk;
   const int ld = b.n[blk];
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  double *Q = b.Qa[blk] + lo + r;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  // the rotations are staged 256 at a time (column offsets already resolved through src): read from global memory inside
+  // the loop, every rotation paid the chain "index -> src[index] -> Q" of dependent round trips
+  __shared__ int scp[256], scj[256];
+  __shared__ double sc[256], ss[256];
   const int *src = b.src[blk] + lo;
-  for (int t = 0; t < nr; t++) {
-    int cp = lo + src[b.roti[blk][lo + t]], cj = lo + src[b.rotj[blk][lo + t]];
-    double c = b.rotc[blk][lo + t], s = b.rots[blk][lo + t];
-    double qp = Q[(size_t)cp * ld], qj = Q[(size_t)cj * ld];
-    Q[(size_t)cp * ld] = c * qp + s * qj;
-    Q[(size_t)cj * ld] = -s * qp + c * qj;
+  double *Q = b.Qa[blk] + lo + r;
+  for (int t0 = 0; t0 < nr; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    if (t < nr) {
+      scp[threadIdx.x] = lo + src[b.roti[blk][lo + t]];
+      scj[threadIdx.x] = lo + src[b.rotj[blk][lo + t]];
+      sc[threadIdx.x] = b.rotc[blk][lo + t];
+      ss[threadIdx.x] = b.rots[blk][lo + t];
+    }
+    __syncthreads();
+    if (r < n) {
+      const int cnt = min(256, nr - t0);
+      for (int u = 0; u < cnt; u++) {
+        const int cp = scp[u], cj = scj[u];
+        const double c = sc[u], s = ss[u];
+        const double qp = Q[(size_t)cp * ld], qj = Q[(size_t)cj * ld];
+        Q[(size_t)cp * ld] = c * qp + s * qj;
+        Q[(size_t)cj * ld] = -s * qp + c * qj;
+      }
+    }
+    __syncthreads();
   }
 }
 
