@@ -280,6 +280,30 @@ class TwoDBasis(object):
             _check(lib().hfg_compute_tei(self.h, 1 if exchange else 0))
         self._uploaded = None
 
+    def lm_map(self):
+        """the sorted (L, |M|) channels of the constructor (basis.cpp:333-375)"""
+        n = ctypes.c_int(4096)
+        L = (ctypes.c_int * 4096)()
+        M = (ctypes.c_int * 4096)()
+        _check(lib().hfg_basis_lm_map(self.h, L, M, ctypes.byref(n)))
+        return [(L[i], M[i]) for i in range(n.value)]
+
+    PRIM_TABLES = ("tei00", "tei02", "tei20", "tei22", "ktei00", "ktei02", "ktei20", "ktei22", "P0", "P2", "Q0", "Q2")
+
+    def prim_table(self, name, ilm, iel):
+        """one table of compute_tei (prim_tei**, prim_ktei**, disjoint_**) in the reference's shape; device-built
+        tables are copied back from HBM"""
+        which = self.PRIM_TABLES.index(name)
+        r, c = ctypes.c_int64(), ctypes.c_int64()
+        ctxh = self.ctx.h if self.ctx is not None else None
+        f = lib().hfg_basis_get_prim
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                      ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        _check(f(ctxh, self.h, which, int(ilm), int(iel), None, ctypes.byref(r), ctypes.byref(c)))
+        out = np.zeros((r.value, c.value), order="F")
+        _check(f(ctxh, self.h, which, int(ilm), int(iel), _p(out), ctypes.byref(r), ctypes.byref(c)))
+        return out
+
     def upload(self, ldft=0, mdft=0, ctx=None):
         """tables -> HBM (also sets up the XC grid of DFTGrid(basis, ldft, mdft))"""
         ctx = ctx or self.ctx or default_context()

@@ -345,6 +345,66 @@ int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *b, int exchange) {
   HFG_CATCH
 }
 
+int hfg_basis_lm_map(const hfg_basis *b, int *L, int *M, int *n) {
+  HFG_TRY
+  if (b->kind) throw std::logic_error("hfg_basis_lm_map: diatomic bases only\n");
+  const int cap = *n, cnt = (int)b->b.lm_map.size();
+  *n = cnt;
+  if (cap < cnt) throw std::logic_error("hfg_basis_lm_map: capacity too small\n");
+  for (int i = 0; i < cnt; i++) {
+    L[i] = b->b.lm_map[i].first;
+    M[i] = b->b.lm_map[i].second;
+  }
+  HFG_CATCH
+}
+
+// One primitive table of TwoDBasis::compute_tei (basis.cpp:1166): which 0-3 prim_tei00/02/20/22, 4-7 prim_ktei**,
+// 8-11 disjoint_P0/P2/Q0/Q2, for channel ilm and element iel, column-major, in the reference's (unpadded) shape.
+// Tables built by hfg_compute_tei_dev are read back from the device layout (hip/tables.h) and unpadded.
+int hfg_basis_get_prim(hfg_ctx *ctx, const hfg_basis *b, int which, int ilm, int iel, double *out, int64_t *rows, int64_t *cols) {
+  HFG_TRY
+  if (b->kind) throw std::logic_error("hfg_basis_get_prim: diatomic bases only\n");
+  const helfem::diatomic::TwoDBasis &B = b->b;
+  const size_t E = B.Nel(), Nlm = B.lm_map.size();
+  if (which < 0 || which > 11 || ilm < 0 || (size_t)ilm >= Nlm || iel < 0 || (size_t)iel >= E)
+    throw std::logic_error("hfg_basis_get_prim: index out of range\n");
+  const size_t idx = (size_t)ilm * E + iel;
+  if (which >= 8) {
+    if (!B.have_tei && !B.have_disjoint) throw std::logic_error("Primitive teis have not been computed!\n");
+    const std::vector<helfem::Mat> *t[4] = {&B.disjoint_P0, &B.disjoint_P2, &B.disjoint_Q0, &B.disjoint_Q2};
+    const helfem::Mat &m = (*t[which - 8])[idx];
+    *rows = (int64_t)m.n_rows;
+    *cols = (int64_t)m.n_cols;
+    if (out) std::copy(m.d.begin(), m.d.end(), out);
+  } else if (b->tei_on_device) {
+    if (!ctx) throw std::logic_error("hfg_basis_get_prim: the tables live on the device, a context is needed\n");
+    if (which >= 4) throw std::logic_error("hfg_basis_get_prim: exchange-ordered tables are formed inside the exchange kernels\n");
+    const size_t p = B.max_Nprim(), pp = p * p, Ni = B.fem.nprim(iel), Np = Ni * Ni;
+    *rows = *cols = (int64_t)Np;
+    if (out) {
+      std::vector<double> pad(pp * pp);
+      HFG_HIP_CHECK(hipSetDevice(ctx->device));
+      HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      HFG_HIP_CHECK(hipMemcpy(pad.data(), b->dev_tei.p + (((size_t)which * Nlm + ilm) * E + iel) * pp * pp, sizeof(double) * pp * pp,
+                              hipMemcpyDeviceToHost));
+      for (size_t cj = 0; cj < Ni; cj++)
+        for (size_t ci = 0; ci < Ni; ci++)
+          for (size_t rj = 0; rj < Ni; rj++)
+            for (size_t ri = 0; ri < Ni; ri++) out[(cj * Ni + ci) * Np + rj * Ni + ri] = pad[(cj * p + ci) * pp + rj * p + ri];
+    }
+  } else {
+    if (!B.have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
+    if (which >= 4 && !B.have_ktei) throw std::logic_error("Primitive exchange teis have not been computed!\n");
+    const std::vector<helfem::Mat> *t[8] = {&B.prim_tei00,  &B.prim_tei02,  &B.prim_tei20,  &B.prim_tei22,
+                                            &B.prim_ktei00, &B.prim_ktei02, &B.prim_ktei20, &B.prim_ktei22};
+    const helfem::Mat &m = (*t[which])[idx];
+    *rows = (int64_t)m.n_rows;
+    *cols = (int64_t)m.n_cols;
+    if (out) std::copy(m.d.begin(), m.d.end(), out);
+  }
+  HFG_CATCH
+}
+
 int hfg_radial_grid(double mumax, int nelem, int igrid, double zexp, double *bval) {
   HFG_TRY
   helfem::Vec g = helfem::get_grid(mumax, nelem, igrid, zexp);

@@ -13,12 +13,26 @@
 // so that lane&15 runs along the rows of C, contiguous in column-major memory, and a result
 // register stores 16 consecutive doubles (128 B) per 16-lane group.
 //
+// Matrix instruction.  On gfx950 v_mfma_f64_16x16x4_f64 sustains 35.8 TFLOP/s in a register-only loop, the four-block
+// v_mfma_f64_4x4x4_4b_f64 76.6 TFLOP/s -- the data-sheet FP64 matrix rate -- and v_fma_f64 44-60 TFLOP/s (the vector
+// loop throttles the shader clock to 1.8-2.1 GHz; profiles/r02_fp64_rate.txt, tests/gpu_probe/fp64_rate.hip).  The
+// tile engine therefore issues the 4x4x4 form (MF = 0).  Its lane maps (tests/gpu_probe/mfma4x4_probe.hip,
+// profiles/r02_mfma4x4_lane_maps.txt):  a-operand lane 16 k + 4 blk + i holds A_blk[i][k], b-operand lane
+// 16 k + 4 blk + j holds B_blk[k][j], result lane 16 i + 4 blk + j holds D_blk[i][j].  With the b-operand taken from
+// the A tile exactly as for the 16x16x4 form (lane l: As[k0 + (l >> 4)][m0 + (l & 15)], the four blocks being four groups
+// of four consecutive rows) and the a-operand Bs[k0 + (l >> 4)][n0 + 4 c + (l & 3)] (the same 4 x 4 block of B in all
+// four blocks), instruction c = 0..3 accumulates C[m0 + (l & 15)][n0 + 4 c + (l >> 4)]: the four instructions together
+// fill the same four result registers, in the same layout, as one 16x16x4 instruction, so the epilogues are shared.
+// MF = 1 keeps the 16x16x4 form (HELFEM_MFMA=16x16x4) for A/B runs.
+//
 // Tiling: 256 threads = 4 waves in a 2x2 arrangement, block tile BM x BN (128x128 or 64x64,
 // chosen by the launcher so that small problems still give >= 256 workgroups), BK = 16.
 // LDS tiles are stored [k][m] with the row padded by 16 doubles: the four k-rows a wave reads at
 // once then fall on disjoint 128-B bank groups (conflict-free ds_read_b64).
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace hfg {
 
@@ -29,7 +43,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // before the first store: interleaved "load, scale, store" through the bounds branches serialises 64 memory round
 // trips per thread, which made the rank-2NB trailing updates and the compact-WY updates of the eigensolver (K = 32
 // or 64: pure streaming of C) run at 1.2-1.6 TB/s.
-template <int BM, int BN, bool ACC = false>
+template <int BM, int BN, bool ACC = false, int MF = 0>
 __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
                                            const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
                                            double beta, double *__restrict__ C, int ldc, double (*As)[BM + 16],
@@ -161,16 +175,33 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
     if (k0 + BK < K) load_tiles(k0 + BK);  // prefetch into registers while the MFMAs run
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      double fa[TM], fb[TN];
+      double fa[TM];
 #pragma unroll
       for (int i = 0; i < TM; i++) fa[i] = As[kk + l4][wm + i * 16 + l15];
+      if constexpr (MF == 1) {
+        double fb[TN];
 #pragma unroll
-      for (int j = 0; j < TN; j++) fb[j] = Bs[kk + l4][wn + j * 16 + l15];
+        for (int j = 0; j < TN; j++) fb[j] = Bs[kk + l4][wn + j * 16 + l15];
 #pragma unroll
-      for (int i = 0; i < TM; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      } else {
+        // column group by column group: only four a-operands are live at a time (all sixteen of a 128-wide tile at once
+        // cost 22 spilled registers)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          double fb[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) fb[c] = Bs[kk + l4][wn + j * 16 + 4 * c + (lane & 3)];
+#pragma unroll
+          for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+              acc[i][j][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fb[c], fa[i], acc[i][j][c], 0, 0, 0);
+        }
+      }
     }
   }
   // acc[i][j][r] = C[bm+wm+16i+l15][bn+wn+16j+l4+4r]
@@ -227,17 +258,17 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
       }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int MF = 0>
 __global__ __launch_bounds__(256, 2) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
                                                const double *__restrict__ A, int lda, const double *__restrict__ B,
                                                int ldb, double beta, double *__restrict__ C, int ldc) {
   __shared__ double As[16][BM + 16];
   __shared__ double Bs[16][BN + 16];
-  dgemm_tile<BM, BN>(blockIdx.x, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, As, Bs);
+  dgemm_tile<BM, BN, false, MF>(blockIdx.x, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, As, Bs);
 }
 
 // the same tile engine over a device-side task list: C_t = A_t B_t, grid (max tiles, tasks)
-template <int BM, int BN, bool ACC = false>
+template <int BM, int BN, bool ACC = false, int MF = 0>
 __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__restrict__ tasks) {
   __shared__ double As[16][BM + 16];
   __shared__ double Bs[16][BN + 16];
@@ -247,8 +278,14 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__res
   const int nbm = (t.M + BM - 1) / BM;
   const int nt = sym ? nbm * (nbm + 1) / 2 : nbm * ((t.N + BN - 1) / BN);
   if ((int)blockIdx.x >= nt) return;
-  dgemm_tile<BM, BN, ACC>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As,
-                          Bs, sym);
+  dgemm_tile<BM, BN, ACC, MF>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc,
+                              As, Bs, sym);
+}
+
+/// HELFEM_MFMA=16x16x4 selects the v_mfma_f64_16x16x4_f64 form of the tile engine (half the issue rate; A/B runs)
+static bool mfma16() {
+  static const bool v = (getenv("HELFEM_MFMA") && !strcmp(getenv("HELFEM_MFMA"), "16x16x4"));
+  return v;
 }
 
 /// task lists whose products accumulate into C (beta != 0 in every active task): streaming epilogue
@@ -257,10 +294,12 @@ void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int
   ProfScope ps(ctx, "gemm");
   if (tile64) {
     const int tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
-    hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+    if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, true, 1>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+    else hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   } else {
     const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
-    hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+    if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true, 1>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+    else hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   }
   HFG_HIP_CHECK(hipGetLastError());
 }
@@ -304,7 +343,8 @@ void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int m
   if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
   ProfScope ps(ctx, "gemm");
   const int tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
-  hipLaunchKernelGGL((k_dgemm_tasklist<64, 64>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, false, 1>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  else hipLaunchKernelGGL((k_dgemm_tasklist<64, 64>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   HFG_HIP_CHECK(hipGetLastError());
 }
 
@@ -315,7 +355,8 @@ void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int max
   const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
   for (int t0 = 0; t0 < ntasks; t0 += 65535) {
     int nt = std::min(65535, ntasks - t0);
-    hipLaunchKernelGGL((k_dgemm_tasklist<128, 128>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
+    if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, false, 1>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
+    else hipLaunchKernelGGL((k_dgemm_tasklist<128, 128>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
   }
   HFG_HIP_CHECK(hipGetLastError());
 }
@@ -326,12 +367,20 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
   ProfScope ps(ctx, "gemm");
   long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (big_tiles >= 512) {
-    hipLaunchKernelGGL((k_dgemm<128, 128>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M,
-                       N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    if (mfma16())
+      hipLaunchKernelGGL((k_dgemm<128, 128, 1>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
+                         alpha, A, lda, B, ldb, beta, C, ldc);
+    else
+      hipLaunchKernelGGL((k_dgemm<128, 128>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
+                         alpha, A, lda, B, ldb, beta, C, ldc);
   } else {
     long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    hipLaunchKernelGGL((k_dgemm<64, 64>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
-                       alpha, A, lda, B, ldb, beta, C, ldc);
+    if (mfma16())
+      hipLaunchKernelGGL((k_dgemm<64, 64, 1>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K, alpha, A,
+                         lda, B, ldb, beta, C, ldc);
+    else
+      hipLaunchKernelGGL((k_dgemm<64, 64>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K, alpha, A,
+                         lda, B, ldb, beta, C, ldc);
   }
   HFG_HIP_CHECK(hipGetLastError());
 }

@@ -120,6 +120,14 @@ int hfg_compute_rs_tei(hfg_basis *basis, int rs_kind, double omega);
  * O(Nlm nq p^4) sums run on the device and the tables stay there); follow with hfg_basis_upload */
 int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis, int exchange);
 /* helpers of main.cpp:276-277: mu grid for --grid/--zexp, and (l,m) shell list for lmmax */
+/* Read-back of the setup tables (test and diagnostic access; basis.cpp:1166-1302 fills them):
+ *   hfg_basis_lm_map: the sorted (L,|M|) channel list of the constructor (basis.cpp:333-375); n in: capacity, out: count
+ *   hfg_basis_get_prim: which 0-3 prim_tei00/02/20/22, 4-7 prim_ktei00/02/20/22, 8-11 disjoint_P0/P2/Q0/Q2 of channel ilm and
+ *   element iel, column-major in the reference's shape (rows/cols returned; out may be NULL to query the shape).  Tables built
+ *   by hfg_compute_tei_dev are copied back from the device (ctx required). */
+int hfg_basis_lm_map(const hfg_basis *basis, int *L, int *M, int *n);
+int hfg_basis_get_prim(hfg_ctx *ctx, const hfg_basis *basis, int which, int ilm, int iel, double *out, int64_t *rows,
+                       int64_t *cols);
 int hfg_radial_grid(double mumax, int nelem, int igrid, double zexp, double *bval /* nelem+1 */);
 int hfg_lm_list(const int *lmmax, int nlm, int *lval, int *mval, int *nang /* in: capacity, out: count */);
 

@@ -224,6 +224,32 @@ def test_tei_tables_built_on_device_match_host_tables(hf):
             assert common.relerr(Jd, Jh) < 1e-13 and common.relerr(Kd, Kh) < 1e-12, (kw, tag)
 
 
+def test_tei_tables_against_the_independent_fixture(hf):
+    """hfg_compute_tei_dev and the host tables against tests/golden/diatomic_tei.npz: tables of the NumPy restatement
+    oracle/diatomic_tei.py of quadrature.cpp:22-123 / basis.cpp:1166-1302, which shares no code with the product (the
+    'exact' set uses 40-digit Legendre functions, the 'ref' set the reference's own Fortran library)"""
+    import os
+    import test_tei_golden_cpu as tg
+    gold = np.load(tg.GOLD)
+    names = ["tei00", "tei02", "tei20", "tei22"]
+    gd = tg.golden_basis(hf, gold)
+    gd.compute_tei(True, device=True)
+    dev = tg.table_errors(gd.prim_table, gold, "exact", names + ["P0", "P2", "Q0", "Q2"])
+    assert tg.tight(dev) < 5e-12 and max(dev.values()) < 1e-8, dev
+    ref = tg.table_errors(gd.prim_table, gold, "ref", names)
+    assert max(ref.values()) < tg.REF_TEI_TOL, ref
+    gh = tg.golden_basis(hf, gold)
+    gh.compute_tei(True)
+    host = tg.table_errors(gh.prim_table, gold, "exact", list(hf.TwoDBasis.PRIM_TABLES))
+    assert tg.tight(host) < 5e-12 and max(host.values()) < 1e-8, host
+    # and the Coulomb / exchange matrices built from the device tables equal those from the host tables
+    gd.upload()
+    gh.upload()
+    P = __import__("common").random_density(gh.Nbf(), 2, seed=11, blocks=gh.get_sym_idx(1))
+    assert __import__("common").relerr(gd.coulomb(P), gh.coulomb(P)) < 1e-13
+    assert __import__("common").relerr(gd.exchange(P), gh.exchange(P)) < 1e-12
+
+
 @pytest.mark.parametrize("env", [dict(HELFEM_TRD="twokernel"), dict(HELFEM_BT="column"),
                                  dict(HELFEM_TRD="unblocked", HELFEM_BT="column"), dict(HELFEM_TRDF_SYM="1"),
                                  dict(HELFEM_TRDF_SYM="0"), dict(HELFEM_TRDF_NTH="512", HELFEM_TRDF_SYM="1"),
