@@ -1,6 +1,7 @@
 // C ABI (include/helfem_gpu.h): contexts, host-side basis API, host-pointer and device-pointer
 // entry points.  No torch types, no exceptions across the boundary.
 #include "common.h"
+#include "../host/diis.h"
 #include "tables.h"
 #include <cstring>
 #include <mutex>
@@ -405,6 +406,31 @@ int hfg_basis_get_prim(hfg_ctx *ctx, const hfg_basis *b, int which, int ilm, int
   HFG_CATCH
 }
 
+// One evaluation of the reference's ADIIS + CDIIS weights (DIIS::get_w / solve_F, src/general/diis.cpp:214-290, 392-412)
+// for a history of n entries, oldest first: B (n x n, err_i . err_j), T (n x n, T(i,j) = Tr P_i F_j, row-major), the
+// energies E and the maximum absolute error of the newest entry.  mode 0 = mixed (the drivers' setting), 1 = CDIIS only,
+// 2 = ADIIS only.  w receives n weights, the first *dropped of them zero (entries the extrapolation dropped).
+int hfg_diis_weights(int n, const double *B, const double *T, const double *E, double maxerr, double diiseps, double diisthr,
+                     int mode, double *w, int *dropped) {
+  HFG_TRY
+  if (n < 1) throw std::logic_error("hfg_diis_weights: empty history\n");
+  helfem::DiisMixer mix(mode != 2, diiseps, diisthr, mode != 1, false, (size_t)n);
+  for (int i = 0; i < n; i++) {
+    mix.push(E[i], maxerr);
+    for (int j = 0; j <= i; j++) {
+      mix.set_B((size_t)i, (size_t)j, B[i * n + j]);
+      mix.set_T((size_t)i, (size_t)j, T[i * n + j]);
+      mix.set_T((size_t)j, (size_t)i, T[j * n + i]);
+    }
+  }
+  size_t dr = 0;
+  std::vector<double> sol = mix.solve(dr);
+  for (int i = 0; i < n; i++) w[i] = 0.0;
+  for (size_t i = 0; i < sol.size(); i++) w[dr + i] = sol[i];
+  if (dropped) *dropped = (int)dr;
+  HFG_CATCH
+}
+
 int hfg_radial_grid(double mumax, int nelem, int igrid, double zexp, double *bval) {
   HFG_TRY
   helfem::Vec g = helfem::get_grid(mumax, nelem, igrid, zexp);
@@ -531,8 +557,27 @@ int hfg_fock_finish_dev(hfg_ctx *ctx, hfg_basis *b, const double *dFc, const dou
 }
 
 // ---- host-pointer API ------------------------------------------------------------------------------
+// The host-pointer entry points return COMPLETE matrices (they are what an arma::mat caller binds):
+// a shard set on the context for the device-resident multi-GPU step (hfg_ctx_set_shard) must not leak into them, so
+// they run with the shard (0, 1) and restore the caller's setting afterwards.  Partial (sharded) results are available
+// from the *_dev entry points only.
+namespace {
+struct FullShard {
+  hfg_ctx *c;
+  int r, n;
+  explicit FullShard(hfg_ctx *ctx) : c(ctx), r(ctx->shard_rank), n(ctx->shard_n) {
+    c->shard_rank = 0;
+    c->shard_n = 1;
+  }
+  ~FullShard() {
+    c->shard_rank = r;
+    c->shard_n = n;
+  }
+};
+}  // namespace
 int hfg_coulomb(hfg_ctx *ctx, hfg_basis *b, const double *P, double *J) {
   HFG_TRY
+  FullShard full(ctx);
   size_t N = b->Nbf();
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dJ = st.alloc(N * N);
@@ -543,6 +588,7 @@ int hfg_coulomb(hfg_ctx *ctx, hfg_basis *b, const double *P, double *J) {
 }
 int hfg_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
   HFG_TRY
+  FullShard full(ctx);
   size_t N = b->Nbf();
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dK = st.alloc(N * N);
@@ -553,6 +599,7 @@ int hfg_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
 }
 int hfg_rs_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
   HFG_TRY
+  FullShard full(ctx);
   size_t N = b->Nbf();
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dK = st.alloc(N * N);
@@ -563,6 +610,7 @@ int hfg_rs_exchange(hfg_ctx *ctx, hfg_basis *b, const double *P, double *K) {
 }
 int hfg_model_potential(hfg_ctx *ctx, hfg_basis *b, const hfg_model_pot *p1, const hfg_model_pot *p2, double *H) {
   HFG_TRY
+  FullShard full(ctx);
   if (!p1) throw std::logic_error("hfg_model_potential: no potential given\n");
   size_t N = b->Nbf();
   if (b->kind == 1) {  // atomic: radial integrals on the host, as the reference does
@@ -586,6 +634,7 @@ int hfg_model_potential(hfg_ctx *ctx, hfg_basis *b, const hfg_model_pot *p1, con
 int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *P, double *H, double *Exc,
                 double *Nel, double *Ekin, double thr) {
   HFG_TRY
+  FullShard full(ctx);
   size_t N = b->Nbf();
   Stage st(ctx);
   double *dP = st.up(P, N * N), *dH = st.alloc(N * N), *dS = st.alloc(3);
@@ -602,6 +651,7 @@ int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double
 int hfg_xc_fock_pol(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const double *Pa, const double *Pb, double *Ha,
                     double *Hb, double *Exc, double *Nel, double *Ekin, double thr) {
   HFG_TRY
+  FullShard full(ctx);
   size_t N = b->Nbf();
   Stage st(ctx);
   double *dPa = st.up(Pa, N * N), *dPb = st.up(Pb, N * N);

@@ -31,12 +31,14 @@
 // once then fall on disjoint 128-B bank groups (conflict-free ds_read_b64).
 #include "common.h"
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
 namespace hfg {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // one BM x BN tile (linear tile index id) of one product; As/Bs are the workgroup's LDS tiles
 // ACC: the epilogue reads C (beta != 0).  All loads of the old tile are issued back to back with clamped indices
@@ -46,13 +48,12 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 template <int BM, int BN, bool ACC = false, int MF = 0>
 __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
                                            const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-                                           double beta, double *__restrict__ C, int ldc, double (*As)[BM + 16],
-                                           double (*Bs)[BN + 16], int sym = 0) {
+                                           double beta, double *__restrict__ C, int ldc, double (*As)[16][BM + 16],
+                                           double (*Bs)[16][BN + 16], int sym = 0) {
   constexpr int BK = 16;
   constexpr int PAD = 16;
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
   constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr int EA = BM * BK / 256, EB = BN * BK / 256;  // elements per thread per tile
   static_assert(PAD == 16, "LDS row padding is part of the tile types");
 
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
@@ -81,11 +82,29 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
   const int wm = (wave & 1) * WM, wn = (wave >> 1) * WN;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  double4_t acc[TM][TN];
+  // accumulators: one double4 per 16 x 16 block for the 16x16x4 form; four separate doubles for the 4x4x4 form (as
+  // elements of a double4 every instruction got a fresh destination register next to its source accumulator and the
+  // 128-wide tile spilled 14 registers inside the K loop -- spill reloads share vmcnt with the operand prefetch)
+  constexpr bool V4 = (MF == 1);
+  double4_t accv[V4 ? TM : 1][V4 ? TN : 1];
+  double accs[V4 ? 1 : TM][V4 ? 1 : TN][4];
+  if constexpr (V4) {
 #pragma unroll
-  for (int i = 0; i < TM; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-    for (int j = 0; j < TN; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < TN; j++) accv[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) accs[i][j][c] = 0.0;
+  }
+  auto acc = [&](int i, int j, int r) -> double {
+    if constexpr (V4) return accv[i][j][r];
+    else return accs[i][j][r];
+  };
 
   // ACC with 64 x 64 tiles: the 16 old values of C per thread are requested before the K loop, so their latency
   // hides behind the operand loads and the MFMAs (the product is a rank-32/64 update: C is all the traffic there is)
@@ -103,106 +122,146 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
         }
   }
 
-  double ra[EA], rb[EB];
+  // ---- operand staging: global -> registers -> LDS (k-major tiles As[k][m], Bs[k][n]), double buffered -------------
+  // An operand is either contiguous along the tile's long dimension (A not transposed, B transposed: "kind C") or along
+  // k (A transposed, B not transposed: "kind K").  A thread moves 16-byte vectors:
+  //   kind C: vector v = (row pair 2 mv, column k), mv = v % (B?/2): 64 lanes read 1 KiB of one column, one
+  //           ds_write_b128 per vector;
+  //   kind K: vector v = (row m, k pair 2 kv), m = v % B?: lanes run along m, so that the two 8-byte LDS writes of a
+  //           vector (rows 2 kv and 2 kv + 1 of the tile) are conflict free; the 16-byte global reads of a wave then hit
+  //           64 different lines, each of which is used up by the thread's other vectors and by its neighbours.
+  // Fast path (no bounds tests, 16-byte loads): the tile lies inside the operand for this k step, the leading dimension
+  // is even and the base address 16-byte aligned; otherwise element-wise loads with bounds tests fill the same registers.
+  constexpr int VA = BM * BK / 2 / 256, VB = BN * BK / 2 / 256;  // vectors per thread and tile
+  const bool fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) && (bm + BM <= M);
+  const bool fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0) && (bn + BN <= N);
+  // per-thread origin inside a tile
+  const int a_mv = tid % (BM / 2), a_kc = tid / (BM / 2);  // kind C: rows 2 a_mv, column a_kc + r * (512 / BM)
+  const int a_m = tid % BM, a_kv = tid / BM;               // kind K: row a_m, k pair a_kv + r * (256 / BM)
+  const int b_nv = tid % (BN / 2), b_kc = tid / (BN / 2);
+  const int b_n = tid % BN, b_kv = tid / BN;
+  const double *pA = transA ? A + (size_t)(bm + a_m) * lda + 2 * a_kv : A + (size_t)a_kc * lda + bm + 2 * a_mv;
+  const double *pB = transB ? B + (size_t)b_kc * ldb + bn + 2 * b_nv : B + (size_t)(bn + b_n) * ldb + 2 * b_kv;
+  d2_t va[VA], vb[VB];
   auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int r = 0; r < EA; r++) {
-      int e = tid + 256 * r;
-      int m, k;
+    const bool fullk = (k0 + BK <= K);
+    if (fastA && fullk) {
       if (!transA) {
-        m = e % BM;
-        k = e / BM;
-      } else {
-        k = e % BK;
-        m = e / BK;
-      }
-      int gm = bm + m, gk = k0 + k;
-      double v = 0.0;
-      if (gm < M && gk < K) v = transA ? A[(size_t)gm * lda + gk] : A[(size_t)gk * lda + gm];
-      ra[r] = v;
-    }
 #pragma unroll
-    for (int r = 0; r < EB; r++) {
-      int e = tid + 256 * r;
-      int n, k;
-      if (!transB) {
-        k = e % BK;
-        n = e / BK;
+        for (int r = 0; r < VA; r++) va[r] = *reinterpret_cast<const d2_t *>(pA + (size_t)(k0 + r * (512 / BM)) * lda);
       } else {
-        n = e % BN;
-        k = e / BN;
+#pragma unroll
+        for (int r = 0; r < VA; r++) va[r] = *reinterpret_cast<const d2_t *>(pA + k0 + 2 * r * (256 / BM));
       }
-      int gn = bn + n, gk = k0 + k;
-      double v = 0.0;
-      if (gn < N && gk < K) v = transB ? B[(size_t)gk * ldb + gn] : B[(size_t)gn * ldb + gk];
-      rb[r] = v;
+    } else {
+#pragma unroll
+      for (int r = 0; r < VA; r++) {
+        int gm0, gk0, gm1, gk1;
+        if (!transA) {
+          gm0 = bm + 2 * a_mv;
+          gm1 = gm0 + 1;
+          gk0 = gk1 = k0 + a_kc + r * (512 / BM);
+        } else {
+          gm0 = gm1 = bm + a_m;
+          gk0 = k0 + 2 * (a_kv + r * (256 / BM));
+          gk1 = gk0 + 1;
+        }
+        d2_t v;
+        v.x = (gm0 < M && gk0 < K) ? (transA ? A[(size_t)gm0 * lda + gk0] : A[(size_t)gk0 * lda + gm0]) : 0.0;
+        v.y = (gm1 < M && gk1 < K) ? (transA ? A[(size_t)gm1 * lda + gk1] : A[(size_t)gk1 * lda + gm1]) : 0.0;
+        va[r] = v;
+      }
+    }
+    if (fastB && fullk) {
+      if (transB) {
+#pragma unroll
+        for (int r = 0; r < VB; r++) vb[r] = *reinterpret_cast<const d2_t *>(pB + (size_t)(k0 + r * (512 / BN)) * ldb);
+      } else {
+#pragma unroll
+        for (int r = 0; r < VB; r++) vb[r] = *reinterpret_cast<const d2_t *>(pB + k0 + 2 * r * (256 / BN));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < VB; r++) {
+        int gn0, gk0, gn1, gk1;
+        if (transB) {
+          gn0 = bn + 2 * b_nv;
+          gn1 = gn0 + 1;
+          gk0 = gk1 = k0 + b_kc + r * (512 / BN);
+        } else {
+          gn0 = gn1 = bn + b_n;
+          gk0 = k0 + 2 * (b_kv + r * (256 / BN));
+          gk1 = gk0 + 1;
+        }
+        d2_t v;
+        v.x = (gn0 < N && gk0 < K) ? (transB ? B[(size_t)gk0 * ldb + gn0] : B[(size_t)gn0 * ldb + gk0]) : 0.0;
+        v.y = (gn1 < N && gk1 < K) ? (transB ? B[(size_t)gk1 * ldb + gn1] : B[(size_t)gn1 * ldb + gk1]) : 0.0;
+        vb[r] = v;
+      }
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
+    if (!transA) {
 #pragma unroll
-    for (int r = 0; r < EA; r++) {
-      int e = tid + 256 * r;
-      int m, k;
-      if (!transA) {
-        m = e % BM;
-        k = e / BM;
-      } else {
-        k = e % BK;
-        m = e / BK;
+      for (int r = 0; r < VA; r++) *reinterpret_cast<d2_t *>(&As[buf][a_kc + r * (512 / BM)][2 * a_mv]) = va[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < VA; r++) {
+        As[buf][2 * (a_kv + r * (256 / BM))][a_m] = va[r].x;
+        As[buf][2 * (a_kv + r * (256 / BM)) + 1][a_m] = va[r].y;
       }
-      As[k][m] = ra[r];
     }
+    if (transB) {
 #pragma unroll
-    for (int r = 0; r < EB; r++) {
-      int e = tid + 256 * r;
-      int n, k;
-      if (!transB) {
-        k = e % BK;
-        n = e / BK;
-      } else {
-        n = e % BN;
-        k = e / BN;
+      for (int r = 0; r < VB; r++) *reinterpret_cast<d2_t *>(&Bs[buf][b_kc + r * (512 / BN)][2 * b_nv]) = vb[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < VB; r++) {
+        Bs[buf][2 * (b_kv + r * (256 / BN))][b_n] = vb[r].x;
+        Bs[buf][2 * (b_kv + r * (256 / BN)) + 1][b_n] = vb[r].y;
       }
-      Bs[k][n] = rb[r];
     }
   };
 
   load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  int buf = 0;
   for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
-    store_tiles();
-    __syncthreads();
-    if (k0 + BK < K) load_tiles(k0 + BK);  // prefetch into registers while the MFMAs run
+    const bool more = (k0 + BK < K);
+    if (more) load_tiles(k0 + BK);  // the next step's operands travel while this step's MFMAs run
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
       double fa[TM];
 #pragma unroll
-      for (int i = 0; i < TM; i++) fa[i] = As[kk + l4][wm + i * 16 + l15];
+      for (int i = 0; i < TM; i++) fa[i] = As[buf][kk + l4][wm + i * 16 + l15];
       if constexpr (MF == 1) {
         double fb[TN];
 #pragma unroll
-        for (int j = 0; j < TN; j++) fb[j] = Bs[kk + l4][wn + j * 16 + l15];
+        for (int j = 0; j < TN; j++) fb[j] = Bs[buf][kk + l4][wn + j * 16 + l15];
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            accv[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], accv[i][j], 0, 0, 0);
       } else {
-        // column group by column group: only four a-operands are live at a time (all sixteen of a 128-wide tile at once
-        // cost 22 spilled registers)
+        // column group by column group: only four a-operands are live at a time
 #pragma unroll
         for (int j = 0; j < TN; j++) {
           double fb[4];
 #pragma unroll
-          for (int c = 0; c < 4; c++) fb[c] = Bs[kk + l4][wn + j * 16 + 4 * c + (lane & 3)];
+          for (int c = 0; c < 4; c++) fb[c] = Bs[buf][kk + l4][wn + j * 16 + 4 * c + (lane & 3)];
 #pragma unroll
           for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int c = 0; c < 4; c++)
-              acc[i][j][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fb[c], fa[i], acc[i][j][c], 0, 0, 0);
+              accs[i][j][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fb[c], fa[i], accs[i][j][c], 0, 0, 0);
         }
       }
     }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();  // one barrier per step: buffer buf has been read by every wave, buffer buf ^ 1 is complete
+    buf ^= 1;
   }
   // acc[i][j][r] = C[bm+wm+16i+l15][bn+wn+16j+l4+4r]
   if constexpr (PRE) {
@@ -213,7 +272,7 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           int gm = bm + wm + i * 16 + l15, gn = bn + wn + j * 16 + l4 + 4 * r;
-          if (gm < M && gn < N) C[(size_t)gn * ldc + gm] = alpha * acc[i][j][r] + beta * cpre[i][j][r];
+          if (gm < M && gn < N) C[(size_t)gn * ldc + gm] = alpha * acc(i, j, r) + beta * cpre[i][j][r];
         }
     return;
   } else if constexpr (ACC) {
@@ -237,7 +296,7 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             int gm = bm + wm + (i0 + i) * 16 + l15, gn = bn + wn + j * 16 + l4 + 4 * r;
-            if (gm < M && gn < N) C[(size_t)gn * ldc + gm] = alpha * acc[i0 + i][j][r] + beta * cv[i][j][r];
+            if (gm < M && gn < N) C[(size_t)gn * ldc + gm] = alpha * acc(i0 + i, j, r) + beta * cv[i][j][r];
           }
     }
     return;
@@ -251,7 +310,7 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
         int gm = bm + wm + i * 16 + l15, gn = bn + wn + j * 16 + l4 + 4 * r;
         if (gm < M && gn < N) {
           size_t o = (size_t)gn * ldc + gm;
-          double v = alpha * acc[i][j][r];
+          double v = alpha * acc(i, j, r);
           if (beta != 0.0) v += beta * C[o];
           C[o] = v;
         }
@@ -262,16 +321,16 @@ template <int BM, int BN, int MF = 0>
 __global__ __launch_bounds__(256, 2) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
                                                const double *__restrict__ A, int lda, const double *__restrict__ B,
                                                int ldb, double beta, double *__restrict__ C, int ldc) {
-  __shared__ double As[16][BM + 16];
-  __shared__ double Bs[16][BN + 16];
+  __shared__ __attribute__((aligned(16))) double As[2][16][BM + 16];
+  __shared__ __attribute__((aligned(16))) double Bs[2][16][BN + 16];
   dgemm_tile<BM, BN, false, MF>(blockIdx.x, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, As, Bs);
 }
 
 // the same tile engine over a device-side task list: C_t = A_t B_t, grid (max tiles, tasks)
 template <int BM, int BN, bool ACC = false, int MF = 0>
 __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__restrict__ tasks) {
-  __shared__ double As[16][BM + 16];
-  __shared__ double Bs[16][BN + 16];
+  __shared__ __attribute__((aligned(16))) double As[2][16][BM + 16];
+  __shared__ __attribute__((aligned(16))) double Bs[2][16][BN + 16];
   const GemmTask t = tasks[blockIdx.y];
   if (t.M <= 0 || t.N <= 0) return;
   const int sym = (!ACC && BM == BN && t.M == t.N && t.beta == 0.0) ? t.sym : 0;

@@ -6,6 +6,7 @@
 // this one (HELFEM_SCF=host).
 #include "tables.h"
 #include "../host/dftfuncs.h"
+#include "../host/diis.h"
 #include "../host/scf.h"
 #include <chrono>
 #include <cmath>
@@ -116,7 +117,7 @@ struct DevSCF {
   size_t N = 0, NN = 0;
   DevBuf<double> S, T, V, H0, Sinvh, Ca, Cb, Ea, Eb, Pa, Pb, P, J, Ka, Kb, XCa, XCb, Fa, Fb, T1, T2, Err, scal, partial, res;
   DevBuf<int> blockid;
-  std::unique_ptr<DevBuf<double>[]> histF, histE;  // DIIS history (ring)
+  std::unique_ptr<DevBuf<double>[]> histF, histE, histP;  // DIIS history (ring): Fock matrices, errors, densities
   std::vector<double> hres;
 
   explicit DevSCF(hfg_ctx *c) : ctx(c), s(c->stream) {}
@@ -206,7 +207,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   d.Ea.resize(N);
   d.scal.resize(4);
   d.partial.resize(RED_BLOCKS);
-  d.res.resize(64);
+  d.res.resize(8 + 3 * (size_t)std::max(1, opt.diisorder) + 8);
   if (!restr) {
     for (DevBuf<double> *b : {&d.Cb, &d.Pb, &d.Fb}) b->resize(NN);
     d.Eb.resize(N);
@@ -226,9 +227,11 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   const int order = opt.diisorder;
   d.histF.reset(new DevBuf<double>[order]);
   d.histE.reset(new DevBuf<double>[order]);
+  d.histP.reset(new DevBuf<double>[order]);
   for (int k = 0; k < order; k++) {
     d.histF[k].resize(nspin * NN);
     d.histE[k].resize(nspin * NN);
+    d.histP[k].resize(nspin * NN);
   }
 
   std::unique_ptr<DevBuf<int>[]> avgdev(new DevBuf<int>[avg_idx.size() + 1]);
@@ -306,8 +309,10 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   }
   if (opt.iguess == 0) prepare_tables();
 
-  std::vector<std::vector<double> > B;  // DIIS inner products of the stored errors, indexed by ring slot
-  B.assign(order, std::vector<double>(order, 0.0));
+  // ADIIS + CDIIS weights of the reference (diis.cpp:214-290) on the host from inner products of the stored matrices;
+  // the restricted driver counts its one spin twice, as the reference does by passing Fa = Fb, Pa = Pb to uDIIS
+  helfem::DiisMixer mixer(true, opt.diiseps, opt.diisthr, true, verbose, (size_t)order);
+  const double spinfac = restr ? 2.0 : 1.0;
   std::deque<int> slots;  // ring slots in age order
   double Eold = 0.0;
   for (int it = 1; it <= opt.maxit; it++) {
@@ -398,23 +403,36 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       d.axpby(-1.0, d.T1.p, 1.0, d.Fb.p, NN);
     }
 
-    // DIIS: store (F, err) in a ring slot, new row of B, slot 5 = max |err|
+    // DIIS: store (F, P, err) in a ring slot; new row of B = err.err, new row and column of T = Tr P F; slot 5 = max |err|
     t0 = wall();
     int slot;
-    if ((int)slots.size() == order) {
+    if (mixer.full()) {
+      mixer.pop_oldest();
       slot = slots.front();
       slots.pop_front();
-    } else
-      slot = (int)slots.size();
+    } else {
+      slot = -1;  // lowest free ring slot (the extrapolation may have dropped old entries: DiisMixer::solve)
+      for (int q = 0; q < order && slot < 0; q++) {
+        bool used = false;
+        for (int v : slots) used = used || (v == q);
+        if (!used) slot = q;
+      }
+    }
     slots.push_back(slot);
     for (int sp = 0; sp < nspin; sp++) {
       double *F = sp ? d.Fb.p : d.Fa.p;
       d.diis_error(F, sp ? d.Pb.p : d.Pa.p, d.histE[slot].p + sp * NN);
       HFG_HIP_CHECK(hipMemcpyAsync(d.histF[slot].p + sp * NN, F, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+      HFG_HIP_CHECK(hipMemcpyAsync(d.histP[slot].p + sp * NN, sp ? d.Pb.p : d.Pa.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
     }
     d.maxabs(d.histE[slot].p, nspin * NN, 5);
-    for (size_t k = 0; k < slots.size(); k++) d.dot(d.histE[slot].p, d.histE[slots[k]].p, nspin * NN, 8 + (int)k);
-    d.fetch(8 + (int)slots.size());
+    const int nh0 = (int)slots.size();
+    for (int k = 0; k < nh0; k++) {
+      d.dot(d.histE[slot].p, d.histE[slots[k]].p, nspin * NN, 8 + k);
+      d.dot(d.histP[slots[k]].p, d.histF[slot].p, nspin * NN, 8 + nh0 + k);      // T(k, n)
+      d.dot(d.histP[slot].p, d.histF[slots[k]].p, nspin * NN, 8 + 2 * nh0 + k);  // T(n, k)
+    }
+    d.fetch(8 + 3 * nh0);
     if (dft) {
       double sc[3];
       HFG_HIP_CHECK(hipMemcpyAsync(sc, d.scal.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
@@ -431,13 +449,18 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     res.Exx = 0.0;
     if (anyK) res.Exx = restr ? d.hres[3] : 0.5 * d.hres[3] + 0.5 * d.hres[4];
     const double diiserr = d.hres[5];
-    for (size_t k = 0; k < slots.size(); k++) B[slot][slots[k]] = B[slots[k]][slot] = d.hres[8 + k];
     if (verbose) {
       printf("Coulomb energy %.10e % .6f\n", res.Ecoul, res.tJ);
       if (anyK) printf("Exchange energy %.10e % .6f\n", res.Exx, res.tK);
     }
     res.Etot = res.Ekin + res.Epot + res.Ecoul + res.Exx + res.Exc + res.Enucr;
     const double dE = res.Etot - Eold;
+    mixer.push(res.Etot, diiserr);
+    for (int k = 0; k < nh0; k++) {
+      mixer.set_B((size_t)k, (size_t)nh0 - 1, spinfac * d.hres[8 + k]);
+      mixer.set_T((size_t)k, (size_t)nh0 - 1, spinfac * d.hres[8 + nh0 + k]);
+      mixer.set_T((size_t)nh0 - 1, (size_t)k, spinfac * d.hres[8 + 2 * nh0 + k]);
+    }
     if (verbose) {
       printf("Total energy is % .10f\n", res.Etot);
       if (it > 1) printf("Energy changed by %e\n", dE);
@@ -445,48 +468,13 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     }
     Eold = res.Etot;
 
-    // Pulay coefficients on the host (tiny), extrapolated Fock matrices on the device
+    // weights on the host (tiny), extrapolated Fock matrices on the device
+    t0 = wall();
+    size_t dropped = 0;
+    const std::vector<double> coef = mixer.solve(dropped);
+    for (size_t k = 0; k < dropped; k++) slots.pop_front();
     const size_t nh = slots.size();
-    std::vector<double> coef(nh, 0.0);
-    if (nh == 1)
-      coef[0] = 1.0;
-    else {
-      const size_t m = nh + 1;
-      std::vector<double> A(m * m, 0.0), rhs(m, 0.0);
-      for (size_t a = 0; a < nh; a++)
-        for (size_t b2 = 0; b2 < nh; b2++) A[a * m + b2] = B[slots[a]][slots[b2]];
-      for (size_t a = 0; a < nh; a++) A[a * m + nh] = A[nh * m + a] = 1.0;
-      rhs[nh] = 1.0;
-      bool ok = true;
-      for (size_t c = 0; c < m && ok; c++) {
-        size_t p = c;
-        for (size_t r = c + 1; r < m; r++)
-          if (fabs(A[r * m + c]) > fabs(A[p * m + c])) p = r;
-        if (p != c) {
-          for (size_t k = 0; k < m; k++) std::swap(A[c * m + k], A[p * m + k]);
-          std::swap(rhs[c], rhs[p]);
-        }
-        if (A[c * m + c] == 0.0) {
-          ok = false;
-          break;
-        }
-        for (size_t r = c + 1; r < m; r++) {
-          double f = A[r * m + c] / A[c * m + c];
-          for (size_t k = c; k < m; k++) A[r * m + k] -= f * A[c * m + k];
-          rhs[r] -= f * rhs[c];
-        }
-      }
-      if (ok) {
-        std::vector<double> x(m);
-        for (size_t ii = m; ii-- > 0;) {
-          double sv = rhs[ii];
-          for (size_t k = ii + 1; k < m; k++) sv -= A[ii * m + k] * x[k];
-          x[ii] = sv / A[ii * m + ii];
-        }
-        for (size_t a = 0; a < nh; a++) coef[a] = x[a];
-      } else
-        coef[nh - 1] = 1.0;
-    }
+    if (verbose) printf("DIIS solution done in %.6f\n", wall() - t0);
     const bool convd = (diiserr < opt.convthr) && (fabs(dE) < opt.convthr);
 
     t0 = wall();

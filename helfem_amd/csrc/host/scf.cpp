@@ -1,4 +1,5 @@
 #include "scf.h"
+#include "diis.h"
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -14,60 +15,49 @@ double wall() {
   return duration_cast<duration<double> >(steady_clock::now().time_since_epoch()).count();
 }
 
-// Pulay DIIS on the commutator error e = Sinvh^T (FPS - SPF) Sinvh (reference: diis.cpp:129-168
-// builds the same error matrix; its ADIIS admixture only changes the path to convergence).
-struct DIIS {
-  size_t imax;
-  std::deque<Mat> Fs, errs;
-  explicit DIIS(size_t n) : imax(n) {}
-  void push(const Mat &F, const Mat &err) {
-    if (Fs.size() == imax) {
+// History of the Fock-matrix extrapolation (uDIIS of the reference, diis.cpp:129-168: Fock matrices, densities and error
+// vectors of both spins; the restricted drivers pass the same matrices for both spins, main.cpp:779-781, 938).  The
+// weights come from DiisMixer (ADIIS + CDIIS, diis.h), which only sees inner products.
+struct FockHistory {
+  DiisMixer mix;
+  std::deque<Mat> Fs, Ps, errs;  // [Fa | Fb], [Pa | Pb], [ea | eb]; restricted runs store one spin and count it twice
+  double spinfac;
+  FockHistory(const Options &opt, bool restricted)
+      : mix(true, opt.diiseps, opt.diisthr, true, opt.verbose, (size_t)opt.diisorder), spinfac(restricted ? 2.0 : 1.0) {}
+  static double dot(const Mat &a, const Mat &b) {
+    double s = 0.0;
+    for (size_t k = 0; k < a.d.size(); k++) s += a.d[k] * b.d[k];
+    return s;
+  }
+  void update(const Mat &F, const Mat &P, const Mat &err, double E, double maxerr) {
+    if (mix.full()) {
+      mix.pop_oldest();
       Fs.pop_front();
+      Ps.pop_front();
       errs.pop_front();
     }
     Fs.push_back(F);
+    Ps.push_back(P);
     errs.push_back(err);
-  }
-  Mat solve() const {
-    size_t n = Fs.size();
-    if (n == 1) return Fs[0];
-    size_t m = n + 1;
-    std::vector<double> A(m * m, 0.0), rhs(m, 0.0);
-    for (size_t i = 0; i < n; i++)
-      for (size_t j = 0; j <= i; j++) {
-        double s = 0.0;
-        for (size_t k = 0; k < errs[i].d.size(); k++) s += errs[i].d[k] * errs[j].d[k];
-        A[i * m + j] = A[j * m + i] = s;
-      }
-    for (size_t i = 0; i < n; i++) A[i * m + n] = A[n * m + i] = 1.0;
-    rhs[n] = 1.0;
-    // Gaussian elimination with partial pivoting
-    std::vector<size_t> piv(m);
-    for (size_t i = 0; i < m; i++) piv[i] = i;
-    for (size_t c = 0; c < m; c++) {
-      size_t p = c;
-      for (size_t r = c + 1; r < m; r++)
-        if (fabs(A[r * m + c]) > fabs(A[p * m + c])) p = r;
-      if (p != c) {
-        for (size_t k = 0; k < m; k++) std::swap(A[c * m + k], A[p * m + k]);
-        std::swap(rhs[c], rhs[p]);
-      }
-      if (A[c * m + c] == 0.0) return Fs.back();
-      for (size_t r = c + 1; r < m; r++) {
-        double f = A[r * m + c] / A[c * m + c];
-        for (size_t k = c; k < m; k++) A[r * m + k] -= f * A[c * m + k];
-        rhs[r] -= f * rhs[c];
-      }
+    mix.push(E, maxerr);
+    const size_t n = Fs.size() - 1;
+    for (size_t i = 0; i <= n; i++) {
+      mix.set_B(i, n, spinfac * dot(errs[i], errs[n]));
+      mix.set_T(i, n, spinfac * dot(Ps[i], Fs[n]));  // Tr P F = sum_kl P_kl F_kl for symmetric matrices
+      mix.set_T(n, i, spinfac * dot(Ps[n], Fs[i]));
     }
-    std::vector<double> x(m);
-    for (size_t ii = m; ii-- > 0;) {
-      double s = rhs[ii];
-      for (size_t k = ii + 1; k < m; k++) s -= A[ii * m + k] * x[k];
-      x[ii] = s / A[ii * m + ii];
+  }
+  Mat solve() {
+    size_t dropped = 0;
+    std::vector<double> w = mix.solve(dropped);
+    for (size_t k = 0; k < dropped; k++) {
+      Fs.pop_front();
+      Ps.pop_front();
+      errs.pop_front();
     }
     Mat F(Fs[0].n_rows, Fs[0].n_cols);
-    for (size_t i = 0; i < n; i++)
-      for (size_t k = 0; k < F.d.size(); k++) F.d[k] += x[i] * Fs[i].d[k];
+    for (size_t i = 0; i < Fs.size(); i++)
+      for (size_t k = 0; k < F.d.size(); k++) F.d[k] += w[i] * Fs[i].d[k];
     return F;
   }
 };
@@ -200,7 +190,7 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
     if (verbose) printf("Done in %.6f\n", wall() - t0);
   }
 
-  DIIS diis(opt.diisorder);
+  FockHistory diis(opt, restr);
   double Eold = 0.0;
   Mat P, Fa, Fb;
   const size_t Nb = S.n_rows;
@@ -288,24 +278,30 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
       Mat err = FPS - FPS.t();
       return be.gemm(be.gemm(Sinvh, true, err, false), false, Sinvh, false);
     };
-    Mat err, Fcat;
+    Mat err, Fcat, Pcat;
     if (restr) {
       err = diis_err(Fa, Pa);
       Fcat = Fa;
+      Pcat = Pa;
     } else {
       Mat ea = diis_err(Fa, Pa), eb = diis_err(Fb, Pb);
       err.zeros(ea.n_rows, 2 * ea.n_cols);
       Fcat.zeros(Nb, 2 * Nb);
+      Pcat.zeros(Nb, 2 * Nb);
       std::copy(ea.d.begin(), ea.d.end(), err.d.begin());
       std::copy(eb.d.begin(), eb.d.end(), err.d.begin() + ea.d.size());
       std::copy(Fa.d.begin(), Fa.d.end(), Fcat.d.begin());
       std::copy(Fb.d.begin(), Fb.d.end(), Fcat.d.begin() + Fa.d.size());
+      std::copy(Pa.d.begin(), Pa.d.end(), Pcat.d.begin());
+      std::copy(Pb.d.begin(), Pb.d.end(), Pcat.d.begin() + Pa.d.size());
     }
     double diiserr = 0.0;
     for (double v : err.d) diiserr = std::max(diiserr, fabs(v));
+    diis.update(Fcat, Pcat, err, res.Etot, diiserr);
     if (verbose) printf("DIIS error is %e, update done in %.6f\n", diiserr, wall() - t0);
-    diis.push(Fcat, err);
+    t0 = wall();
     Mat Fd = diis.solve();
+    if (verbose) printf("DIIS solution done in %.6f\n", wall() - t0);
 
     bool convd = (diiserr < opt.convthr) && (fabs(dE) < opt.convthr);
 

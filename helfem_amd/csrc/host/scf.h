@@ -67,6 +67,9 @@ struct Options {
   int multiplicity = 1;   // --M: spin multiplicity 2S+1; nela - nelb = M - 1
   int restricted = -1;    // --restricted: -1 auto (restricted iff M == 1), 0 unrestricted, 1 restricted; with M > 1 that
                           // is the constrained-UHF form of ROHF (scf::ROHF_update, scf_helpers.cpp:470)
+  // ADIIS / CDIIS mixing of the Fock extrapolation (diatomic/main.cpp:119-121, diis.cpp:214-290)
+  double diiseps = 1e-2;  // --diiseps: DIIS error below which CDIIS starts to be mixed in
+  double diisthr = 1e-3;  // --diisthr: DIIS error below which the extrapolation is pure CDIIS
   int diisorder = 5;
   int iguess = 0;  // --iguess: 0 core Hamiltonian, 1 GSZ (needs gsz_d), 3 Thomas-Fermi; 2 (SAP) is not available
   double gsz_d1 = 0.0, gsz_d2 = 0.0;  // screening lengths of the GSZ guess for the two centres (atomic: gsz_d1)

@@ -120,6 +120,13 @@ int hfg_compute_rs_tei(hfg_basis *basis, int rs_kind, double omega);
  * O(Nlm nq p^4) sums run on the device and the tables stay there); follow with hfg_basis_upload */
 int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis, int exchange);
 /* helpers of main.cpp:276-277: mu grid for --grid/--zexp, and (l,m) shell list for lmmax */
+/* DIIS::get_w + solve_F (src/general/diis.cpp:214-290, 392-412): ADIIS + CDIIS weights of the Fock extrapolation from the
+ * inner products of a history of n entries, oldest first: B[i*n+j] = err_i . err_j, T[i*n+j] = Tr(Pa_i Fa_j) + Tr(Pb_i Fb_j),
+ * energies E[n], max |err| of the newest entry.  mode 0: mixed as the drivers run it (--diiseps / --diisthr), 1: CDIIS only,
+ * 2: ADIIS only.  Host-side arithmetic (no GPU). */
+int hfg_diis_weights(int n, const double *B, const double *T, const double *E, double maxerr, double diiseps, double diisthr,
+                     int mode, double *w, int *dropped);
+
 /* Read-back of the setup tables (test and diagnostic access; basis.cpp:1166-1302 fills them):
  *   hfg_basis_lm_map: the sorted (L,|M|) channel list of the constructor (basis.cpp:333-375); n in: capacity, out: count
  *   hfg_basis_get_prim: which 0-3 prim_tei00/02/20/22, 4-7 prim_ktei00/02/20/22, 8-11 disjoint_P0/P2/Q0/Q2 of channel ilm and

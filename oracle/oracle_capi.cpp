@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).  C entry points for ctypes (tests, bench
 // cpu_baseline, smoke).  Plain pointers, column-major doubles, int status (0 = ok).
 #include "oracle.h"
-#include "../helfem_amd/csrc/host/scf.h"
+#include "oracle_scf.h"
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -11,6 +11,7 @@ using helfem::diatomic::TwoDBasis;
 
 static thread_local std::string g_err;
 static thread_local int g_orc_iguess = 0;  // --iguess of the following orc_scf_* calls
+static thread_local double g_orc_diiseps = 1e-2, g_orc_diisthr = 1e-3;  // --diiseps / --diisthr of the following calls
 #define ORC_TRY try {
 #define ORC_CATCH                   \
   }                                 \
@@ -32,50 +33,6 @@ static std::vector<std::vector<size_t> > to_blocks(int nblk, const int64_t *ptr,
   return b;
 }
 
-namespace {
-struct OracleBackend : public helfem::scf::Backend {
-  const TwoDBasis *b = nullptr;
-  const helfem::atomic::TwoDBasis *ab = nullptr;
-  int ldft = 0, mdft = 0;
-  const char *name() const override { return "oracle"; }
-  void prepare(const TwoDBasis &basis, bool, int l, int m) override {
-    b = &basis;
-    ldft = l;
-    mdft = m;
-  }
-  void prepare_atomic(const helfem::atomic::TwoDBasis &basis, bool, int l, int m) override {
-    ab = &basis;
-    ldft = l;
-    mdft = m;
-  }
-  Mat coulomb(const Mat &P) override { return ab ? oracle::atomic_coulomb(*ab, P) : oracle::coulomb(*b, P); }
-  Mat exchange(const Mat &P) override { return ab ? oracle::atomic_exchange(*ab, P) : oracle::exchange(*b, P); }
-  Mat rs_exchange(const Mat &P) override {
-    if (!ab) throw std::logic_error("Range separated functionals are not supported.\n");
-    return oracle::atomic_rs_exchange(*ab, P);
-  }
-  Mat model_potential(const helfem::ModelPotential &p1, const helfem::ModelPotential &p2) override {
-    return ab ? ab->model_potential(p1) : oracle::model_potential(*b, ldft, mdft, p1, p2);
-  }
-  void eval_Fxc(int x, int c, const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin, double thr) override {
-    if (ab) oracle::atomic_eval_Fxc(*ab, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
-    else oracle::eval_Fxc(*b, ldft, mdft, x, c, P, H, Exc, Nel, Ekin, thr);
-  }
-  void eval_Fxc_pol(int x, int c, const Mat &Pa, const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin,
-                    double thr) override {
-    if (ab) oracle::atomic_eval_Fxc_pol(*ab, ldft, mdft, x, c, Pa, Pb, Ha, Hb, Exc, Nel, Ekin, thr);
-    else oracle::eval_Fxc_pol(*b, ldft, mdft, x, c, Pa, Pb, Ha, Hb, Exc, Nel, Ekin, thr);
-  }
-  void eig_gsym_sub(Vec &E, Mat &C, const Mat &F, const Mat &Sinvh, const std::vector<std::vector<size_t> > &sym) override {
-    oracle::eig_gsym_sub(E, C, F, Sinvh, sym);
-  }
-  Mat Sinvh(const Mat &S, bool chol, const std::vector<std::vector<size_t> > &sym) override {
-    return oracle::form_Sinvh(S, chol, sym);
-  }
-  Mat gemm(const Mat &A, bool tA, const Mat &B, bool tB) override { return helfem::matmul(A, tA, B, tB); }
-  void eig_sym(Vec &E, Mat &C, const Mat &A) override { oracle::eig_sym(E, C, A); }
-};
-}  // namespace
 
 extern "C" {
 
@@ -250,7 +207,7 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
                      double Rmax, int igrid, double zexp, int lpad, const char *method, int ldft, int mdft,
                      int symmetry, int multiplicity, int maxit, double convthr, int verbose, double *out) {
   ORC_TRY
-  helfem::scf::Options o;
+  oracle::ScfIn o;
   o.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
   if (multiplicity < 0) o.restricted = 1;
   o.Z1 = Z1;
@@ -264,18 +221,18 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
   o.igrid = igrid;
   o.zexp = zexp;
   o.lpad = lpad;
-  o.method = method;
-  parse_xc_func(o.x_func, o.c_func, o.method);
+  parse_xc_func(o.x_func, o.c_func, method);
   o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
   o.iguess = g_orc_iguess;
+  o.diiseps = g_orc_diiseps;
+  o.diisthr = g_orc_diisthr;
   o.ldft = ldft;
   o.mdft = mdft;
   o.symmetry = symmetry;
   o.maxit = maxit;
   o.convthr = convthr;
   o.verbose = verbose != 0;
-  OracleBackend be;
-  helfem::scf::Result r = helfem::scf::run_diatomic(o, be);
+  oracle::ScfOut r = oracle::scf_diatomic(o);
   out[0] = r.Etot;
   out[1] = r.Ekin;
   out[2] = r.Epot;
@@ -358,6 +315,12 @@ int orc_atomic_rs_exchange(void *h, const double *P, double *K) {
 /// --iguess for the following orc_scf_* calls of this thread (0 core, 3 Thomas-Fermi)
 int orc_scf_set_iguess(int iguess) {
   g_orc_iguess = iguess;
+  return 0;
+}
+/// --diiseps / --diisthr for the following orc_scf_* calls of this thread
+int orc_scf_set_diis(double diiseps, double diisthr) {
+  g_orc_diiseps = diiseps;
+  g_orc_diisthr = diisthr;
   return 0;
 }
 /// kind/Z/d/H of the two centres; atomic bases ignore the second one
@@ -444,23 +407,21 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
                    double zexp, const char *method, int ldft, int mdft, int symmetry, int multiplicity, int maverage,
                    int maxit, double convthr, int verbose, double *out) {
   ORC_TRY
-  helfem::scf::AtomicOptions a;
-  a.maverage = maverage != 0;
-  a.common.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
-  if (multiplicity < 0) a.common.restricted = 1;
-  a.Z = Z;
-  a.Q = Q;
-  a.lmax = lmax;
-  a.mmax = mmax;
-  helfem::scf::Options &o = a.common;
+  oracle::ScfIn o;
+  o.maverage = maverage != 0;
+  o.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
+  if (multiplicity < 0) o.restricted = 1;
+  o.Z1 = Z;
+  o.Q = Q;
+  o.lmax = lmax;
+  o.mmax = mmax;
   o.nelem = nelem;
   o.nnodes = nnodes;
   o.nquad = nquad;
   o.Rmax = Rmax;
   o.igrid = igrid;
   o.zexp = zexp;
-  o.method = method;
-  parse_xc_func(o.x_func, o.c_func, o.method);
+  parse_xc_func(o.x_func, o.c_func, method);
   o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
   if (o.x_func == 178) {  // hyb_lda_xc_cam_lda0: omega = 1/3, alpha = 1/2, beta = -1/4, erfc kernel
     o.kfrac = 0.5;
@@ -469,14 +430,15 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
     o.rs_kind = 2;
   }
   o.iguess = g_orc_iguess;
+  o.diiseps = g_orc_diiseps;
+  o.diisthr = g_orc_diisthr;
   o.ldft = ldft;
   o.mdft = mdft;
   o.symmetry = symmetry;
   o.maxit = maxit;
   o.convthr = convthr;
   o.verbose = verbose != 0;
-  OracleBackend be;
-  helfem::scf::Result r = helfem::scf::run_atomic(a, be);
+  oracle::ScfOut r = oracle::scf_atomic(o);
   out[0] = r.Etot;
   out[1] = r.Ekin;
   out[2] = r.Epot;

@@ -1,0 +1,603 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.h).  The checker's OWN self-consistent-field drivers and its own
+// ADIIS/CDIIS accelerator: nothing here is shared with the product's loops (helfem_amd/csrc/host/scf.cpp,
+// helfem_amd/csrc/host/diis.cpp, helfem_amd/csrc/hip/scf_device.hip).  Restated from the reference
+// (paths relative to /root/reference):
+//   src/diatomic/main.cpp:300-340, 402-1009   driver: occupations, guess, iteration loop, energy expression
+//   src/atomic/main.cpp:245-1010              the same for the atomic program (range-separated exchange :708-780)
+//   src/general/diis.cpp                      uDIIS: update :129-168, PiF_update :170-187, get_w :214-290,
+//                                             get_w_diis_wrk :297-372, solve_F :392-412, get_w_adiis :492-600
+//   src/general/lbfgs.cpp                     L-BFGS two-loop recursion
+//   src/general/scf_helpers.cpp               form_NOs :439-466, ROHF_update :470-523, fock_symmetry_average :263-284
+// The setup tables (basis, one-electron matrices, primitive integrals) come from the shared host setup code, which
+// tests/test_tei_golden_cpu.py pins against an independent restatement.
+#include "oracle_scf.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <stdexcept>
+
+namespace oracle {
+namespace {
+
+double tr(const Mat &A, const Mat &B) { return helfem::trace_prod(A, B); }
+Mat mm(const Mat &A, const Mat &B) { return helfem::matmul(A, false, B, false); }
+Mat mtm(const Mat &A, const Mat &B) { return helfem::matmul(A, true, B, false); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// uDIIS of the reference: a stack of (Fa, Fb, Pa, Pb, E, err) entries, oldest first
+// ---------------------------------------------------------------------------------------------------------------
+struct Entry {
+  Mat Fa, Fb, Pa, Pb;
+  double E;
+  std::vector<double> err;
+};
+
+struct LBFGSHist {
+  std::vector<std::vector<double> > xs, gs;
+  void add(const std::vector<double> &x, const std::vector<double> &g) {
+    xs.push_back(x);
+    gs.push_back(g);
+    if (xs.size() > 10) {
+      xs.erase(xs.begin());
+      gs.erase(gs.begin());
+    }
+  }
+  std::vector<double> direction() const {
+    const size_t k = gs.size() - 1, n = gs[k].size();
+    std::vector<double> q(gs[k]);
+    auto dotv = [n](const std::vector<double> &a, const std::vector<double> &b) {
+      double s = 0;
+      for (size_t i = 0; i < n; i++) s += a[i] * b[i];
+      return s;
+    };
+    std::vector<std::vector<double> > s(k, std::vector<double>(n)), y(k, std::vector<double>(n));
+    for (size_t i = 0; i < k; i++)
+      for (size_t a = 0; a < n; a++) {
+        s[i][a] = xs[i + 1][a] - xs[i][a];
+        y[i][a] = gs[i + 1][a] - gs[i][a];
+      }
+    std::vector<double> alpha(k);
+    for (size_t ii = 0; ii < k; ii++) {
+      const size_t i = k - 1 - ii;
+      alpha[i] = dotv(s[i], q) / dotv(y[i], s[i]);
+      for (size_t a = 0; a < n; a++) q[a] -= alpha[i] * y[i][a];
+    }
+    std::vector<double> r(q);
+    if (xs.size() >= 2) {
+      const double gamma = dotv(s[k - 1], y[k - 1]) / dotv(y[k - 1], y[k - 1]);
+      for (size_t a = 0; a < n; a++) r[a] = gamma * q[a];
+    }
+    for (size_t i = 0; i < k; i++) {
+      const double beta = dotv(y[i], r) / dotv(y[i], s[i]);
+      for (size_t a = 0; a < n; a++) r[a] += s[i][a] * (alpha[i] - beta);
+    }
+    return r;
+  }
+};
+
+class UDIIS {
+ public:
+  UDIIS(const Mat &S, const Mat &Sinvh, double eps, double thr, bool verbose, size_t imax)
+      : S_(S), X_(Sinvh), eps_(eps), thr_(thr), verbose_(verbose), imax_(imax) {}
+
+  void update(const Mat &Fa, const Mat &Fb, const Mat &Pa, const Mat &Pb, double E, double &error) {
+    Entry e;
+    e.Fa = Fa;
+    e.Fb = Fb;
+    e.Pa = Pa;
+    e.Pb = Pb;
+    e.E = E;
+    Mat ea = mm(mm(Fa, Pa), S_), eb = mm(mm(Fb, Pb), S_);
+    ea -= ea.t();
+    eb -= eb.t();
+    ea = mm(mtm(X_, ea), X_);
+    eb = mm(mtm(X_, eb), X_);
+    e.err = ea.d;
+    e.err.insert(e.err.end(), eb.d.begin(), eb.d.end());
+    error = 0.0;
+    for (double v : e.err) error = std::max(error, std::fabs(v));
+    if (stack_.size() == imax_) stack_.erase(stack_.begin());
+    stack_.push_back(e);
+    refresh();
+  }
+
+  void solve_F(Mat &Fa, Mat &Fb) {
+    std::vector<double> w;
+    for (;;) {
+      w = weights();
+      if (stack_.size() == 1) {
+        w.assign(1, 1.0);
+        break;
+      }
+      if (std::fabs(w.back()) <= std::sqrt(DBL_EPSILON)) {
+        if (verbose_) printf("Weight on last matrix too small, reducing to %i matrices.\n", (int)stack_.size() - 1);
+        stack_.erase(stack_.begin());
+        refresh();
+      } else
+        break;
+    }
+    Fa.zeros(stack_[0].Fa.n_rows, stack_[0].Fa.n_cols);
+    Fb.zeros(stack_[0].Fb.n_rows, stack_[0].Fb.n_cols);
+    for (size_t i = 0; i < stack_.size(); i++) {
+      Fa += w[i] * stack_[i].Fa;
+      Fb += w[i] * stack_[i].Fb;
+    }
+  }
+
+ private:
+  void refresh() {  // PiF_update
+    const size_t N = stack_.size();
+    const Entry &n = stack_.back();
+    PiF_.assign(N, 0.0);
+    PiFj_.assign(N * N, 0.0);
+    for (size_t i = 0; i < N; i++) PiF_[i] = tr(stack_[i].Pa - n.Pa, n.Fa) + tr(stack_[i].Pb - n.Pb, n.Fb);
+    for (size_t i = 0; i < N; i++)
+      for (size_t j = 0; j < N; j++)
+        PiFj_[i * N + j] = tr(stack_[i].Pa - n.Pa, stack_[j].Fa - n.Fa) + tr(stack_[i].Pb - n.Pb, stack_[j].Fb - n.Fb);
+  }
+
+  static std::vector<double> contraction(const std::vector<double> &x) {
+    double n2 = 0;
+    for (double v : x) n2 += v * v;
+    std::vector<double> c(x.size());
+    for (size_t i = 0; i < x.size(); i++) c[i] = x[i] * x[i] / n2;
+    return c;
+  }
+  double adiis_E(const std::vector<double> &x) const {
+    const size_t N = PiF_.size();
+    const std::vector<double> c = contraction(x);
+    double E = 0;
+    for (size_t i = 0; i < N; i++) E += 2.0 * c[i] * PiF_[i];
+    for (size_t i = 0; i < N; i++)
+      for (size_t j = 0; j < N; j++) E += c[i] * PiFj_[i * N + j] * c[j];
+    return E;
+  }
+  std::vector<double> adiis_dEdx(const std::vector<double> &x) const {
+    const size_t N = PiF_.size();
+    const std::vector<double> c = contraction(x);
+    std::vector<double> dEdc(N);
+    for (size_t i = 0; i < N; i++) {
+      dEdc[i] = 2.0 * PiF_[i];
+      for (size_t j = 0; j < N; j++) dEdc[i] += PiFj_[i * N + j] * c[j] + PiFj_[j * N + i] * c[j];
+    }
+    double xn = 0;
+    for (double v : x) xn += v * v;
+    // jac(i,j) = d c_i / d x_j = -c_i 2 x_j / xn (+ 2 x_i / xn on the diagonal);  dE/dx_j = sum_i jac(i,j) dEdc_i
+    std::vector<double> g(N, 0.0);
+    for (size_t j = 0; j < N; j++)
+      for (size_t i = 0; i < N; i++) {
+        double jac = -c[i] * 2.0 * x[j] / xn;
+        if (i == j) jac += 2.0 * x[i] / xn;
+        g[j] += jac * dEdc[i];
+      }
+    return g;
+  }
+
+  std::vector<double> w_adiis() const {
+    const size_t N = PiF_.size();
+    if (N == 1) return std::vector<double>(1, 1.0);
+    std::vector<double> x(N, 1.0 / N);
+    LBFGSHist bfgs;
+    double steplen = 0.01;
+    const double fac = 2.0;
+    auto moved = [&](const std::vector<double> &sd, double t) {
+      std::vector<double> y(x);
+      for (size_t i = 0; i < N; i++) y[i] += sd[i] * t;
+      return y;
+    };
+    for (int iter = 0; iter < 1000; iter++) {
+      std::vector<double> g = adiis_dEdx(x);
+      double gn = 0;
+      for (double v : g) gn += v * v;
+      if (std::sqrt(gn) <= 1e-7) break;
+      bfgs.add(x, g);
+      std::vector<double> sd = bfgs.direction();
+      for (double &v : sd) v = -v;
+      std::vector<std::pair<double, double> > steps;
+      steps.push_back(std::make_pair(steplen / fac, adiis_E(moved(sd, steplen / fac))));
+      steps.push_back(std::make_pair(steplen, adiis_E(moved(sd, steplen))));
+      size_t imin = 0;
+      auto locate = [&]() {
+        imin = 0;
+        for (size_t i = 1; i < steps.size(); i++)
+          if (steps[i].second < steps[imin].second) imin = i;
+      };
+      for (;;) {
+        std::sort(steps.begin(), steps.end());
+        locate();
+        if (imin == 0) {
+          if (steps[0].first < DBL_EPSILON) break;
+          const double t = steps[0].first / fac;
+          steps.push_back(std::make_pair(t, adiis_E(moved(sd, t))));
+        } else if (imin == steps.size() - 1) {
+          const double t = steps[imin].first * fac;
+          steps.push_back(std::make_pair(t, adiis_E(moved(sd, t))));
+        } else
+          break;
+      }
+      if (imin != 0 && imin != steps.size() - 1) {
+        // three-point parabola  y = b0 + b1 t + b2 t^2  solved by Cramer's rule on the Vandermonde system
+        const double t[3] = {steps[imin - 1].first, steps[imin].first, steps[imin + 1].first};
+        const double y[3] = {steps[imin - 1].second, steps[imin].second, steps[imin + 1].second};
+        const double det = (t[1] - t[0]) * (t[2] - t[0]) * (t[2] - t[1]);
+        if (det != 0.0) {
+          const double b2 = (y[0] * (t[2] - t[1]) - y[1] * (t[2] - t[0]) + y[2] * (t[1] - t[0])) / det;
+          const double b1 = (-y[0] * (t[2] * t[2] - t[1] * t[1]) + y[1] * (t[2] * t[2] - t[0] * t[0]) - y[2] * (t[1] * t[1] - t[0] * t[0])) / det;
+          if (std::isfinite(b2) && b2 > std::sqrt(DBL_EPSILON)) {
+            const double t0 = -b1 / (2.0 * b2);
+            if (t[0] < t0 && t0 < t[2]) {
+              steps.push_back(std::make_pair(t0, adiis_E(moved(sd, t0))));
+              locate();
+            }
+          }
+        }
+      }
+      if (steps[imin].first < DBL_EPSILON) break;
+      x = moved(sd, steps[imin].first);
+      steplen = steps[imin].first;
+    }
+    return contraction(x);
+  }
+
+  // B w = 1 by the pseudo-inverse of the symmetric B (its singular value decomposition), weights normalised
+  std::vector<double> w_cdiis() const {
+    const size_t N = stack_.size();
+    Mat B(N, N);
+    for (size_t i = 0; i < N; i++)
+      for (size_t j = 0; j < N; j++) {
+        double s = 0;
+        for (size_t k = 0; k < stack_[i].err.size(); k++) s += stack_[i].err[k] * stack_[j].err[k];
+        B(i, j) = s;
+      }
+    Vec lam;
+    Mat U;
+    eig_sym(lam, U, B);
+    std::vector<double> sol(N, 0.0);
+    for (size_t k = 0; k < N; k++) {
+      if (lam[k] == 0.0) continue;
+      double u1 = 0;
+      for (size_t a = 0; a < N; a++) u1 += U(a, k);
+      for (size_t a = 0; a < N; a++) sol[a] += u1 / lam[k] * U(a, k);
+    }
+    double s = 0;
+    for (double v : sol) s += v;
+    if (s == 0.0) {
+      sol.assign(N, 1.0);
+      s = (double)N;
+    }
+    for (double &v : sol) v /= s;
+    return sol;
+  }
+
+  std::vector<double> weights() {  // DIIS::get_w with usediis = useadiis = true (diatomic/main.cpp:775-776)
+    const size_t N = stack_.size();
+    double err = 0;
+    for (double v : stack_.back().err) err = std::max(err, std::fabs(v));
+    double diisw = std::max(std::min(1.0 - (err - thr_) / (eps_ - thr_), 1.0), 0.0);
+    const double adiisw = 1.0 - diisw;
+    if (cooloff_ > 0) {
+      diisw = 0.0;
+      cooloff_--;
+    } else if (N > 1 && stack_[N - 1].E - stack_[N - 2].E > 0.1) {
+      cooloff_ = 2;
+      diisw = 0.0;
+    }
+    std::vector<double> w(N, 0.0);
+    if (diisw != 0.0) {
+      std::vector<double> wd = w_cdiis();
+      for (size_t i = 0; i < N; i++) w[i] += diisw * wd[i];
+    }
+    if (adiisw != 0.0) {
+      std::vector<double> wa = w_adiis();
+      for (size_t i = 0; i < N; i++) w[i] += adiisw * wa[i];
+    }
+    if (verbose_) {
+      printf(" DIIS weights (CDIIS share %.3f)\n", diisw);
+      for (double v : w) printf(" % .4e", v);
+      printf("\n");
+    }
+    return w;
+  }
+
+  Mat S_, X_;
+  double eps_, thr_;
+  bool verbose_;
+  size_t imax_;
+  int cooloff_ = 0;
+  std::vector<Entry> stack_;
+  std::vector<double> PiF_, PiFj_;
+};
+
+// scf::fock_symmetry_average
+Mat average_over(const Mat &Fin, const std::vector<std::vector<std::vector<size_t> > > &groups) {
+  Mat Fout(Fin);
+  for (const auto &g : groups) {
+    if (g.empty()) continue;
+    const size_t n = g[0].size();
+    Mat mean(n, n);
+    for (const auto &idx : g)
+      for (size_t j = 0; j < n; j++)
+        for (size_t i = 0; i < n; i++) mean(i, j) += Fin(idx[i], idx[j]);
+    mean *= 1.0 / (double)g.size();
+    for (const auto &idx : g)
+      for (size_t j = 0; j < n; j++)
+        for (size_t i = 0; i < n; i++) Fout(idx[i], idx[j]) = mean(i, j);
+  }
+  return Fout;
+}
+
+// scf::form_NOs + scf::ROHF_update, written as the reference writes them: natural orbitals in DECREASING occupation,
+// core orbitals first, virtual orbitals last
+void cuhf_update(Mat &Fa, Mat &Fb, const Mat &P, const Mat &Sh, const Mat &Sinvh, size_t nocca, size_t noccb) {
+  Mat Porth = mm(mtm(Sh, P), Sh);
+  Vec val;
+  Mat vec;
+  eig_sym(val, vec, Porth);
+  const size_t N = val.size();
+  Mat Pv(N, N);
+  for (size_t i = 0; i < N; i++)
+    for (size_t r = 0; r < N; r++) Pv(r, i) = vec(r, N - 1 - i);
+  Mat AO_to_NO = mm(Sinvh, Pv), NO_to_AO = mm(Sh, Pv).t();
+  Mat Delta = 0.5 * (Fa - Fb);
+  Mat Dno = mm(mtm(AO_to_NO, Delta), AO_to_NO);
+  const size_t Nc = std::min(nocca, noccb), Na = std::max(nocca, noccb) - Nc, Nv = N - Na - Nc;
+  Mat lam(N, N);
+  for (size_t c = 0; c < Nc; c++)
+    for (size_t v = N - Nv; v < N; v++) {
+      lam(c, v) = -Dno(c, v);
+      lam(v, c) = -Dno(v, c);
+    }
+  Mat lamAO = mm(mtm(NO_to_AO, lam), NO_to_AO);
+  Fa += lamAO;
+  Fb -= lamAO;
+}
+
+struct Engine {  // what differs between the two programs
+  std::function<Mat(const Mat &)> coulomb, exchange, rs_exchange;
+  std::function<void(const Mat &, Mat &, double &, double &, double &)> xc;                            // restricted
+  std::function<void(const Mat &, const Mat &, Mat &, Mat &, double &, double &, double &)> xc_pol;  // unrestricted
+  std::function<Mat()> guess_potential;  // model potential of the guess (iguess != 0)
+  std::function<void()> compute_tei;
+};
+
+ScfOut iterate(const ScfIn &in, const Mat &S, const Mat &T, const Mat &Vnuc, const std::vector<std::vector<size_t> > &dsym,
+               const std::vector<std::vector<std::vector<size_t> > > &avg, int nel, double Enucr, Engine &en) {
+  ScfOut out;
+  out.Enucr = Enucr;
+  const bool verbose = in.verbose;
+  const bool dft = in.x_func > 0 || in.c_func > 0;
+  // scf::parse_nela_nelb with nela = nelb = 0 on input (scf_helpers.cpp:558-591)
+  const int M = in.multiplicity;
+  if (M < 1) throw std::runtime_error("Invalid value for multiplicity, which must be >=1.\n");
+  if ((nel % 2 == 0 && M % 2 != 1) || (nel % 2 == 1 && M % 2 != 0)) throw std::runtime_error("Requested multiplicity not achievable.\n");
+  const int nela = (nel % 2 == 0) ? nel / 2 + (M - 1) / 2 : nel / 2 + M / 2, nelb = nel - nela;
+  if (nelb < 0) throw std::runtime_error("Requested multiplicity not achievable.\n");
+  int restr = in.restricted;
+  if (restr == -1) restr = (nela == nelb);
+  const bool closed = restr && nela == nelb, rohf = restr && nela != nelb;
+  out.nela = nela;
+  out.nelb = nelb;
+
+  const Mat H0 = T + Vnuc;
+  const Mat Sinvh = form_Sinvh(S, !in.diag, dsym);
+  Mat Sh;
+  if (rohf) Sh = mm(S, Sinvh);
+  const size_t Nb = S.n_rows;
+
+  Vec Ea, Eb;
+  Mat Ca, Cb;
+  bool have_tei = false;
+  Mat Hguess = H0;
+  if (in.iguess != 0) {
+    en.compute_tei();
+    have_tei = true;
+    Hguess = T + en.guess_potential();
+  }
+  eig_gsym_sub(Ea, Ca, Hguess, Sinvh, dsym);
+  Eb = Ea;
+  Cb = Ca;
+  if (!have_tei) en.compute_tei();
+
+  UDIIS diis(S, Sinvh, in.diiseps, in.diisthr, verbose, (size_t)in.diisorder);
+  double Eold = 0.0;
+  Mat P, Pa, Pb, Fa, Fb;
+  for (int it = 1; it <= in.maxit; it++) {
+    if (verbose) printf("\n**** Iteration %i ****\n\n", it);
+    Pa = form_density(Ca, nela);
+    Pb = nelb ? form_density(Cb, nelb) : Mat(Nb, Nb);
+    P = Pa + Pb;
+    out.Ekin = tr(P, T);
+    out.Epot = tr(P, Vnuc);
+    Mat J = en.coulomb(P);
+    out.Ecoul = 0.5 * tr(P, J);
+    if (verbose) printf("Coulomb energy %.10e\n", out.Ecoul);
+    Mat Ka, Kb;
+    out.Exx = 0.0;
+    if (in.kfrac != 0.0 || in.kshort != 0.0) {
+      auto build = [&](const Mat &Ps) {
+        Mat K(Nb, Nb);
+        if (in.kfrac != 0.0) K += in.kfrac * en.exchange(Ps);
+        if (in.omega != 0.0) K += in.kshort * en.rs_exchange(Ps);
+        return K;
+      };
+      Ka = build(Pa);
+      if (nelb) Kb = closed ? Ka : build(Pb);
+      else Kb.zeros(Nb, Nb);
+      out.Exx = 0.5 * tr(Pa, Ka) + 0.5 * tr(Pb, Kb);
+      if (verbose) printf("Exchange energy %.10e\n", out.Exx);
+    }
+    Mat XCa, XCb;
+    out.Exc = 0.0;
+    if (dft) {
+      double nelnum = 0, ekin = 0;
+      if (closed) {
+        en.xc(P, XCa, out.Exc, nelnum, ekin);
+        XCb = XCa;
+      } else
+        en.xc_pol(Pa, Pb, XCa, XCb, out.Exc, nelnum, ekin);
+      if (verbose) {
+        printf("DFT energy %.10e\n", out.Exc);
+        printf("Error in integrated number of electrons % e\n", nelnum - nela - nelb);
+      }
+    }
+    Fa = H0 + J;
+    Fb = H0 + J;
+    if (Ka.n_rows == Nb) Fa += Ka;
+    if (Kb.n_rows == Nb) Fb += Kb;
+    if (dft) {
+      Fa += XCa;
+      if (nelb > 0) Fb += XCb;
+    }
+    if (!avg.empty()) {
+      Fa = average_over(Fa, avg);
+      Fb = average_over(Fb, avg);
+    }
+    if (in.symmetry) {
+      Fa = enforce_fock_symmetry(Fa, dsym);
+      Fb = enforce_fock_symmetry(Fb, dsym);
+    }
+    if (rohf) cuhf_update(Fa, Fb, P, Sh, Sinvh, nela, nelb);
+
+    out.Etot = out.Ekin + out.Epot + out.Ecoul + out.Exx + out.Exc + out.Enucr;
+    const double dE = out.Etot - Eold;
+    if (verbose) {
+      printf("Total energy is % .10f\n", out.Etot);
+      if (it > 1) printf("Energy changed by %e\n", dE);
+    }
+    Eold = out.Etot;
+
+    double diiserr = 0.0;
+    diis.update(Fa, Fb, Pa, Pb, out.Etot, diiserr);
+    if (verbose) printf("DIIS error is %e\n", diiserr);
+    Mat Fda, Fdb;
+    diis.solve_F(Fda, Fdb);
+    const bool convd = diiserr < in.convthr && std::fabs(dE) < in.convthr;
+
+    eig_gsym_sub(Ea, Ca, Fda, Sinvh, dsym);
+    if (closed) {
+      Eb = Ea;
+      Cb = Ca;
+    } else
+      eig_gsym_sub(Eb, Cb, Fdb, Sinvh, dsym);
+    out.iterations = it;
+    if (convd) {
+      out.converged = true;
+      break;
+    }
+  }
+  out.Ea = Ea;
+  out.Eb = Eb;
+  return out;
+}
+
+helfem::ModelPotential guess_nucleus(int iguess, int Z, double d) {
+  helfem::ModelPotential p;
+  p.Z = Z;
+  p.kind = (Z == 0) ? 0 : iguess;
+  p.d = d;
+  if (iguess == 1 && Z != 0 && !(d > 0.0)) throw std::logic_error("GSZ guess: the screening length d_Z must be given\n");
+  if (iguess != 0 && iguess != 1 && iguess != 3) throw std::logic_error("Unsupported guess\n");
+  return p;
+}
+}  // namespace
+
+ScfOut scf_diatomic(const ScfIn &in) {
+  if (in.omega != 0.0) throw std::logic_error("Range separated functionals are not supported.\n");  // diatomic/main.cpp:393
+  int nquad = in.nquad;
+  if (nquad == 0) nquad = 5 * in.nnodes;
+  else if (nquad < 2 * in.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
+  helfem::IVec lval, mval;
+  helfem::diatomic::lm_to_l_m(in.lmmax, lval, mval);
+  const double Rhalf = 0.5 * in.Rbond;
+  const double mumax = helfem::arcosh(in.Rmax / Rhalf);
+  Vec bval = helfem::get_grid(mumax, in.nelem, in.igrid, in.zexp);
+  helfem::diatomic::TwoDBasis basis(in.Z1, in.Z2, Rhalf, in.nnodes, nquad, bval, lval, mval, in.lpad);
+  const bool dft = in.x_func > 0 || in.c_func > 0;
+  int ldft = in.ldft, mdft = in.mdft;
+  if (dft || in.iguess != 0) {
+    int lmaxmax = 0;
+    for (int l : in.lmmax) lmaxmax = std::max(lmaxmax, l);
+    if (ldft == 0) ldft = 4 * lmaxmax + 12;
+    if (ldft < 2 * lmaxmax + 2) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
+    if (mdft == 0) mdft = 4 * (int)in.lmmax.size() + 5;
+    if (mdft < 2 * (int)in.lmmax.size()) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
+  }
+  int symm = in.symmetry;
+  if (symm == 2 && in.Z1 != in.Z2) symm = 1;
+  ScfIn in2 = in;
+  in2.symmetry = symm;
+  Engine en;
+  en.compute_tei = [&]() { basis.compute_tei(in.kfrac != 0.0); };
+  en.coulomb = [&](const Mat &P) { return coulomb(basis, P); };
+  en.exchange = [&](const Mat &P) { return exchange(basis, P); };
+  en.rs_exchange = [&](const Mat &) -> Mat { throw std::logic_error("Range separated functionals are not supported.\n"); };
+  en.xc = [&](const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin) {
+    eval_Fxc(basis, ldft, mdft, in.x_func, in.c_func, P, H, Exc, Nel, Ekin, in.dftthr);
+  };
+  en.xc_pol = [&](const Mat &Pa, const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin) {
+    eval_Fxc_pol(basis, ldft, mdft, in.x_func, in.c_func, Pa, Pb, Ha, Hb, Exc, Nel, Ekin, in.dftthr);
+  };
+  en.guess_potential = [&]() {
+    return model_potential(basis, ldft, mdft, guess_nucleus(in.iguess, in.Z1, in.gsz_d1), guess_nucleus(in.iguess, in.Z2, in.gsz_d2));
+  };
+  std::vector<std::vector<std::vector<size_t> > > none;
+  ScfOut out = iterate(in2, basis.overlap(), basis.kinetic(), basis.nuclear(), basis.get_sym_idx(symm), none, in.Z1 + in.Z2 - in.Q,
+                       in.Z1 * in.Z2 / in.Rbond, en);
+  out.Nbf = basis.Nbf();
+  return out;
+}
+
+ScfOut scf_atomic(const ScfIn &in) {
+  const int nel = in.Z1 - in.Q;
+  if (nel <= 0) throw std::logic_error("No electrons.\n");
+  int nquad = in.nquad;
+  if (nquad == 0) nquad = 5 * in.nnodes;
+  else if (nquad < 2 * in.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
+  helfem::IVec lval, mval;
+  helfem::atomic::angular_basis(in.lmax, in.mmax, lval, mval);
+  Vec bval = helfem::get_grid(in.Rmax, in.nelem, in.igrid, in.zexp);
+  helfem::atomic::TwoDBasis basis(in.Z1, in.nnodes, nquad, bval, lval, mval);
+  const bool dft = in.x_func > 0 || in.c_func > 0;
+  int ldft = in.ldft, mdft = in.mdft;
+  if (dft) {
+    if (ldft == 0) ldft = 4 * in.lmax + 10;
+    if (ldft < 2 * in.lmax) throw std::logic_error("Increase ldft to guarantee accuracy of quadrature!\n");
+    if (mdft == 0) mdft = 4 * in.mmax + 5;
+    if (mdft < 2 * in.mmax) throw std::logic_error("Increase mdft to guarantee accuracy of quadrature!\n");
+  }
+  Engine en;
+  en.compute_tei = [&]() {
+    basis.compute_tei(in.kfrac != 0.0);
+    if (in.omega != 0.0) {
+      if (in.rs_kind == 1) basis.compute_yukawa(in.omega);
+      else basis.compute_erfc(in.omega);
+    }
+  };
+  en.coulomb = [&](const Mat &P) { return atomic_coulomb(basis, P); };
+  en.exchange = [&](const Mat &P) { return atomic_exchange(basis, P); };
+  en.rs_exchange = [&](const Mat &P) { return atomic_rs_exchange(basis, P); };
+  en.xc = [&](const Mat &P, Mat &H, double &Exc, double &Nel, double &Ekin) {
+    atomic_eval_Fxc(basis, ldft, mdft, in.x_func, in.c_func, P, H, Exc, Nel, Ekin, in.dftthr);
+  };
+  en.xc_pol = [&](const Mat &Pa, const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin) {
+    atomic_eval_Fxc_pol(basis, ldft, mdft, in.x_func, in.c_func, Pa, Pb, Ha, Hb, Exc, Nel, Ekin, in.dftthr);
+  };
+  en.guess_potential = [&]() { return basis.model_potential(guess_nucleus(in.iguess, in.Z1, in.gsz_d1)); };
+  // index lists of atomic/main.cpp:308-312: for every l the functions of the shells (l, m), all m
+  std::vector<std::vector<std::vector<size_t> > > avg;
+  if (in.maverage) {
+    int lmx = 0;
+    for (int l : basis.lval) lmx = std::max(lmx, l);
+    avg.resize(lmx + 1);
+    for (int l = 0; l <= lmx; l++)
+      for (size_t a = 0; a < basis.Nang(); a++)
+        if (basis.lval[a] == l) avg[l].push_back(basis.lm_indices(l, basis.mval[a]));
+  }
+  ScfOut out = iterate(in, basis.overlap(), basis.kinetic(), basis.nuclear(), basis.get_sym_idx(in.symmetry), avg, nel, 0.0, en);
+  out.Nbf = basis.Nbf();
+  return out;
+}
+
+}  // namespace oracle

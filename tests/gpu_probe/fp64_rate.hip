@@ -64,6 +64,68 @@ __global__ __launch_bounds__(256) void k_mfma4(double *out, unsigned long long *
   }
 }
 
+// the same instruction with DIFFERENT operand registers from one instruction to the next (8 a-operands x 8 b-operands, 64
+// accumulators), as a GEMM tile issues them
+__global__ __launch_bounds__(256) void k_mfma4_var(double *out, unsigned long long *clk, int iters) {
+  double acc[64], a[8], b[8];
+  for (int i = 0; i < 64; i++) acc[i] = 0.0;
+  for (int i = 0; i < 8; i++) {
+    a[i] = threadIdx.x * 1e-3 + i;
+    b[i] = 1.0 + threadIdx.x * 1e-4 * (i + 1);
+  }
+  unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[i * 8 + j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[j], acc[i * 8 + j], 0, 0, 0);
+    // keep the operands live and changing so that nothing is hoisted
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      a[i] += 1e-9;
+      b[i] -= 1e-9;
+    }
+  }
+  unsigned long long c1 = clock64(), w1 = wall_clock64();
+  double s = 0.0;
+  for (int i = 0; i < 64; i++) s += acc[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = c1 - c0;
+    clk[1] = w1 - w0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mfma16_var(double *out, unsigned long long *clk, int iters) {
+  double4_t acc[16];
+  double a[4], b[4];
+  for (int i = 0; i < 16; i++) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < 4; i++) {
+    a[i] = threadIdx.x * 1e-3 + i;
+    b[i] = 1.0 + threadIdx.x * 1e-4 * (i + 1);
+  }
+  unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i * 4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      a[i] += 1e-9;
+      b[i] -= 1e-9;
+    }
+  }
+  unsigned long long c1 = clock64(), w1 = wall_clock64();
+  double s = 0.0;
+  for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = c1 - c0;
+    clk[1] = w1 - w0;
+  }
+}
+
 template <typename K>
 static void run(const char *name, K kern, double flops_per_wave_iter, int iters) {
   double *d;
@@ -97,5 +159,7 @@ int main() {
   run("v_fma_f64 x32", k_fma, 32 * 64 * 2.0, 20000);
   run("v_mfma_f64_16x16x4 x16", k_mfma16, 16 * 2048.0, 20000);
   run("v_mfma_f64_4x4x4_4b x32", k_mfma4, 32 * 4 * 4 * 4 * 4 * 2.0, 20000);
+  run("4x4x4_4b, 8x8 operands", k_mfma4_var, 64 * 512.0, 10000);
+  run("16x16x4, 4x4 operands", k_mfma16_var, 16 * 2048.0, 10000);
   return 0;
 }
