@@ -46,37 +46,85 @@ def build_basis(hf, w):
 
 
 def cpu_baseline(w, bval, lval, mval, ldft, mdft, P, F, Sinvh, blocks):
-    """The oracle (CPU restatement of the reference algorithm, single thread) timed on a bounded sample of the
-    same workload, extrapolated to one SCF iteration."""
+    """The CPU path timed on this host's cores, on a bounded sample of the same workload, extrapolated to one SCF
+    iteration (kind "port+lapack"):
+      * generalized eigensolve as scf::eig_gsym_sub does it (/root/reference/src/general/scf_helpers.cpp:131-186): per
+        symmetry block Sinvh^T F Sinvh, LAPACK dsyevd, Sinvh C -- ALL blocks in full, through torch's CPU LAPACK/BLAS (MKL)
+        on every core this process may use;
+      * XC quadrature with the oracle (loop-for-loop restatement of the reference's dense algorithm), `cores` radial points
+        at a time on `cores` threads, the sample points spread evenly over the radial elements;
+      * Coulomb with the oracle, one thread -- the reference's coulomb() has no OpenMP either (basis.cpp:1359-1530)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import threading
+    import torch
     import oracle_lib as orc
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    torch.set_num_threads(cores)
     Rh = 0.5 * w["Rbond"]
+    os.environ["HELFEM_NUM_THREADS"] = str(min(cores, 64))
     ob = orc.OracleBasis(w["Z1"], w["Z2"], Rh, w["nnodes"], 5 * w["nnodes"], bval, lval, mval, 10)
     ob.compute_tei(False)
     t0 = time.time()
     ob.coulomb(P)
     tJ = time.time() - t0
+    # XC: one radial point per thread, points spread over the elements
     NQ = w["nelem"] * 5 * w["nnodes"]
-    qs = NQ // 2
+    nth = max(1, min(cores, 32, NQ))
+    npts = max(8, nth) if NQ >= 8 else NQ
+    pts = sorted(set(int(round((k + 0.5) * NQ / npts)) % NQ for k in range(npts)))
+    work = list(pts)
+    lock = threading.Lock()
+
+    def worker():
+        while True:
+            with lock:
+                if not work:
+                    return
+                q = work.pop()
+            ob.eval_Fxc(ldft, mdft, w["x"], w["c"], P, q_begin=q, q_end=q + 1)
+
+    threads = [threading.Thread(target=worker) for _ in range(nth)]
     t0 = time.time()
-    ob.eval_Fxc(ldft, mdft, w["x"], w["c"], P, q_begin=qs, q_end=qs + 1)
-    tXC1 = time.time() - t0
-    # eigensolve: the smallest symmetry block in full, scaled by n^3 to the other blocks
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    tXC_sample = time.time() - t0
+    tXC = tXC_sample * NQ / float(len(pts))
+    # eigensolve: every block, LAPACK on all cores
+    Ft = torch.from_numpy(np.ascontiguousarray(F))
+    Xt = torch.from_numpy(np.ascontiguousarray(Sinvh))
     sizes = [len(b) for b in blocks]
-    ib = int(np.argmin(sizes))
-    idx = blocks[ib]
-    cols = np.where(np.abs(Sinvh[idx, :]).sum(axis=0) > 0)[0]
-    Fb = np.asfortranarray(F[np.ix_(idx, idx)])
-    Xb = np.asfortranarray(Sinvh[np.ix_(idx, cols)])
     t0 = time.time()
-    orc.eig_gsym(Fb, Xb)
-    tE1 = time.time() - t0
-    tE = tE1 * sum((n / float(sizes[ib])) ** 3 for n in sizes)
-    total = tJ + tXC1 * NQ + tE
-    return dict(value=total * 1e3, unit="ms", cores=1, kind="port",
-                sample="oracle single thread: full Coulomb (%.2fs) + 1 of %d XC radial points (%.2fs each) + "
-                       "eig_gsym of the n=%d block (%.2fs) scaled by n^3 to blocks %s"
-                       % (tJ, NQ, tXC1, sizes[ib], tE1, sizes))
+    for idx in blocks:
+        it = torch.as_tensor(np.asarray(idx, dtype=np.int64))
+        cols = torch.nonzero(Xt[it, :].abs().sum(dim=0) > 0).flatten()
+        Xb = Xt[it][:, cols]
+        Fb = Ft[it][:, it]
+        Forth = Xb.T @ (Fb @ Xb)
+        Eb, Zb = torch.linalg.eigh(Forth)
+        Cb = Xb @ Zb
+        del Cb, Eb
+    tE = time.time() - t0
+    total = tJ + tXC + tE
+    return dict(value=total * 1e3, unit="ms", cores=cores, kind="port+lapack", cpu=cpu_model,
+                parts_ms=dict(coulomb=tJ * 1e3, xc=tXC * 1e3, eig=tE * 1e3),
+                sample="Coulomb: oracle, full build, 1 thread as the reference (%.2f s); XC: oracle, %d of %d radial points spread "
+                       "over the %d elements on %d threads (%.2f s wall, scaled x%.1f); eigensolve: all blocks %s with "
+                       "LAPACK dsyevd + 3 GEMMs (torch CPU, MKL, %d threads, %.2f s)"
+                       % (tJ, len(pts), NQ, w["nelem"], nth, tXC_sample, NQ / float(len(pts)), sizes, cores, tE))
 
 
 def main():
@@ -204,6 +252,8 @@ def main():
                        "name": args.workload, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": ("profiles/r01_pmc_traffic.json (committed rocprofv3 --pmc passes of this command, not "
+                                            "measured in this run)") if traffic is not None else None,
                          "kernel": "hfg::" + TRD_KERNEL, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_ms * 1e3, "launches_per_step": launches_per_step,
                          "note": "latency-bound: one dependent launch per Householder column (see DESIGN.md 3.4)"},

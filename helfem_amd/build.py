@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "helfem_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "helfem_amd", "lib")
 OBJDIR = os.path.join(ROOT, "helfem_amd", "build")
 
-HOST_SRCS = ["host/fem.cpp", "host/special.cpp", "host/atomic_basis.cpp", "host/diatomic_basis.cpp", "host/scf.cpp", "host/diis.cpp", "host/dftfuncs.cpp"]
+HOST_SRCS = ["host/fem.cpp", "host/special.cpp", "host/atomic_basis.cpp", "host/diatomic_basis.cpp", "host/scf.cpp", "host/diis.cpp", "host/checkpoint.cpp", "host/dftfuncs.cpp"]
 HIP_SRCS = ["hip/tables.cpp", "hip/capi.cpp", "hip/fock.hip", "hip/exchange.hip", "hip/exchange_lr.hip", "hip/gemm.hip", "hip/eig.hip", "hip/dc.hip", "hip/trd.hip",
             "hip/misc.hip", "hip/scf_gpu.cpp", "hip/scf_device.hip", "hip/tei_dev.hip"]
 
@@ -75,11 +75,47 @@ def build_product(verbose=True, force=False):
         raise RuntimeError("hipcc failed")
     lib = os.path.join(LIBDIR, "libhelfem_amd.so")
     if force or procs or not os.path.exists(lib):
-        cmd = [hipcc, "-shared", "--offload-arch=gfx950", "-o", lib] + objs + ["-lpthread"]
+        cmd = [hipcc, "-shared", "--offload-arch=gfx950", "-o", lib] + objs + ["-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_cli(verbose=verbose, force=force or bool(procs))
+    build_adapter_test(verbose=verbose)
     return lib
+
+
+def build_cli(verbose=True, force=False):
+    """helfem_amd/bin/diatomic and helfem_amd/bin/atomic: the reference's command lines in front of libhelfem_amd.so"""
+    bindir = os.path.join(ROOT, "helfem_amd", "bin")
+    os.makedirs(bindir, exist_ok=True)
+    lib = os.path.join(LIBDIR, "libhelfem_amd.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    for name in ("diatomic", "atomic"):
+        src = os.path.join(CSRC, "cli", name + "_main.cpp")
+        exe = os.path.join(bindir, name)
+        deps = (os.path.join(CSRC, "cli", "options.h"), os.path.join(ROOT, "include", "helfem_gpu.h"), lib)
+        if force or _newer(src, exe, deps):
+            # linked through hipcc so that the HIP runtime the library needs is found the same way as for the library itself
+            cmd = [hipcc, "-O2", "-std=c++17", src, "-o", exe, "-L" + LIBDIR, "-lhelfem_amd", "-Wl,-rpath,$ORIGIN/../lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+
+
+def build_adapter_test(verbose=True):
+    """tests/cpp/adapter_test: calls the hot path through include/helfem_gpu_arma.hpp (built next to the library; the GPU box
+    runs it from tests/test_gpu_adapter.py)"""
+    src = os.path.join(ROOT, "tests", "cpp", "adapter_test.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "adapter_test")
+    lib = os.path.join(LIBDIR, "libhelfem_amd.so")
+    deps = (os.path.join(ROOT, "include", "helfem_gpu_arma.hpp"), os.path.join(ROOT, "include", "helfem_gpu.h"), lib)
+    if _newer(src, exe, deps):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        cmd = [hipcc, "-O2", "-std=c++17", "-Wall", src, "-o", exe, "-L" + LIBDIR, "-lhelfem_amd", "-Wl,-rpath,$ORIGIN/../../helfem_amd/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return exe
 
 
 def build_oracle(verbose=True):

@@ -1,0 +1,157 @@
+// `atomic`: the command line of the reference's atomic program (/root/reference/src/atomic/main.cpp:58-1030) in front of
+// the MI355X implementation of its SCF hot path.  See diatomic_main.cpp.
+#include "../../../include/helfem_gpu.h"
+#include "options.h"
+#include <cstring>
+
+static void fail(const std::string &msg) {
+  fprintf(stderr, "%s", msg.c_str());
+  if (msg.empty() || msg.back() != '\n') fprintf(stderr, "\n");
+  exit(1);
+}
+
+int main(int argc, char **argv) {
+  cli::Parser parser;
+  parser.add("Z", "nuclear charge", true);
+  parser.add("Zl", "left-hand nuclear charge", false, "");
+  parser.add("Zr", "right-hand nuclear charge", false, "");
+  parser.add("Rmid", "distance of nuclei from center", false, "0.0");
+  parser.add("angstrom", "input distances in angstrom", false, "0", true);
+  parser.add("nela", "number of alpha electrons", false, "0");
+  parser.add("nelb", "number of beta  electrons", false, "0");
+  parser.add("Q", "charge state", false, "0");
+  parser.add("M", "spin multiplicity", false, "0");
+  parser.add("lmax", "maximum l quantum number", true);
+  parser.add("mmax", "maximum m quantum number", true);
+  parser.add("Rmax", "practical infinity in au", false, "40.0");
+  parser.add("grid", "type of grid: 1 for linear, 2 for quadratic, 3 for polynomial, 4 for exponential", false, "4");
+  parser.add("grid0", "type of grid: 1 for linear, 2 for quadratic, 3 for polynomial, 4 for exponential", false, "4");
+  parser.add("zexp", "parameter in radial grid", false, "2.0");
+  parser.add("zexp0", "parameter in radial grid", false, "2.0");
+  parser.add("nelem", "number of elements", true);
+  parser.add("nelem0", "number of elements between center and off-center nuclei", false, "0");
+  parser.add("nnodes", "number of nodes per element", false, "15");
+  parser.add("nquad", "number of quadrature points", false, "0");
+  parser.add("maxit", "maximum number of iterations", false, "50");
+  parser.add("convthr", "convergence threshold", false, "1e-7");
+  parser.add("Ez", "electric dipole field", false, "0.0");
+  parser.add("Qzz", "electric quadrupole field", false, "0.0");
+  parser.add("Bz", "magnetic dipole field", false, "0.0");
+  parser.add("diag", "exact diagonalization", false, "1", true);
+  parser.add("method", "method to use", false, "HF");
+  parser.add("ldft", "theta rule for dft quadrature (0 for auto)", false, "0");
+  parser.add("mdft", "phi rule for dft quadrature (0 for auto)", false, "0");
+  parser.add("dftthr", "density threshold for dft", false, "1e-12");
+  parser.add("restricted", "spin-restricted orbitals", false, "-1");
+  parser.add("symmetry", "force orbital symmetry", false, "1");
+  parser.add("primbas", "primitive radial basis", false, "4");
+  parser.add("diiseps", "when to start mixing in diis", false, "1e-2");
+  parser.add("diisthr", "when to switch over fully to diis", false, "1e-3");
+  parser.add("diisorder", "length of diis history", false, "5");
+  parser.add("readocc", "read occupations from file, use until nth build", false, "0");
+  parser.add("perturb", "randomly perturb initial guess", false, "0.0");
+  parser.add("seed", "seed for random perturbation", false, "0");
+  parser.add("iguess", "guess: 0 for core, 1 for GSZ, 2 for SAP, 3 for TF", false, "0");  // see diatomic_main.cpp
+  parser.add("finitenuc", "finite nuclear model", false, "0");
+  parser.add("Rrms", "finite nuclear rms radius", false, "0.0");
+  parser.add("load", "load guess from checkpoint", false, "");
+  parser.add("save", "save calculation to checkpoint", false, "helfem.chk");
+  parser.add("x_pars", "file for parameters for exchange functional", false, "");
+  parser.add("c_pars", "file for parameters for correlation functional", false, "");
+  parser.add("maverage", "average Fock matrix over m values", false, "0", true);
+  parser.add("dampfock", "damping factor for off-diagonal elents", false, "0.7");
+  parser.add("dampthr", "damping threshold", false, "0.1");
+  parser.add("zeroder", "zero derivative at Rmax?", false, "0", true);
+  parser.add("taylor_order", "order of Taylor expansion near the nucleus", false, "-1");
+  parser.add("iconf", "Confinement potential: 1 for polynomial, 2 for exponential, 3 for barrier, 4 for Junquera et al.", false, "0");
+  parser.add("conf_N", "Exponent in confinement potential", false, "0");
+  parser.add("conf_R", "Confinement radius", false, "0.0");
+  parser.add("conf_barrier", "Confinement barrier height", false, "0.0");
+  parser.add("shift_conf", "Where does confinement start?", false, "0.0");
+  parser.add("add_conf", "Add element boundary at shifted potential radius R?", false, "1", true);
+  parser.add("device", "HIP device to run on", false, "0");
+  parser.parse_check(argc, argv);
+
+  try {
+    hfg_scf_options o;
+    hfg_scf_options_default(&o, 1);
+    o.Z1 = hfg_get_Z(parser.str("Z").c_str());
+    if (o.Z1 < 0) fail(hfg_last_error());
+    if (hfg_get_Z(parser.str("Zl").c_str()) != 0 || hfg_get_Z(parser.str("Zr").c_str()) != 0 || parser.real("Rmid") != 0.0 ||
+        parser.integer("nelem0") != 0)
+      fail("Off-center nuclei (--Zl --Zr --Rmid --nelem0) are not supported by this build.\n");
+    o.nela = parser.integer("nela");
+    o.nelb = parser.integer("nelb");
+    o.Q = parser.integer("Q");
+    o.M = parser.integer("M");
+    o.lmax = parser.integer("lmax");
+    o.mmax = parser.integer("mmax");
+    o.Rmax = parser.real("Rmax");
+    o.grid = parser.integer("grid");
+    o.zexp = parser.real("zexp");
+    o.nelem = parser.integer("nelem");
+    o.nnodes = parser.integer("nnodes");
+    o.nquad = parser.integer("nquad");
+    o.maxit = parser.integer("maxit");
+    o.convthr = parser.real("convthr");
+    o.Ez = parser.real("Ez");
+    o.Qzz = parser.real("Qzz");
+    o.Bz = parser.real("Bz");
+    o.diag = parser.boolean("diag") ? 1 : 0;
+    o.finitenuc = parser.integer("finitenuc");
+    snprintf(o.method, sizeof(o.method), "%s", parser.str("method").c_str());
+    o.ldft = parser.integer("ldft");
+    o.mdft = parser.integer("mdft");
+    o.dftthr = parser.real("dftthr");
+    o.restricted = parser.integer("restricted");
+    o.symmetry = parser.integer("symmetry");
+    o.primbas = parser.integer("primbas");
+    o.diiseps = parser.real("diiseps");
+    o.diisthr = parser.real("diisthr");
+    o.diisorder = parser.integer("diisorder");
+    o.readocc = parser.integer("readocc");
+    o.perturb = parser.real("perturb");
+    o.iguess = parser.integer("iguess");
+    snprintf(o.load, sizeof(o.load), "%s", parser.str("load").c_str());
+    snprintf(o.save, sizeof(o.save), "%s", parser.str("save").c_str());
+    o.maverage = parser.boolean("maverage") ? 1 : 0;
+    o.dampfock = parser.real("dampfock");
+    o.dampthr = parser.real("dampthr");
+    o.zeroder = parser.boolean("zeroder") ? 1 : 0;
+    o.iconf = parser.integer("iconf");
+    if (parser.integer("taylor_order") != -1) fail("--taylor_order is not supported by this build (the small-r expansion order is fixed).\n");
+    double xp[64], cp[64];
+    int nx = 64, nc = 64;
+    if (hfg_parse_xc_params(parser.str("x_pars").c_str(), xp, &nx)) fail(hfg_last_error());
+    if (hfg_parse_xc_params(parser.str("c_pars").c_str(), cp, &nc)) fail(hfg_last_error());
+    o.x_pars = nx ? xp : nullptr;
+    o.n_x_pars = nx;
+    o.c_pars = nc ? cp : nullptr;
+    o.n_c_pars = nc;
+    o.verbose = 1;
+
+    printf("Running %s calculation with Rmax=%e and %i elements.\n", o.method, o.Rmax, o.nelem);
+    printf("Using %i point quadrature rule.\n", o.nquad ? o.nquad : 5 * o.nnodes);
+    printf("Nuclear charge is %i\n", o.Z1);
+    fflush(stdout);
+
+    if (hfg_scf_options_check(&o)) fail(hfg_last_error());
+    hfg_ctx *ctx = nullptr;
+    if (hfg_ctx_create(&ctx, parser.integer("device"), nullptr)) fail(hfg_last_error());
+    hfg_scf_result r;
+    int rc = hfg_scf_run(ctx, &o, &r, nullptr, nullptr);
+    if (rc) {
+      std::string msg = hfg_last_error();
+      hfg_ctx_destroy(ctx);
+      fail(msg);
+    }
+    printf("Number of electrons is %i %i\n", r.nela, r.nelb);
+    printf("%s after %i iterations\n", r.converged ? "Converged" : "NOT converged", r.iterations);
+    if (o.save[0]) printf("Checkpoint written to %s\n", o.save);
+    hfg_ctx_destroy(ctx);
+    return r.converged ? 0 : 2;
+  } catch (const std::exception &e) {
+    fail(e.what());
+  }
+  return 1;
+}

@@ -1,6 +1,7 @@
 // C ABI (include/helfem_gpu.h): contexts, host-side basis API, host-pointer and device-pointer
 // entry points.  No torch types, no exceptions across the boundary.
 #include "common.h"
+#include "../host/checkpoint.h"
 #include "../host/diis.h"
 #include "tables.h"
 #include <cstring>
@@ -15,6 +16,7 @@ void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr);
 void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false);
+void set_xc_params(hfg_ctx *ctx, int x_func, const double *x_pars, int nx, int c_func, const double *c_pars, int nc);
 void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
                      double *dHa, double *dHb, double *dScal, double thr);
 void model_potential_dev(hfg_ctx *ctx, hfg_basis *basis, int kind1, int Z1, double d1, double H1, int kind2, int Z2,
@@ -51,12 +53,23 @@ void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc
 using namespace hfg;
 
 #define HFG_TRY try {
-#define HFG_CATCH                   \
-  }                                 \
-  catch (const std::exception &e) { \
-    hfg::set_error(e.what());       \
-    return 1;                       \
-  }                                 \
+// status codes carry the exception class across the C boundary so that the C++ adapter (include/helfem_gpu_arma.hpp)
+// can rethrow what the reference would have thrown: 1 std::logic_error (misuse: "Primitive teis have not been
+// computed!", basis.cpp:1361), 2 std::runtime_error (functional / shape / device errors, dftgrid.cpp:54), 3 anything else
+#define HFG_CATCH                       \
+  }                                     \
+  catch (const std::logic_error &e) {   \
+    hfg::set_error(e.what());           \
+    return 1;                           \
+  }                                     \
+  catch (const std::runtime_error &e) { \
+    hfg::set_error(e.what());           \
+    return 2;                           \
+  }                                     \
+  catch (const std::exception &e) {     \
+    hfg::set_error(e.what());           \
+    return 3;                           \
+  }                                     \
   return 0;
 
 // ---- context helpers ---------------------------------------------------------------------------
@@ -431,6 +444,107 @@ int hfg_diis_weights(int n, const double *B, const double *T, const double *E, d
   HFG_CATCH
 }
 
+// ---- checkpoint files ------------------------------------------------------------------------------------------------
+struct hfg_chk {
+  helfem::Checkpoint c;
+  hfg_chk(const char *path, bool write) : c(path, write) {}
+};
+int hfg_chk_available(void) { return helfem::hdf5_available() ? 1 : 0; }
+int hfg_chk_open(const char *path, int write, hfg_chk **chk) {
+  HFG_TRY
+  *chk = new hfg_chk(path, write != 0);
+  HFG_CATCH
+}
+int hfg_chk_close(hfg_chk *chk) {
+  delete chk;
+  return 0;
+}
+int hfg_chk_exist(hfg_chk *chk, const char *name) {
+  try {
+    return chk->c.exist(name) ? 1 : 0;
+  } catch (...) {
+    return 0;
+  }
+}
+int hfg_chk_write_mat(hfg_chk *chk, const char *name, const double *m, int64_t rows, int64_t cols) {
+  HFG_TRY
+  helfem::Mat M((size_t)rows, (size_t)cols);
+  if (rows * cols) memcpy(M.memptr(), m, sizeof(double) * rows * cols);
+  chk->c.write(name, M);
+  HFG_CATCH
+}
+int hfg_chk_write_ivec(hfg_chk *chk, const char *name, const int *v, int64_t n) {
+  HFG_TRY
+  chk->c.write(name, helfem::IVec(v, v + n));
+  HFG_CATCH
+}
+int hfg_chk_write_double(hfg_chk *chk, const char *name, double v) {
+  HFG_TRY
+  chk->c.write(name, v);
+  HFG_CATCH
+}
+int hfg_chk_write_int(hfg_chk *chk, const char *name, int v) {
+  HFG_TRY
+  chk->c.write(name, v);
+  HFG_CATCH
+}
+int hfg_chk_write_basis(hfg_chk *chk, const hfg_basis *b) {
+  HFG_TRY
+  if (b->kind) chk->c.write(b->ab);
+  else chk->c.write(b->b);
+  HFG_CATCH
+}
+int hfg_chk_read_mat(hfg_chk *chk, const char *name, double *m, int64_t *rows, int64_t *cols) {
+  HFG_TRY
+  if (!m) {
+    std::vector<long long> d = chk->c.dims(name);
+    if (d.size() != 2) throw std::runtime_error(std::string("Error - ") + name + " should have dimension 2.\n");
+    *rows = d[1];  // stored with swapped dimensions
+    *cols = d[0];
+  } else {
+    helfem::Mat M;
+    chk->c.read(name, M);
+    *rows = (int64_t)M.n_rows;
+    *cols = (int64_t)M.n_cols;
+    if (M.n_elem()) memcpy(m, M.memptr(), sizeof(double) * M.n_elem());
+  }
+  HFG_CATCH
+}
+int hfg_chk_read_ivec(hfg_chk *chk, const char *name, int *v, int64_t *n) {
+  HFG_TRY
+  helfem::IVec iv;
+  chk->c.read(name, iv);
+  if (v) {
+    if (*n < (int64_t)iv.size()) throw std::logic_error("hfg_chk_read_ivec: capacity too small\n");
+    std::copy(iv.begin(), iv.end(), v);
+  }
+  *n = (int64_t)iv.size();
+  HFG_CATCH
+}
+int hfg_chk_read_double(hfg_chk *chk, const char *name, double *v) {
+  HFG_TRY
+  chk->c.read(name, *v);
+  HFG_CATCH
+}
+int hfg_chk_read_int(hfg_chk *chk, const char *name, int *v) {
+  HFG_TRY
+  chk->c.read(name, *v);
+  HFG_CATCH
+}
+int hfg_chk_read_diatomic_basis(hfg_chk *chk, int lpad, hfg_basis **out) {
+  HFG_TRY
+  hfg_basis *b = new hfg_basis();
+  try {
+    b->kind = 0;
+    b->b = chk->c.read_diatomic_basis(lpad);
+  } catch (...) {
+    delete b;
+    throw;
+  }
+  *out = b;
+  HFG_CATCH
+}
+
 int hfg_radial_grid(double mumax, int nelem, int igrid, double zexp, double *bval) {
   HFG_TRY
   helfem::Vec g = helfem::get_grid(mumax, nelem, igrid, zexp);
@@ -665,6 +779,41 @@ int hfg_xc_fock_pol(hfg_ctx *ctx, hfg_basis *b, int x_func, int c_func, const do
   *Exc = sc[0];
   *Nel = sc[1];
   *Ekin = sc[2];
+  HFG_CATCH
+}
+int hfg_xc_fock_ext(hfg_ctx *ctx, hfg_basis *b, int x_func, const double *x_pars, int n_x_pars, int c_func, const double *c_pars,
+                    int n_c_pars, const double *P, double *H, double *Exc, double *Nel, double *Ekin, double thr) {
+  HFG_TRY
+  struct Reset {  // the defaults come back whatever happens
+    hfg_ctx *c;
+    ~Reset() {
+      try {
+        set_xc_params(c, 0, nullptr, 0, 0, nullptr, 0);
+      } catch (...) {
+      }
+    }
+  } reset{ctx};
+  set_xc_params(ctx, x_func, x_pars, n_x_pars, c_func, c_pars, n_c_pars);
+  int rc = hfg_xc_fock(ctx, b, x_func, c_func, P, H, Exc, Nel, Ekin, thr);
+  if (rc) return rc;
+  HFG_CATCH
+}
+int hfg_xc_fock_pol_ext(hfg_ctx *ctx, hfg_basis *b, int x_func, const double *x_pars, int n_x_pars, int c_func,
+                        const double *c_pars, int n_c_pars, const double *Pa, const double *Pb, double *Ha, double *Hb, double *Exc,
+                        double *Nel, double *Ekin, double thr) {
+  HFG_TRY
+  struct Reset {
+    hfg_ctx *c;
+    ~Reset() {
+      try {
+        set_xc_params(c, 0, nullptr, 0, 0, nullptr, 0);
+      } catch (...) {
+      }
+    }
+  } reset{ctx};
+  set_xc_params(ctx, x_func, x_pars, n_x_pars, c_func, c_pars, n_c_pars);
+  int rc = hfg_xc_fock_pol(ctx, b, x_func, c_func, Pa, Pb, Ha, Hb, Exc, Nel, Ekin, thr);
+  if (rc) return rc;
   HFG_CATCH
 }
 int hfg_eig_sym(hfg_ctx *ctx, int64_t n, const double *A, double *E, double *C) {

@@ -747,15 +747,11 @@ __global__ __launch_bounds__(256) void k_dgemm_tasks(const GemmTask *__restrict_
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      // four v_mfma_f64_4x4x4_4b per 16 x 16 result block (twice the issue rate of the 16x16x4 form, same result
-      // registers: gemm.hip)
-      double fa[2], fb[2][4];
+      double fa[2], fb[2];
       for (int i = 0; i < 2; i++) fa[i] = As[kk + l4][wm + i * 16 + l15];
-      for (int j = 0; j < 2; j++)
-        for (int c = 0; c < 4; c++) fb[j][c] = Bs[kk + l4][wn + j * 16 + 4 * c + (lane & 3)];
+      for (int j = 0; j < 2; j++) fb[j] = Bs[kk + l4][wn + j * 16 + l15];
       for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 2; j++)
-          for (int c = 0; c < 4; c++) acc[i][j][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(fb[j][c], fa[i], acc[i][j][c], 0, 0, 0);
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   }
   for (int i = 0; i < 2; i++)

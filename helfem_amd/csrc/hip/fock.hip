@@ -1088,6 +1088,39 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   HFG_HIP_CHECK(hipGetLastError());
 }
 
+/// External functional parameters for the following XC builds on this stream (NULL / 0: the functional's defaults).
+/// Supported: lda_x {alpha}, gga_x_pbe {kappa, mu}, gga_c_pbe {beta, gamma, BB} -- libxc's parameter lists; anything
+/// else throws (std::runtime_error, as libxc's "number of parameters" check does through the reference).
+void set_xc_params(hfg_ctx *ctx, int x_func, const double *x_pars, int nx, int c_func, const double *c_pars, int nc) {
+  xc::XCPar par = HFG_XCPAR_DEFAULTS;
+  if (nx > 0) {
+    if (!x_pars) throw std::runtime_error("Exchange functional parameters missing.\n");
+    if (x_func == 1 && nx == 1) par.x_alpha = x_pars[0];
+    else if (x_func == 101 && nx == 2) {
+      par.x_kappa = x_pars[0];
+      par.x_mu = x_pars[1];
+    } else
+      throw std::runtime_error("External parameters are not supported for exchange functional " + std::to_string(x_func) + " with " +
+                               std::to_string(nx) + " values (supported: lda_x {alpha}, gga_x_pbe {kappa, mu}).\n");
+  }
+  if (nc > 0) {
+    if (!c_pars) throw std::runtime_error("Correlation functional parameters missing.\n");
+    if (c_func == 130 && nc == 3) {
+      par.c_beta = c_pars[0];
+      par.c_gamma = c_pars[1];
+      par.c_BB = c_pars[2];
+    } else
+      throw std::runtime_error("External parameters are not supported for correlation functional " + std::to_string(c_func) + " with " +
+                               std::to_string(nc) + " values (supported: gga_c_pbe {beta, gamma, BB}).\n");
+  }
+  // the host copy must stay valid until the asynchronous copy has run: a small per-thread ring
+  static thread_local xc::XCPar staged[8];
+  static thread_local int slot = 0;
+  staged[slot] = par;
+  HFG_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(xc::c_xcpar), &staged[slot], sizeof(par), 0, hipMemcpyHostToDevice, ctx->stream));
+  slot = (slot + 1) % 8;
+}
+
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr) {
   hfg_dev_tables *t = tables_of(ctx, basis);

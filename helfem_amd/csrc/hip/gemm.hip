@@ -13,17 +13,18 @@
 // so that lane&15 runs along the rows of C, contiguous in column-major memory, and a result
 // register stores 16 consecutive doubles (128 B) per 16-lane group.
 //
-// Matrix instruction.  On gfx950 v_mfma_f64_16x16x4_f64 sustains 35.8 TFLOP/s in a register-only loop, the four-block
-// v_mfma_f64_4x4x4_4b_f64 76.6 TFLOP/s -- the data-sheet FP64 matrix rate -- and v_fma_f64 44-60 TFLOP/s (the vector
-// loop throttles the shader clock to 1.8-2.1 GHz; profiles/r02_fp64_rate.txt, tests/gpu_probe/fp64_rate.hip).  The
-// tile engine therefore issues the 4x4x4 form (MF = 0).  Its lane maps (tests/gpu_probe/mfma4x4_probe.hip,
-// profiles/r02_mfma4x4_lane_maps.txt):  a-operand lane 16 k + 4 blk + i holds A_blk[i][k], b-operand lane
-// 16 k + 4 blk + j holds B_blk[k][j], result lane 16 i + 4 blk + j holds D_blk[i][j].  With the b-operand taken from
-// the A tile exactly as for the 16x16x4 form (lane l: As[k0 + (l >> 4)][m0 + (l & 15)], the four blocks being four groups
-// of four consecutive rows) and the a-operand Bs[k0 + (l >> 4)][n0 + 4 c + (l & 3)] (the same 4 x 4 block of B in all
-// four blocks), instruction c = 0..3 accumulates C[m0 + (l & 15)][n0 + 4 c + (l >> 4)]: the four instructions together
-// fill the same four result registers, in the same layout, as one 16x16x4 instruction, so the epilogues are shared.
-// MF = 1 keeps the 16x16x4 form (HELFEM_MFMA=16x16x4) for A/B runs.
+// Matrix instruction.  Both FP64 forms are compiled: v_mfma_f64_16x16x4_f64 (MF = 1, the default) and the four-block
+// v_mfma_f64_4x4x4_4b_f64 (MF = 0, HELFEM_MFMA=4x4x4).  Measured on gfx950 with this tile engine (tools/gemm_bench.py,
+// profiles/r02_gemm_bench.txt): 54.4 / 51.5 TFLOP/s at m = n = k = 2816 and 47.0 / 46.2 at 4230 -- the same within the
+// noise, 69 % of the 78.6 TFLOP/s data-sheet rate -- and 29.5 at 1400 (121 tiles of 128 x 128 on 256 CUs).  (A
+// register-only loop of the 16x16x4 form with every instruction reading the SAME operand registers sustains only 36
+// TFLOP/s, the 4x4x4 form 77: profiles/r02_fp64_rate.txt; that loop under-reports the 16x16x4 rate and was mistaken for
+// the ceiling in round 1.)  Lane maps of the 4x4x4 form (tests/gpu_probe/mfma4x4_probe.hip,
+// profiles/r02_mfma4x4_lane_maps.txt): a-operand lane 16 k + 4 blk + i holds A_blk[i][k], b-operand lane 16 k + 4 blk + j
+// holds B_blk[k][j], result lane 16 i + 4 blk + j holds D_blk[i][j].  With the b-operand taken from the A tile exactly as
+// for the 16x16x4 form (lane l: As[k0 + (l >> 4)][m0 + (l & 15)]) and the a-operand Bs[k0 + (l >> 4)][n0 + 4 c + (l & 3)],
+// instruction c = 0..3 accumulates C[m0 + (l & 15)][n0 + 4 c + (l >> 4)]: four instructions fill the same four result
+// registers, in the same layout, as one 16x16x4 instruction, so the epilogues are shared.
 //
 // Tiling: 256 threads = 4 waves in a 2x2 arrangement, block tile BM x BN (128x128 or 64x64,
 // chosen by the launcher so that small problems still give >= 256 workgroups), BK = 16.
@@ -45,7 +46,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // before the first store: interleaved "load, scale, store" through the bounds branches serialises 64 memory round
 // trips per thread, which made the rank-2NB trailing updates and the compact-WY updates of the eigensolver (K = 32
 // or 64: pure streaming of C) run at 1.2-1.6 TB/s.
-template <int BM, int BN, bool ACC = false, int MF = 0>
+template <int BM, int BN, bool ACC = false, int MF = 1>
 __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
                                            const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
                                            double beta, double *__restrict__ C, int ldc, double (*As)[16][BM + 16],
@@ -317,7 +318,7 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
       }
 }
 
-template <int BM, int BN, int MF = 0>
+template <int BM, int BN, int MF = 1>
 __global__ __launch_bounds__(256, 2) void k_dgemm(int transA, int transB, int M, int N, int K, double alpha,
                                                const double *__restrict__ A, int lda, const double *__restrict__ B,
                                                int ldb, double beta, double *__restrict__ C, int ldc) {
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_dgemm(int transA, int transB, int M,
 }
 
 // the same tile engine over a device-side task list: C_t = A_t B_t, grid (max tiles, tasks)
-template <int BM, int BN, bool ACC = false, int MF = 0>
+template <int BM, int BN, bool ACC = false, int MF = 1>
 __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__restrict__ tasks) {
   __shared__ __attribute__((aligned(16))) double As[2][16][BM + 16];
   __shared__ __attribute__((aligned(16))) double Bs[2][16][BN + 16];
@@ -341,9 +342,9 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__res
                               As, Bs, sym);
 }
 
-/// HELFEM_MFMA=16x16x4 selects the v_mfma_f64_16x16x4_f64 form of the tile engine (half the issue rate; A/B runs)
-static bool mfma16() {
-  static const bool v = (getenv("HELFEM_MFMA") && !strcmp(getenv("HELFEM_MFMA"), "16x16x4"));
+/// HELFEM_MFMA=4x4x4 selects the v_mfma_f64_4x4x4_4b_f64 form of the tile engine (A/B runs; same speed, more LDS reads)
+static bool mfma4() {
+  static const bool v = (getenv("HELFEM_MFMA") && !strcmp(getenv("HELFEM_MFMA"), "4x4x4"));
   return v;
 }
 
@@ -353,11 +354,11 @@ void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int
   ProfScope ps(ctx, "gemm");
   if (tile64) {
     const int tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
-    if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, true, 1>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+    if (mfma4()) hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, true, 0>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
     else hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   } else {
     const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
-    if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true, 1>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+    if (mfma4()) hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true, 0>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
     else hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, true>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   }
   HFG_HIP_CHECK(hipGetLastError());
@@ -402,7 +403,7 @@ void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int m
   if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
   ProfScope ps(ctx, "gemm");
   const int tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
-  if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, false, 1>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  if (mfma4()) hipLaunchKernelGGL((k_dgemm_tasklist<64, 64, false, 0>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   else hipLaunchKernelGGL((k_dgemm_tasklist<64, 64>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   HFG_HIP_CHECK(hipGetLastError());
 }
@@ -414,7 +415,7 @@ void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int max
   const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
   for (int t0 = 0; t0 < ntasks; t0 += 65535) {
     int nt = std::min(65535, ntasks - t0);
-    if (mfma16()) hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, false, 1>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
+    if (mfma4()) hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, false, 0>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
     else hipLaunchKernelGGL((k_dgemm_tasklist<128, 128>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
   }
   HFG_HIP_CHECK(hipGetLastError());
@@ -426,16 +427,16 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
   ProfScope ps(ctx, "gemm");
   long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (big_tiles >= 512) {
-    if (mfma16())
-      hipLaunchKernelGGL((k_dgemm<128, 128, 1>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
+    if (mfma4())
+      hipLaunchKernelGGL((k_dgemm<128, 128, 0>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
                          alpha, A, lda, B, ldb, beta, C, ldc);
     else
       hipLaunchKernelGGL((k_dgemm<128, 128>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
                          alpha, A, lda, B, ldb, beta, C, ldc);
   } else {
     long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    if (mfma16())
-      hipLaunchKernelGGL((k_dgemm<64, 64, 1>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K, alpha, A,
+    if (mfma4())
+      hipLaunchKernelGGL((k_dgemm<64, 64, 0>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K, alpha, A,
                          lda, B, ldb, beta, C, ldc);
     else
       hipLaunchKernelGGL((k_dgemm<64, 64>), dim3((unsigned)tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K, alpha, A,

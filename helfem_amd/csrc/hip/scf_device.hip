@@ -104,6 +104,13 @@ __global__ void k_finish_reduce(const double *__restrict__ partial, int nb, int 
   *out = s;
 }
 
+// f(i, j) *= fac on the occupied-virtual blocks (i < nocc <= j and j < nocc <= i) of an n x n matrix
+__global__ void k_scale_offdiag_blocks(double *__restrict__ f, int n, int nocc, double fac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i >= n) return;
+  if ((i < nocc) != (j < nocc)) f[(size_t)j * n + i] *= fac;
+}
+
 double wall() {
   using namespace std::chrono;
   return duration_cast<duration<double> >(steady_clock::now().time_since_epoch()).count();
@@ -166,9 +173,11 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   res.Enucr = Enucr;
   const bool verbose = opt.verbose;
   const bool dft = (opt.x_func > 0 || opt.c_func > 0);
-  const int M = opt.multiplicity;
-  if (M < 1 || (nel + M - 1) % 2 != 0 || M - 1 > nel) throw std::logic_error("Requested multiplicity not achievable.\n");
-  const int nela = (nel + M - 1) / 2, nelb = nel - nela;
+  int nela = opt.nela, nelb = opt.nelb;
+  {
+    int Qv = opt.Q, Mv = opt.multiplicity;
+    helfem::scf::parse_nela_nelb(nela, nelb, Qv, Mv, nel + opt.Q);  // nel = Ztot - Q
+  }
   const bool restr_req = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
   const bool rohf = restr_req && nela != nelb;  // restricted open shell: unrestricted machinery + CUHF constraint
   const bool restr = restr_req && !rohf;
@@ -478,9 +487,23 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     const bool convd = (diiserr < opt.convthr) && (fabs(dE) < opt.convthr);
 
     t0 = wall();
+    const bool damping = (opt.dampfock != 1.0 && diiserr >= opt.dampthr);  // atomic/main.cpp:917-936
+    if (damping && verbose) printf("Damping off-diagonal elements of Fock matrix by % .3f\n", opt.dampfock);
     for (int sp = 0; sp < nspin; sp++) {
       double *Fd = d.T1.p;
       for (size_t a = 0; a < nh; a++) d.axpby(coef[a], d.histF[slots[a]].p + sp * NN, a ? 1.0 : 0.0, Fd, NN);
+      const int nocc = sp ? nelb : nela;
+      if (damping && nocc > 0 && n > nocc) {
+        // F <- S C f C^T S with f = C^T F C, its occupied-virtual blocks scaled (C: the orbitals that built this density)
+        const double *Cs = sp ? d.Cb.p : d.Ca.p;
+        gemm_dev(ctx, true, false, n, n, n, 1.0, Cs, n, Fd, n, 0.0, d.T2.p, n);         // C^T F
+        gemm_dev(ctx, false, false, n, n, n, 1.0, d.T2.p, n, Cs, n, 0.0, d.Err.p, n);    // f
+        hipLaunchKernelGGL(k_scale_offdiag_blocks, dim3((n + 255) / 256, n), dim3(256), 0, s, d.Err.p, n, nocc, opt.dampfock);
+        gemm_dev(ctx, false, false, n, n, n, 1.0, d.S.p, n, Cs, n, 0.0, d.T2.p, n);      // S C
+        gemm_dev(ctx, false, false, n, n, n, 1.0, d.T2.p, n, d.Err.p, n, 0.0, Fd, n);    // S C f
+        gemm_dev(ctx, false, true, n, n, n, 1.0, Fd, n, d.T2.p, n, 0.0, d.Err.p, n);     // S C f (S C)^T
+        HFG_HIP_CHECK(hipMemcpyAsync(Fd, d.Err.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+      }
       eig_gsym_sub_dev(ctx, n, Fd, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), sp ? d.Eb.p : d.Ea.p,
                        sp ? d.Cb.p : d.Ca.p);
     }
@@ -502,6 +525,32 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   res.C.zeros(N, N);
   HFG_HIP_CHECK(hipMemcpyAsync(res.C.memptr(), d.Ca.p, sizeof(double) * NN, hipMemcpyDeviceToHost, s));
   HFG_HIP_CHECK(hipStreamSynchronize(s));
+  if (opt.keep_matrices) {  // what the reference's drivers write to their checkpoint, from HBM
+    auto down = [&](const char *name, const double *p, size_t rows, size_t cols) {
+      helfem::Mat m(rows, cols);
+      if (p) HFG_HIP_CHECK(hipMemcpy(m.memptr(), p, sizeof(double) * rows * cols, hipMemcpyDeviceToHost));
+      res.mats[name] = m;
+    };
+    down("S", d.S.p, N, N);
+    down("T", d.T.p, N, N);
+    down("Vnuc", d.V.p, N, N);
+    down("H0", d.H0.p, N, N);
+    down("Sinvh", d.Sinvh.p, N, N);
+    down("P", d.P.p, N, N);
+    down("Pa", d.Pa.p, N, N);
+    down("Pb", restr ? d.Pa.p : d.Pb.p, N, N);
+    down("J", d.J.p, N, N);
+    down("Ka", anyK ? d.Ka.p : nullptr, anyK ? N : 0, anyK ? N : 0);
+    down("Kb", anyK ? (restr ? d.Ka.p : d.Kb.p) : nullptr, anyK ? N : 0, anyK ? N : 0);
+    down("XCa", dft ? d.XCa.p : nullptr, dft ? N : 0, dft ? N : 0);
+    down("XCb", dft ? (restr ? d.XCa.p : d.XCb.p) : nullptr, dft ? N : 0, dft ? N : 0);
+    down("Fa", d.Fa.p, N, N);
+    down("Fb", restr ? d.Fa.p : d.Fb.p, N, N);
+    down("Cb", restr ? d.Ca.p : d.Cb.p, N, N);
+    res.mats["Ca"] = res.C;
+    res.Eb.resize(N);
+    HFG_HIP_CHECK(hipMemcpy(res.Eb.data(), restr ? d.Ea.p : d.Eb.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  }
   if (verbose) {
     printf("%-21s energy: % .16f\n", "Kinetic", res.Ekin);
     printf("%-21s energy: % .16f\n", "Nuclear attraction", res.Epot);

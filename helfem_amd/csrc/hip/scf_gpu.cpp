@@ -2,7 +2,10 @@
 // C ABI entry points of include/helfem_gpu.h, exactly as an Armadillo-based caller would.
 #include "common.h"
 #include "../host/dftfuncs.h"
+#include "../host/checkpoint.h"
 #include "../host/scf.h"
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -127,7 +130,7 @@ bool host_driver() {
 
 // set-up of src/diatomic/main.cpp:245-430 (basis, quadrature defaults, symmetry), then the device-resident loop
 helfem::scf::Result run_diatomic_device(hfg_ctx *ctx, const helfem::scf::Options &opt) {
-  int nel = opt.Z1 + opt.Z2;
+  int nel = opt.Z1 + opt.Z2 - opt.Q;
   int Nquad = opt.nquad;
   if (Nquad == 0) Nquad = 5 * opt.nnodes;
   else if (Nquad < 2 * opt.nnodes) throw std::logic_error("Insufficient radial quadrature.\n");
@@ -269,9 +272,15 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
     out[9] = r.tK;
     out[10] = r.tXC;
     out[11] = r.tdiag;
-  } catch (const std::exception &e) {
+  } catch (const std::logic_error &e) {
     hfg::set_error(e.what());
     return 1;
+  } catch (const std::runtime_error &e) {
+    hfg::set_error(e.what());
+    return 2;
+  } catch (const std::exception &e) {
+    hfg::set_error(e.what());
+    return 3;
   }
   return 0;
 }
@@ -289,6 +298,8 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
     a.lmax = lmax;
     a.mmax = mmax;
     helfem::scf::Options &o = a.common;
+    o.dampfock = 0.7;  // defaults of the atomic program (atomic/main.cpp:111-112)
+    o.dampthr = 0.1;
     o.nelem = nelem;
     o.nnodes = nnodes;
     o.nquad = nquad;
@@ -328,9 +339,297 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
     out[9] = r.tK;
     out[10] = r.tXC;
     out[11] = r.tdiag;
-  } catch (const std::exception &e) {
+  } catch (const std::logic_error &e) {
     hfg::set_error(e.what());
     return 1;
+  } catch (const std::runtime_error &e) {
+    hfg::set_error(e.what());
+    return 2;
+  } catch (const std::exception &e) {
+    hfg::set_error(e.what());
+    return 3;
+  }
+  return 0;
+}
+
+// ---- complete runs behind one options structure (the reference's command lines) --------------------------------------
+static const char *const k_elements[] = {
+    "",   "H",  "He", "Li", "Be", "B",  "C",  "N",  "O",  "F",  "Ne", "Na", "Mg", "Al", "Si", "P",  "S",  "Cl", "Ar", "K",
+    "Ca", "Sc", "Ti", "V",  "Cr", "Mn", "Fe", "Co", "Ni", "Cu", "Zn", "Ga", "Ge", "As", "Se", "Br", "Kr", "Rb", "Sr", "Y",
+    "Zr", "Nb", "Mo", "Tc", "Ru", "Rh", "Pd", "Ag", "Cd", "In", "Sn", "Sb", "Te", "I",  "Xe", "Cs", "Ba", "La", "Ce", "Pr",
+    "Nd", "Pm", "Sm", "Eu", "Gd", "Tb", "Dy", "Ho", "Er", "Tm", "Yb", "Lu", "Hf", "Ta", "W",  "Re", "Os", "Ir", "Pt", "Au",
+    "Hg", "Tl", "Pb", "Bi", "Po", "At", "Rn", "Fr", "Ra", "Ac", "Th", "Pa", "U",  "Np", "Pu", "Am", "Cm", "Bk", "Cf", "Es",
+    "Fm", "Md", "No", "Lr", "Rf", "Db", "Sg", "Bh", "Hs", "Mt", "Ds", "Rg", "Cn", "Nh", "Fl", "Mc", "Lv", "Ts", "Og"};
+
+int hfg_get_Z(const char *el) {
+  if (!el || !el[0]) return 0;  // no nucleus (elements.cpp:27-29)
+  if (!isalpha((unsigned char)el[0])) return atoi(el);
+  for (int Z = 1; Z < (int)(sizeof(k_elements) / sizeof(k_elements[0])); Z++) {
+    const char *a = el, *b = k_elements[Z];
+    while (*a && *b && tolower((unsigned char)*a) == tolower((unsigned char)*b)) a++, b++;
+    if (!*a && !*b) return Z;
+  }
+  hfg::set_error(std::string("Element \"") + el + "\" not found in table of elements!\n");
+  return -1;
+}
+
+int hfg_parse_xc_params(const char *input, double *pars, int *n) {
+  try {
+    const int cap = *n;
+    *n = 0;
+    if (!input || !input[0]) return 0;
+    std::string text;
+    {
+      FILE *f = fopen(input, "r");
+      if (f) {  // a file name: one or more numbers, whitespace separated (arma raw_ascii)
+        char buf[4096];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+        fclose(f);
+      } else
+        text = input;  // a string of numbers (arma::vec(std::string))
+    }
+    const char *ptr = text.c_str();
+    for (;;) {
+      while (*ptr && (isspace((unsigned char)*ptr) || *ptr == ',' || *ptr == ';')) ptr++;
+      if (!*ptr) break;
+      char *end = nullptr;
+      double v = strtod(ptr, &end);
+      if (end == ptr) throw std::runtime_error(std::string("Cannot parse functional parameters from \"") + input + "\"\n");
+      if (*n >= cap) throw std::logic_error("hfg_parse_xc_params: capacity too small\n");
+      pars[(*n)++] = v;
+      ptr = end;
+    }
+  } catch (const std::logic_error &e) {
+    hfg::set_error(e.what());
+    return 1;
+  } catch (const std::runtime_error &e) {
+    hfg::set_error(e.what());
+    return 2;
+  } catch (const std::exception &e) {
+    hfg::set_error(e.what());
+    return 3;
+  }
+  return 0;
+}
+
+int hfg_scf_options_default(hfg_scf_options *o, int program) {
+  if (!o) return 1;
+  memset(o, 0, sizeof(*o));
+  o->program = program;
+  o->Rbond = 0.0;
+  o->M = 0;
+  o->mmax = program ? 0 : -1;
+  o->lpad = 10;
+  o->Rmax = 40.0;
+  o->grid = 4;
+  o->zexp = program ? 2.0 : 1.0;
+  o->nnodes = 15;
+  o->maxit = 50;
+  o->convthr = 1e-7;
+  o->diag = 1;
+  strcpy(o->method, "HF");
+  o->dftthr = 1e-12;
+  o->restricted = -1;
+  o->symmetry = 1;
+  o->primbas = 4;
+  o->diiseps = 1e-2;
+  o->diisthr = 1e-3;
+  o->diisorder = 5;
+  o->dampfock = program ? 0.7 : 1.0;
+  o->dampthr = 0.1;
+  o->iguess = 0;  // the reference default (2, SAP) needs its tabulated potentials: the drivers say so when it is asked for
+  strcpy(o->save, "helfem.chk");
+  o->verbose = 1;
+  return 0;
+}
+
+namespace hfg {
+// what the reference's drivers leave in their checkpoint (diatomic/main.cpp:236-537, 790-963), in its HDF5 layout
+void write_checkpoint(const hfg_scf_options &p, const helfem::scf::Options &o, const helfem::scf::Result &r) {
+  helfem::Checkpoint chk(p.save, true);
+  chk.write("nela", r.nela);
+  chk.write("nelb", r.nelb);
+  int Nquad = o.nquad ? o.nquad : 5 * o.nnodes;
+  if (p.program == 0) {
+    helfem::IVec lval, mval;
+    helfem::diatomic::lm_to_l_m(o.lmmax, lval, mval);
+    const double Rhalf = 0.5 * o.Rbond;
+    helfem::Vec bval = helfem::get_grid(helfem::arcosh(o.Rmax / Rhalf), o.nelem, o.igrid, o.zexp);
+    chk.write(helfem::diatomic::TwoDBasis(o.Z1, o.Z2, Rhalf, o.nnodes, Nquad, bval, lval, mval, o.lpad));
+  } else {
+    helfem::IVec lval, mval;
+    helfem::atomic::angular_basis(p.lmax, p.mmax, lval, mval);
+    chk.write(helfem::atomic::TwoDBasis(p.Z1, o.nnodes, Nquad, helfem::get_grid(o.Rmax, o.nelem, o.igrid, o.zexp), lval, mval));
+  }
+  chk.write("Enucr", r.Enucr);
+  for (const char *name : {"S", "T", "Sinvh", "Vnuc", "H0", "P", "Pa", "Pb", "J", "Ka", "Kb", "XCa", "XCb", "Fa", "Fb", "Ca", "Cb"}) {
+    auto it = r.mats.find(name);
+    if (it != r.mats.end()) chk.write(name, it->second);
+  }
+  chk.write("Ekin", r.Ekin);
+  chk.write("Epot", r.Epot);
+  chk.write("Eefield", 0.0);
+  chk.write("Emfield", 0.0);
+  chk.write("Ecoul", r.Ecoul);
+  chk.write("Exx", r.Exx);
+  chk.write("Exc", r.Exc);
+  chk.write("Etot", r.Etot);
+  chk.write("Ea", r.E);
+  chk.write("Eb", r.Eb.empty() ? r.E : r.Eb);
+  chk.write("Converged", r.converged ? 1 : 0);
+}
+}  // namespace hfg
+
+static void check_options(const hfg_scf_options &p) {
+    // features outside the hot-path scope: refuse loudly rather than compute something else
+  if (p.Ez != 0.0 || p.Qzz != 0.0 || p.Bz != 0.0) throw std::logic_error("External electric / magnetic fields are not supported by this build.\n");
+  if (p.finitenuc != 0) throw std::logic_error("Finite nuclear models are not supported by this build.\n");
+  if (p.readocc != 0) throw std::logic_error("Forced occupations (--readocc) are not supported by this build.\n");
+  if (p.perturb != 0.0) throw std::logic_error("Random perturbation of the guess (--perturb) is not supported by this build.\n");
+  if (p.primbas != 4) throw std::logic_error("Only the LIP primitive basis (--primbas 4) is supported by this build.\n");
+  if (p.iconf != 0) throw std::logic_error("Confinement potentials (--iconf) are not supported by this build.\n");
+  if (p.zeroder != 0) throw std::logic_error("--zeroder is not supported by this build.\n");
+  if (p.load[0]) throw std::logic_error("Loading a guess from a checkpoint (--load) is not supported by this build.\n");
+  if (p.iguess == 2) throw std::logic_error("Unsupported guess (SAP needs the reference's tabulated potentials)\n");
+  if (p.iguess == 1) throw std::logic_error("Unsupported guess (GSZ needs the reference's per-element parameters)\n");
+  if (p.iguess != 0 && p.iguess != 3) throw std::logic_error("Unsupported guess\n");
+  if (p.n_x_pars > 0 || p.n_c_pars > 0)
+    throw std::logic_error("External functional parameters (--x_pars / --c_pars) are not supported by the SCF driver of this build.\n");
+
+  if (p.nelem <= 0) throw std::logic_error("need option: --nelem\n");
+  if (p.program == 0) {
+    if (p.nlm <= 0 || p.nlm > HFG_MAX_LMMAX) throw std::logic_error("need option: --lmax\n");
+    if (!(p.Rbond > 0.0)) throw std::logic_error("need option: --Rbond\n");
+    if (p.maverage) throw std::logic_error("--maverage is implemented for the atomic program only in this build.\n");
+  }
+  int x_func, c_func;
+  helfem::parse_xc_func(x_func, c_func, p.method);  // throws on unknown functionals
+  bool erf, yuk;
+  helfem::is_range_separated(x_func, erf, yuk);
+  if (p.program == 0 && (erf || yuk)) throw std::logic_error("Range separated functionals are not supported.\n");  // diatomic/main.cpp:393
+  int nela = p.nela, nelb = p.nelb, Q = p.Q, M = p.M > 0 ? p.M : 1;
+  helfem::scf::parse_nela_nelb(nela, nelb, Q, M, p.program == 0 ? p.Z1 + p.Z2 : p.Z1);
+  if (nela + nelb <= 0) throw std::logic_error("No electrons.\n");
+}
+
+/* validates an options structure the way hfg_scf_run does before it touches the device (usable without a GPU) */
+int hfg_scf_options_check(const hfg_scf_options *opt) {
+  try {
+    if (!opt) throw std::logic_error("hfg_scf_options_check: null argument\n");
+    check_options(*opt);
+  } catch (const std::logic_error &e) {
+    hfg::set_error(e.what());
+    return 1;
+  } catch (const std::runtime_error &e) {
+    hfg::set_error(e.what());
+    return 2;
+  } catch (const std::exception &e) {
+    hfg::set_error(e.what());
+    return 3;
+  }
+  return 0;
+}
+
+int hfg_scf_run(hfg_ctx *ctx, const hfg_scf_options *in, hfg_scf_result *res, double *E, double *C) {
+  try {
+    if (!ctx || !in || !res) throw std::logic_error("hfg_scf_run: null argument\n");
+    const hfg_scf_options &p = *in;
+    check_options(p);
+
+    helfem::scf::AtomicOptions a;
+    helfem::scf::Options &o = a.common;
+    o.nela = p.nela;
+    o.nelb = p.nelb;
+    o.Q = p.Q;
+    o.multiplicity = p.M > 0 ? p.M : 1;
+    o.restricted = p.restricted;
+    o.lpad = p.lpad;
+    o.Rmax = p.Rmax;
+    o.igrid = p.grid;
+    o.zexp = p.zexp;
+    o.nelem = p.nelem;
+    o.nnodes = p.nnodes;
+    o.nquad = p.nquad;
+    o.maxit = p.maxit;
+    o.convthr = p.convthr;
+    o.diag = p.diag != 0;
+    o.method = p.method;
+    helfem::parse_xc_func(o.x_func, o.c_func, o.method);
+    helfem::range_separation(o.x_func, o.omega, o.kfrac, o.kshort);
+    {
+      bool erf, yuk;
+      helfem::is_range_separated(o.x_func, erf, yuk);
+      o.rs_kind = yuk ? 1 : (erf ? 2 : 0);
+    }
+    o.ldft = p.ldft;
+    o.mdft = p.mdft;
+    o.dftthr = p.dftthr;
+    o.symmetry = p.symmetry;
+    o.diiseps = p.diiseps;
+    o.diisthr = p.diisthr;
+    o.diisorder = p.diisorder;
+    o.iguess = p.iguess;
+    o.dampfock = p.program ? p.dampfock : 1.0;
+    o.dampthr = p.dampthr;
+    o.verbose = p.verbose != 0;
+    o.keep_matrices = p.save[0] != 0;
+    if (o.keep_matrices) {
+      std::string why;
+      if (!helfem::hdf5_available(&why))  // before the run, not after it
+        throw std::runtime_error("Checkpoint: no usable HDF5 library in this process (" + why + "set HELFEM_HDF5_LIB, or run with --save \"\")\n");
+    }
+    helfem::scf::Result r;
+    if (p.program == 0) {
+      o.Z1 = p.Z1;
+      o.Z2 = p.Z2;
+      o.Rbond = p.Rbond;
+      o.lmmax.assign(p.lmmax, p.lmmax + p.nlm);
+      if (host_driver()) {
+        GPUBackend be(ctx);
+        r = helfem::scf::run_diatomic(o, be);
+      } else
+        r = run_diatomic_device(ctx, o);
+    } else {
+      a.Z = p.Z1;
+      a.Q = p.Q;
+      a.lmax = p.lmax;
+      a.mmax = p.mmax;
+      a.maverage = p.maverage != 0;
+      if (host_driver()) {
+        GPUBackend be(ctx);
+        r = helfem::scf::run_atomic(a, be);
+      } else
+        r = run_atomic_device(ctx, a);
+    }
+    res->Etot = r.Etot;
+    res->Ekin = r.Ekin;
+    res->Epot = r.Epot;
+    res->Enucr = r.Enucr;
+    res->Ecoul = r.Ecoul;
+    res->Exx = r.Exx;
+    res->Exc = r.Exc;
+    res->iterations = r.iterations;
+    res->converged = r.converged ? 1 : 0;
+    res->nela = r.nela;
+    res->nelb = r.nelb;
+    res->Nbf = (int64_t)r.Nbf;
+    res->tJ = r.tJ;
+    res->tK = r.tK;
+    res->tXC = r.tXC;
+    res->tdiag = r.tdiag;
+    if (E && r.E.size()) memcpy(E, r.E.data(), sizeof(double) * r.E.size());
+    if (C && r.C.n_elem()) memcpy(C, r.C.memptr(), sizeof(double) * r.C.n_elem());
+    if (p.save[0]) hfg::write_checkpoint(p, o, r);
+  } catch (const std::logic_error &e) {
+    hfg::set_error(e.what());
+    return 1;
+  } catch (const std::runtime_error &e) {
+    hfg::set_error(e.what());
+    return 2;
+  } catch (const std::exception &e) {
+    hfg::set_error(e.what());
+    return 3;
   }
   return 0;
 }

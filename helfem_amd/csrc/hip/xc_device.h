@@ -75,6 +75,17 @@ __host__ __device__ inline Dual derf(Dual a) {
 #define HFG_PI 3.14159265358979323846
 
 // energy per particle of each functional as a Dual in (rho, sigma)
+// External functional parameters (libxc's xc_func_set_ext_params as the reference calls it for --x_pars / --c_pars,
+// dftgrid.cpp:405-410), in libxc's order: lda_x {alpha = 1}, gga_x_pbe {kappa = 0.8040, mu = beta pi^2/3},
+// gga_c_pbe {beta = 0.06672455060314922, gamma = (1 - ln 2)/pi^2, BB = 1}.  One constant-memory copy per translation
+// unit (this header is included by fock.hip only); set_xc_params() there fills it before the grid kernels are launched.
+struct XCPar {
+  double x_alpha, x_kappa, x_mu, c_beta, c_gamma, c_BB;
+};
+#define HFG_XCPAR_DEFAULTS \
+  { 1.0, 0.8040, 0.06672455060314922 * HFG_PI * HFG_PI / 3.0, 0.06672455060314922, (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI), 1.0 }
+static __constant__ XCPar c_xcpar = HFG_XCPAR_DEFAULTS;
+
 __host__ __device__ inline Dual eps_lda_x(Dual rho) { return (-0.75 * cbrt(3.0 / HFG_PI)) * dcbrt(rho); }
 
 // Short-range LDA exchange of the range-separated hybrids: eps_x^sr = eps_x^LDA(rho) F(a), a = omega/(2 k_F).
@@ -149,8 +160,8 @@ __host__ __device__ inline Dual eps_lda_c_pw(Dual rho) {
 }
 
 __host__ __device__ inline Dual eps_gga_x_pbe(Dual rho, Dual sigma) {
-  const double kappa = 0.8040;
-  const double mu = 0.06672455060314922 * HFG_PI * HFG_PI / 3.0;
+  const double kappa = c_xcpar.x_kappa;
+  const double mu = c_xcpar.x_mu;
   Dual exu = eps_lda_x(rho);
   Dual kf = dcbrt((3.0 * HFG_PI * HFG_PI) * rho);
   Dual s2 = sigma / (4.0 * kf * kf * rho * rho);
@@ -159,9 +170,10 @@ __host__ __device__ inline Dual eps_gga_x_pbe(Dual rho, Dual sigma) {
 }
 
 __host__ __device__ inline Dual eps_gga_c_pbe(Dual rho, Dual sigma) {
-  const double beta = 0.06672455060314922;
-  const double gamma = (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI);
+  const double beta = c_xcpar.c_beta;
+  const double gamma = c_xcpar.c_gamma;
   const double B = beta / gamma;
+  const double BB = c_xcpar.c_BB;
   Dual rs = dcbrt(3.0 / (4.0 * HFG_PI) / rho);
   Dual ec = eps_pw92(rs, true);
   Dual kf = dcbrt((3.0 * HFG_PI * HFG_PI) * rho);
@@ -169,7 +181,9 @@ __host__ __device__ inline Dual eps_gga_c_pbe(Dual rho, Dual sigma) {
   Dual t2 = sigma / (4.0 * ks2 * rho * rho);
   Dual Aa = B / dexpm1(-ec / gamma);
   Dual At2 = Aa * t2;
-  Dual H = gamma * dlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  // libxc: f1 = t^2 + BB A t^4, H = gamma log(1 + (beta/gamma) f1 / (1 + A f1)); BB = 1 is PBE
+  Dual f1 = t2 * (1.0 + BB * At2);
+  Dual H = gamma * dlog1p(B * f1 / (1.0 + Aa * f1));
   return ec + H;
 }
 
@@ -195,7 +209,7 @@ __host__ __device__ inline void eval_add(int id, double rho, double sigma, bool 
     if (id == 406) id = 130;
   }
   switch (id) {
-    case 1: e = eps_lda_x(r); break;
+    case 1: e = c_xcpar.x_alpha * eps_lda_x(r); break;
     case 7: e = eps_lda_c_vwn(r); break;
     case 12: e = eps_lda_c_pw(r); break;
     case 13: e = eps_pw92(dcbrt(3.0 / (4.0 * HFG_PI) / r), true); break;  // lda_c_pw_mod
@@ -398,10 +412,12 @@ __host__ __device__ inline T pol_eps_pw(T rs, T z, bool mod) {
   return e0 - mac * f * (1.0 - z4) / fz20 + (e1 - e0) * f * z4;
 }
 template <class T>
-__host__ __device__ inline T pol_eps_pbe_c(T n, T rs, T z, T sig) {
-  const double beta = 0.06672455060314922;
-  const double gamma = (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI);
+__host__ __device__ inline T pol_eps_pbe_c(T n, T rs, T z, T sig, bool ext = false) {
+  // ext: the stand-alone gga_c_pbe takes the external parameters; TPSS's inner PBE keeps the published constants
+  const double beta = ext ? c_xcpar.c_beta : 0.06672455060314922;
+  const double gamma = ext ? c_xcpar.c_gamma : (1.0 - 0.6931471805599453) / (HFG_PI * HFG_PI);
   const double B = beta / gamma;
+  const double BB = ext ? c_xcpar.c_BB : 1.0;
   T ec = pol_eps_pw(rs, z, true);
   T phi = 0.5 * (tpow23(1.0 + z) + tpow23(1.0 - z));
   T phi3 = phi * phi * phi;
@@ -410,7 +426,8 @@ __host__ __device__ inline T pol_eps_pbe_c(T n, T rs, T z, T sig) {
   T t2 = sig / (4.0 * phi * phi * ks2 * n * n);
   T Aa = B / texpm1(-ec / (gamma * phi3));
   T At2 = Aa * t2;
-  return ec + gamma * phi3 * tlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  T f1 = t2 * (1.0 + BB * At2);
+  return ec + gamma * phi3 * tlog1p(B * f1 / (1.0 + Aa * f1));
 }
 
 /// adds functional id's exc (per particle of ra+rb), vrho[2], vsigma[3] (aa, ab, bb); ra + rb >= threshold assumed,
@@ -442,7 +459,7 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
     Dual sa = mk(4.0 * saa, 0.0, 1.0), sb = mk(4.0 * sbb, 0.0, 1.0);
     Dual ea, eb;
     switch (id) {
-      case 1: ea = eps_lda_x(a); eb = eps_lda_x(b); break;
+      case 1: ea = c_xcpar.x_alpha * eps_lda_x(a); eb = c_xcpar.x_alpha * eps_lda_x(b); break;
       case 546: ea = eps_lda_x_sr(a, 0.3, 2); eb = eps_lda_x_sr(b, 0.3, 2); break;
       case 641: ea = eps_lda_x_sr(a, 0.3, 1); eb = eps_lda_x_sr(b, 0.3, 1); break;
       case -178: ea = eps_cam_lda0_x(a); eb = eps_cam_lda0_x(b); break;
@@ -467,7 +484,7 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
     case 7: e = pol_eps_vwn(rs, z); break;
     case 12: e = pol_eps_pw(rs, z, false); break;
     case 13: e = pol_eps_pw(rs, z, true); break;
-    case 130: e = pol_eps_pbe_c(n, rs, z, st); break;
+    case 130: e = pol_eps_pbe_c(n, rs, z, st, true); break;
     default: return;
   }
   T3 en = n * e;

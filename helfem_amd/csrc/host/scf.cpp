@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <deque>
 #include <functional>
+#include <string>
 
 namespace helfem {
 namespace scf {
@@ -142,9 +143,9 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   const bool dft = (opt.x_func > 0 || opt.c_func > 0);
   const int nel = pb.nel;
   // occupations (main.cpp:300-340): nela - nelb = M - 1
-  const int M = opt.multiplicity;
-  if (M < 1 || (nel + M - 1) % 2 != 0 || M - 1 > nel) throw std::logic_error("Requested multiplicity not achievable.\n");
-  const size_t nela = (nel + M - 1) / 2, nelb = nel - nela;
+  int na = opt.nela, nb = opt.nelb, Qv = opt.Q, Mv = opt.multiplicity;
+  parse_nela_nelb(na, nb, Qv, Mv, nel + opt.Q);  // nel = Ztot - Q
+  const size_t nela = (size_t)na, nelb = (size_t)nb;
   const bool restr_req = (opt.restricted == -1) ? (nela == nelb) : (opt.restricted != 0);
   const bool rohf = restr_req && nela != nelb;  // restricted open shell: unrestricted machinery + CUHF constraint
   const bool restr = restr_req && !rohf;
@@ -193,6 +194,9 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   FockHistory diis(opt, restr);
   double Eold = 0.0;
   Mat P, Fa, Fb;
+  struct {
+    Mat Pa, Pb, J, Ka, Kb, XCa, XCb;
+  } last;  // of the last iteration, for the checkpoint
   const size_t Nb = S.n_rows;
   for (int it = 1; it <= opt.maxit; it++) {
     if (verbose) printf("\n**** Iteration %i ****\n\n", it);
@@ -262,6 +266,15 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
       if (rohf) rohf_update(be, Fa, Fb, P, Sh, Sinvh, nela, nelb);  // main.cpp:903-904
     }
 
+    if (opt.keep_matrices) {
+      last.Pa = Pa;
+      last.Pb = Pb;
+      last.J = J;
+      last.Ka = Ka;
+      last.Kb = restr ? Ka : Kb;
+      last.XCa = XCa;
+      last.XCb = restr ? XCa : XCb;
+    }
     res.Etot = res.Ekin + res.Epot + res.Ecoul + res.Exx + res.Exc + res.Enucr;
     double dE = res.Etot - Eold;
     if (verbose) {
@@ -305,6 +318,34 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
 
     bool convd = (diiserr < opt.convthr) && (fabs(dE) < opt.convthr);
 
+    // Fock damping of the atomic program (atomic/main.cpp:917-936): in the basis of the current orbitals the
+    // occupied-virtual blocks are scaled by dampfock while the DIIS error is at least dampthr
+    if (opt.dampfock != 1.0 && diiserr >= opt.dampthr) {
+      if (verbose) printf("Damping off-diagonal elements of Fock matrix by % .3f\n", opt.dampfock);
+      auto damp = [&](const Mat &F, const Mat &C, size_t nocc) {
+        if (!nocc || F.n_rows <= nocc) return F;
+        Mat fmo = be.gemm(be.gemm(C, true, F, false), false, C, false);
+        for (size_t j = nocc; j < fmo.n_cols; j++)
+          for (size_t i = 0; i < nocc; i++) {
+            fmo(i, j) *= opt.dampfock;
+            fmo(j, i) *= opt.dampfock;
+          }
+        Mat SC = be.gemm(S, false, C, false);
+        return be.gemm(be.gemm(SC, false, fmo, false), false, SC, true);
+      };
+      if (restr)
+        Fd = damp(Fd, Ca, nela);
+      else {
+        Mat Fda(Nb, Nb), Fdb(Nb, Nb);
+        std::copy(Fd.d.begin(), Fd.d.begin() + Nb * Nb, Fda.d.begin());
+        std::copy(Fd.d.begin() + Nb * Nb, Fd.d.end(), Fdb.d.begin());
+        Fda = damp(Fda, Ca, nela);
+        Fdb = damp(Fdb, Cb, nelb);
+        std::copy(Fda.d.begin(), Fda.d.end(), Fd.d.begin());
+        std::copy(Fdb.d.begin(), Fdb.d.end(), Fd.d.begin() + Nb * Nb);
+      }
+    }
+
     t0 = wall();
     if (restr) {
       be.eig_gsym_sub(Ea, Ca, Fd, Sinvh, dsym);
@@ -333,9 +374,29 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   res.C = Ca;
   res.P = P;
   res.F = Fa;
-  res.Eb = Eb;
-  res.Cb = Cb;
-  res.Fb = Fb;
+  res.Eb = restr ? Ea : Eb;
+  res.Cb = restr ? Ca : Cb;
+  res.Fb = restr ? Fa : Fb;
+  if (opt.keep_matrices) {
+    std::map<std::string, Mat> &m = res.mats;
+    m["S"] = S;
+    m["T"] = T;
+    m["Vnuc"] = Vnuc;
+    m["H0"] = H0;
+    m["Sinvh"] = Sinvh;
+    m["P"] = P;
+    m["Pa"] = last.Pa;
+    m["Pb"] = last.Pb;
+    m["J"] = last.J;
+    m["Ka"] = last.Ka;
+    m["Kb"] = last.Kb;
+    m["XCa"] = last.XCa;
+    m["XCb"] = last.XCb;
+    m["Fa"] = res.F;
+    m["Fb"] = res.Fb;
+    m["Ca"] = res.C;
+    m["Cb"] = res.Cb;
+  }
   if (verbose) {
     printf("%-21s energy: % .16f\n", "Kinetic", res.Ekin);
     printf("%-21s energy: % .16f\n", "Nuclear attraction", res.Epot);
@@ -349,6 +410,25 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   return res;
 }
 }  // namespace
+
+void parse_nela_nelb(int &nela, int &nelb, int &Q, int &M, int Ztot) {
+  if (nela == 0 && nelb == 0) {
+    const int nel = Ztot - Q;
+    if (M < 1) throw std::runtime_error("Invalid value for multiplicity, which must be >=1.\n");
+    if ((nel % 2 == 0 && M % 2 != 1) || (nel % 2 == 1 && M % 2 != 0))
+      throw std::runtime_error("Requested multiplicity " + std::to_string(M) + " with " + std::to_string(nel) + " electrons.\n");
+    nela = (nel % 2 == 0) ? nel / 2 + (M - 1) / 2 : nel / 2 + M / 2;
+    nelb = nel - nela;
+    if (nela < 0) throw std::runtime_error("A multiplicity of " + std::to_string(M) + " would mean " + std::to_string(nela) + " alpha electrons!\n");
+    if (nelb < 0) throw std::runtime_error("A multiplicity of " + std::to_string(M) + " would mean " + std::to_string(nelb) + " beta electrons!\n");
+  } else {
+    Q = Ztot - nela - nelb;
+    M = 1 + nela - nelb;
+    if (M < 1)
+      throw std::runtime_error("nela=" + std::to_string(nela) + ", nelb=" + std::to_string(nelb) + " would mean multiplicity " +
+                               std::to_string(M) + " which is not allowed!\n");
+  }
+}
 
 static ModelPotential guess_potential(int iguess, int Z, double gsz_d) {
   ModelPotential p;
@@ -369,7 +449,7 @@ Result run_diatomic(const Options &opt, Backend &be) {
   Result res;
   const bool verbose = opt.verbose;
   Problem pb;
-  int nel = opt.Z1 + opt.Z2;
+  int nel = opt.Z1 + opt.Z2 - opt.Q;
 
   int Nquad = opt.nquad;
   if (Nquad == 0) Nquad = 5 * opt.nnodes;

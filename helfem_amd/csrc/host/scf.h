@@ -9,6 +9,7 @@
 #pragma once
 #include "atomic_basis.h"
 #include "diatomic_basis.h"
+#include <map>
 #include <string>
 
 namespace helfem {
@@ -64,6 +65,8 @@ struct Options {
   int ldft = 0, mdft = 0;
   double dftthr = 1e-12;
   int symmetry = 1;
+  int Q = 0;              // --Q: charge state (number of electrons = Z1 + Z2 - Q, atomic: Z - Q)
+  int nela = 0, nelb = 0; // --nela / --nelb: explicit occupations; both zero: from Q and M (scf::parse_nela_nelb)
   int multiplicity = 1;   // --M: spin multiplicity 2S+1; nela - nelb = M - 1
   int restricted = -1;    // --restricted: -1 auto (restricted iff M == 1), 0 unrestricted, 1 restricted; with M > 1 that
                           // is the constrained-UHF form of ROHF (scf::ROHF_update, scf_helpers.cpp:470)
@@ -71,8 +74,12 @@ struct Options {
   double diiseps = 1e-2;  // --diiseps: DIIS error below which CDIIS starts to be mixed in
   double diisthr = 1e-3;  // --diisthr: DIIS error below which the extrapolation is pure CDIIS
   int diisorder = 5;
+  // atomic program: the occupied-virtual blocks of the extrapolated Fock matrix in the basis of the current orbitals are
+  // scaled by dampfock while the DIIS error is at least dampthr (atomic/main.cpp:917-936); 1.0 = none (the diatomic program)
+  double dampfock = 1.0, dampthr = 0.1;
   int iguess = 0;  // --iguess: 0 core Hamiltonian, 1 GSZ (needs gsz_d), 3 Thomas-Fermi; 2 (SAP) is not available
   double gsz_d1 = 0.0, gsz_d2 = 0.0;  // screening lengths of the GSZ guess for the two centres (atomic: gsz_d1)
+  bool keep_matrices = false;  // fill Result::mats with what the reference's drivers write to their checkpoint
   bool verbose = true;
 };
 
@@ -87,6 +94,9 @@ struct Result {
   Mat Cb, Fb;
   int nela = 0, nelb = 0;
   size_t Nbf = 0;
+  // keep_matrices: S, T, Vnuc, H0, Sinvh, P, Pa, Pb, J, Ka, Kb, XCa, XCb, Fa, Fb, Ca, Cb of the last iteration
+  // (diatomic/main.cpp:406-537, 790-963)
+  std::map<std::string, Mat> mats;
 };
 
 /// options of the atomic program on top of the common ones (Z1/Z2/Rbond/lmmax/lpad of `common` are unused)
@@ -96,6 +106,11 @@ struct AtomicOptions {
   int lmax = 0, mmax = 0;
   bool maverage = false;  // --maverage: average the Fock matrices over m for every l (scf::fock_symmetry_average)
 };
+
+/// scf::parse_nela_nelb (src/general/scf_helpers.cpp:558-603): occupations from the charge state and the multiplicity, or
+/// charge and multiplicity from explicit occupations; Ztot = total nuclear charge.  Throws std::runtime_error like the
+/// reference.
+void parse_nela_nelb(int &nela, int &nelb, int &Q, int &M, int Ztot);
 
 std::vector<std::vector<std::vector<size_t> > > atomic_average_groups(const atomic::TwoDBasis &basis);
 Result run_diatomic(const Options &opt, Backend &be);

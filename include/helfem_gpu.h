@@ -14,9 +14,10 @@
  *   - "host" entry points take host pointers and copy through pinned staging; "_dev" entry points
  *     take pointers to HBM (e.g. torch tensors' data_ptr()) and enqueue on the context's stream
  *     without synchronising;
- *   - return value: 0 = success, non-zero = error, text via hfg_last_error() (thread-local).  The
- *     reference throws std::logic_error / std::runtime_error in the same situations
- *     (e.g. "Primitive teis have not been computed!" basis.cpp:1361);
+ *   - return value: 0 = success, non-zero = error, text via hfg_last_error() (thread-local).  The code is the class of
+ *     the exception the reference throws in the same situation: 1 = std::logic_error (e.g. "Primitive teis have not
+ *     been computed!" basis.cpp:1361), 2 = std::runtime_error (functional, shape and device errors, dftgrid.cpp:54),
+ *     3 = any other; include/helfem_gpu_arma.hpp turns them back into those exceptions;
  *   - a context is bound to one device + one stream; one context per host thread.
  *   - there is NO CPU fallback: every compute entry point fails with an error when no gfx950
  *     device is usable.
@@ -173,6 +174,16 @@ int hfg_xc_fock(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
  * dftgrid.cpp:812 (unrestricted; both spin matrices are always formed, i.e. beta = true) */
 int hfg_xc_fock_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *Pa, const double *Pb,
                     double *Ha, double *Hb, double *Exc, double *Nel, double *Ekin, double dens_thr);
+/* The same with the reference's full argument list (dftgrid.h:179/181): x_pars / c_pars are the external functional
+ * parameters of --x_pars / --c_pars (xc_func_set_ext_params in the reference, dftgrid.cpp:405-410).  Supported: gga_x_pbe
+ * (kappa, mu), gga_c_pbe (beta, gamma, B), lda_x (alpha); NULL / 0 keeps the functional's defaults; any other
+ * combination is refused with an error rather than ignored. */
+int hfg_xc_fock_ext(hfg_ctx *ctx, hfg_basis *basis, int x_func, const double *x_pars, int n_x_pars, int c_func,
+                    const double *c_pars, int n_c_pars, const double *P, double *H, double *Exc, double *Nel, double *Ekin,
+                    double dens_thr);
+int hfg_xc_fock_pol_ext(hfg_ctx *ctx, hfg_basis *basis, int x_func, const double *x_pars, int n_x_pars, int c_func,
+                        const double *c_pars, int n_c_pars, const double *Pa, const double *Pb, double *Ha, double *Hb,
+                        double *Exc, double *Nel, double *Ekin, double dens_thr);
 /* Initial-guess model potential: arma::mat TwoDGrid::model_potential(p1, p2) (src/diatomic/twodquadrature.cpp:351) on the
  * quadrature grid of hfg_basis_upload(ldft, mdft), or atomic::basis::TwoDBasis::model_potential(pot)
  * (src/atomic/TwoDBasis.cpp:458; the second centre is ignored).  kind: 0 point nucleus, 1 Green-Sellin-Zachor with the
@@ -243,6 +254,96 @@ int hfg_gemm_dev(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int
 int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmmax, int nlm, int nelem, int nnodes,
                      int nquad, double Rmax, int igrid, double zexp, int lpad, const char *method, int ldft, int mdft,
                      int symmetry, int multiplicity, int maxit, double convthr, int verbose, double *out /* 12 */);
+
+/* ---- complete runs: what `diatomic` (src/diatomic/main.cpp) and `atomic` (src/atomic/main.cpp) do between parsing their
+ * command line and printing the energy table.  Field names are the reference's flag names (main.cpp:89-133 /
+ * atomic/main.cpp:63-119); hfg_scf_options_default() fills in the reference's defaults.  Flags of features outside the
+ * hot-path scope (external fields, finite nuclei, confinement, forced occupations, non-LIP primitive bases) are carried so
+ * that the drivers can reject non-default values with the reference's wording instead of ignoring them. -------------- */
+#define HFG_MAX_LMMAX 16
+typedef struct hfg_scf_options {
+  int program;               /* 0: diatomic, 1: atomic */
+  int Z1, Z2;                /* diatomic: --Z1 --Z2; atomic: --Z in Z1 (Z2 unused) */
+  double Rbond;              /* --Rbond in bohr (the drivers convert --angstrom input) */
+  int nela, nelb, Q, M;      /* --nela --nelb --Q --M (scf::parse_nela_nelb); M = 0 means "not given": 1 */
+  int lmmax[HFG_MAX_LMMAX];  /* diatomic: l_max for |m| = 0 .. nlm-1 (--lmax list, or --lmax with --mmax) */
+  int nlm;
+  int lmax, mmax;            /* atomic: --lmax --mmax */
+  int lpad;                  /* --lpad = 10 */
+  double Rmax;               /* --Rmax = 40 */
+  int grid;                  /* --grid = 4 */
+  double zexp;               /* --zexp = 1 (diatomic), 2 (atomic) */
+  int nelem, nnodes, nquad;  /* --nelem, --nnodes = 15, --nquad = 0 (5 per primitive) */
+  int maxit;                 /* --maxit = 50 */
+  double convthr;            /* --convthr = 1e-7 */
+  int diag;                  /* --diag = 1: S^-1/2 by diagonalisation, 0: Cholesky */
+  char method[128];          /* --method = HF */
+  int ldft, mdft;            /* --ldft --mdft = 0 (automatic) */
+  double dftthr;             /* --dftthr = 1e-12 */
+  int restricted;            /* --restricted = -1 (restricted iff nela == nelb) */
+  int symmetry;              /* --symmetry = 1 */
+  int primbas;               /* --primbas = 4 (LIP); anything else is rejected */
+  double diiseps, diisthr;   /* --diiseps = 1e-2, --diisthr = 1e-3 */
+  int diisorder;             /* --diisorder = 5 */
+  int iguess;                /* --iguess = 2 in the reference (SAP, a data table that is out of scope): 0 core, 3 Thomas-Fermi */
+  const double *x_pars;      /* --x_pars / --c_pars: external functional parameters (scf::parse_xc_params), or NULL */
+  int n_x_pars;
+  const double *c_pars;
+  int n_c_pars;
+  int maverage;              /* --maverage = false */
+  double dampfock, dampthr;  /* atomic: --dampfock = 0.7, --dampthr = 0.1 (damping of the occupied-virtual Fock blocks,
+                                atomic/main.cpp:917-936); 1.0 switches it off */
+  char save[512];            /* --save = helfem.chk ("" to skip); HDF5, src/general/checkpoint.cpp */
+  char load[512];            /* --load = "" */
+  /* out of scope, must keep their defaults: */
+  double Ez, Qzz, Bz;        /* external fields */
+  int finitenuc;             /* finite nuclear model */
+  int readocc;               /* forced occupations */
+  double perturb;            /* random perturbation of the guess */
+  int iconf;                 /* atomic: confinement potential */
+  int zeroder;               /* atomic: zero derivative at Rmax */
+  int verbose;               /* print the reference's per-iteration lines to stdout */
+} hfg_scf_options;
+
+typedef struct hfg_scf_result {
+  double Etot, Ekin, Epot, Enucr, Ecoul, Exx, Exc;
+  int iterations, converged;
+  int nela, nelb;
+  int64_t Nbf;
+  double tJ, tK, tXC, tdiag; /* seconds of the last iteration's steps (the reference's Timer prints) */
+} hfg_scf_result;
+
+int hfg_scf_options_default(hfg_scf_options *opt, int program);
+/* the validation hfg_scf_run performs before it touches the device (no GPU needed): 0 = acceptable */
+int hfg_scf_options_check(const hfg_scf_options *opt);
+/* runs the calculation on ctx's device; E / C (alpha orbital energies Nbf, orbitals Nbf x Nbf) may be NULL */
+int hfg_scf_run(hfg_ctx *ctx, const hfg_scf_options *opt, hfg_scf_result *res, double *E, double *C);
+/* scf::parse_xc_params (src/general/scf_helpers.cpp): one number per line of a text file; n in: capacity, out: count */
+int hfg_parse_xc_params(const char *path, double *pars, int *n);
+/* element symbol or number -> nuclear charge (get_Z of src/general/elements.h as the drivers use it); < 0: unknown */
+int hfg_get_Z(const char *symbol_or_number);
+
+/* ---- checkpoint files in the reference's HDF5 layout (src/general/checkpoint.cpp: matrices as 2-D datasets with swapped
+ * dimensions :117-144, integer vectors :220-257, scalars :627/:701, the basis as its constructor arguments :477-507,
+ * :560-584).  libhdf5 is loaded at run time ($HELFEM_HDF5_LIB, libhdf5.so, ...); every call fails with an error text
+ * when none can be loaded.  hfg_scf_run writes one when hfg_scf_options::save is set. -------------------------------- */
+typedef struct hfg_chk hfg_chk;
+int hfg_chk_available(void);                                    /* 1 when a libhdf5 could be loaded */
+int hfg_chk_open(const char *path, int write, hfg_chk **chk);   /* write != 0 truncates / creates */
+int hfg_chk_close(hfg_chk *chk);
+int hfg_chk_exist(hfg_chk *chk, const char *name);              /* 1 / 0 */
+int hfg_chk_write_mat(hfg_chk *chk, const char *name, const double *m, int64_t rows, int64_t cols); /* arma::mat / arma::vec */
+int hfg_chk_write_ivec(hfg_chk *chk, const char *name, const int *v, int64_t n);                    /* arma::ivec */
+int hfg_chk_write_double(hfg_chk *chk, const char *name, double v);
+int hfg_chk_write_int(hfg_chk *chk, const char *name, int v);
+int hfg_chk_write_basis(hfg_chk *chk, const hfg_basis *basis);  /* Checkpoint::write(basis) */
+/* m == NULL queries the shape */
+int hfg_chk_read_mat(hfg_chk *chk, const char *name, double *m, int64_t *rows, int64_t *cols);
+int hfg_chk_read_ivec(hfg_chk *chk, const char *name, int *v, int64_t *n);
+int hfg_chk_read_double(hfg_chk *chk, const char *name, double *v);
+int hfg_chk_read_int(hfg_chk *chk, const char *name, int *v);
+/* Checkpoint::read(diatomic::basis::TwoDBasis &): a basis object from the stored constructor arguments */
+int hfg_chk_read_diatomic_basis(hfg_chk *chk, int lpad, hfg_basis **basis);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every kernel family is bracketed by hipEvents on the context's stream; the

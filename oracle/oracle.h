@@ -94,5 +94,7 @@ void xc_polarized(int func_id, size_t N, const double *rho, const double *sigma,
                   double *vsigma, double dens_threshold);
 /// "lda_x-lda_c_vwn", "gga_x_pbe-gga_c_pbe", "HF", "none", or numeric ids  (dftfuncs.cpp:64-118)
 void parse_xc_func(int &x_func, int &c_func, const std::string &method);
+/// external functional parameters (xc_func_set_ext_params, dftgrid.cpp:405-410) for all following evaluations; nx = nc = 0 resets
+void set_xc_params(const double *x_pars, int nx, int x_func, const double *c_pars, int nc, int c_func);
 
 }  // namespace oracle

@@ -317,6 +317,11 @@ int orc_scf_set_iguess(int iguess) {
   g_orc_iguess = iguess;
   return 0;
 }
+int orc_set_xc_params(int x_func, const double *x_pars, int nx, int c_func, const double *c_pars, int nc) {
+  ORC_TRY
+  oracle::set_xc_params(x_pars, nx, x_func, c_pars, nc, c_func);
+  ORC_CATCH
+}
 /// --diiseps / --diisthr for the following orc_scf_* calls of this thread
 int orc_scf_set_diis(double diiseps, double diisthr) {
   g_orc_diiseps = diiseps;
@@ -409,6 +414,8 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
   ORC_TRY
   oracle::ScfIn o;
   o.maverage = maverage != 0;
+  o.dampfock = 0.7;  // defaults of the atomic program (atomic/main.cpp:111-112)
+  o.dampthr = 0.1;
   o.multiplicity = multiplicity < 0 ? -multiplicity : multiplicity;  // negative: restricted open shell (ROHF)
   if (multiplicity < 0) o.restricted = 1;
   o.Z1 = Z;

@@ -475,6 +475,23 @@ ScfOut iterate(const ScfIn &in, const Mat &S, const Mat &T, const Mat &Vnuc, con
     diis.solve_F(Fda, Fdb);
     const bool convd = diiserr < in.convthr && std::fabs(dE) < in.convthr;
 
+    if (in.dampfock != 1.0 && diiserr >= in.dampthr) {  // atomic/main.cpp:917-936
+      auto damped = [&](const Mat &F, const Mat &C, int nocc) {
+        if (!nocc || (int)F.n_rows <= nocc) return F;
+        Mat fmo = mm(mtm(C, F), C);
+        const size_t no = (size_t)nocc, nt = fmo.n_rows;
+        for (size_t o = 0; o < no; o++)
+          for (size_t v = no; v < nt; v++) {
+            fmo(o, v) *= in.dampfock;
+            fmo(v, o) *= in.dampfock;
+          }
+        Mat SC = mm(S, C);
+        return mm(mm(SC, fmo), SC.t());
+      };
+      Fda = damped(Fda, Ca, nela);
+      Fdb = damped(Fdb, Cb, nelb);
+    }
+
     eig_gsym_sub(Ea, Ca, Fda, Sinvh, dsym);
     if (closed) {
       Eb = Ea;

@@ -32,6 +32,7 @@ struct ScfIn {
   int iguess = 0;
   double gsz_d1 = 0.0, gsz_d2 = 0.0;
   bool maverage = false;
+  double dampfock = 1.0, dampthr = 0.1;  // atomic program: 0.7 / 0.1 by default (atomic/main.cpp:111-112)
   bool verbose = false;
 };
 

@@ -20,6 +20,13 @@ namespace {
 const double PI = 3.14159265358979323846;
 
 // ---- Slater exchange: exc = -3/4 (3/pi)^{1/3} rho^{1/3} ----
+// external functional parameters (libxc's ext_params of lda_x, gga_x_pbe, gga_c_pbe; orc_set_xc_params)
+struct XCParams {
+  double x_alpha = 1.0, x_kappa = 0.8040, x_mu = 0.06672455060314922 * PI * PI / 3.0;
+  double c_beta = 0.06672455060314922, c_gamma = (1.0 - 0.6931471805599453094) / (PI * PI), c_BB = 1.0;
+};
+XCParams g_xcp;
+
 void lda_x(double rho, double &exc, double &vrho) {
   double cx = -0.75 * cbrt(3.0 / PI);
   exc = cx * cbrt(rho);
@@ -133,8 +140,8 @@ void lda_c_pw_mod(double rho, double &exc, double &vrho) {
 
 // ---- PBE exchange ----
 void gga_x_pbe(double rho, double sigma, double &exc, double &vrho, double &vsigma) {
-  const double kappa = 0.8040;
-  const double mu = 0.06672455060314922 * PI * PI / 3.0;
+  const double kappa = g_xcp.x_kappa;
+  const double mu = g_xcp.x_mu;
   double exu = -0.75 * cbrt(3.0 / PI) * cbrt(rho);
   double kf2 = pow(3.0 * PI * PI * rho, 2.0 / 3.0);
   double s2 = sigma / (4.0 * kf2 * rho * rho);
@@ -148,9 +155,9 @@ void gga_x_pbe(double rho, double sigma, double &exc, double &vrho, double &vsig
 
 // ---- PBE correlation ----
 void gga_c_pbe(double rho, double sigma, double &exc, double &vrho, double &vsigma) {
-  const double beta = 0.06672455060314922;
-  const double gamma = (1.0 - log(2.0)) / (PI * PI);
-  const double B = beta / gamma;
+  const double beta = g_xcp.c_beta;
+  const double gamma = g_xcp.c_gamma;
+  const double B = beta / gamma, BB = g_xcp.c_BB;  // libxc: f1 = t^2 + BB A t^4, H = gamma log(1 + B f1/(1 + A f1))
   double rs = cbrt(3.0 / (4.0 * PI * rho));
   double ec, dec;
   pw92(rs, true, ec, dec);
@@ -159,12 +166,12 @@ void gga_c_pbe(double rho, double sigma, double &exc, double &vrho, double &vsig
   double u = sigma / (4.0 * ks2 * rho * rho);  // t^2
   double E = exp(-ec / gamma);
   double A = B / expm1(-ec / gamma);
-  double N = B * u * (1.0 + A * u);
-  double D = 1.0 + A * u + A * A * u * u;
+  double N = B * u * (1.0 + BB * A * u);
+  double D = 1.0 + A * u + BB * A * A * u * u;
   double arg = 1.0 + N / D;
   double H = gamma * log1p(N / D);
-  double dN_du = B * (1.0 + 2.0 * A * u), dD_du = A + 2.0 * A * A * u;
-  double dN_dA = B * u * u, dD_dA = u + 2.0 * A * u * u;
+  double dN_du = B * (1.0 + 2.0 * BB * A * u), dD_du = A + 2.0 * BB * A * A * u;
+  double dN_dA = B * BB * u * u, dD_dA = u + 2.0 * BB * A * u * u;
   double dH_du = gamma * (dN_du * D - N * dD_du) / (D * D * arg);
   double dH_dA = gamma * (dN_dA * D - N * dD_dA) / (D * D * arg);
   double dA_dec = A * A * E / (B * gamma);
@@ -197,7 +204,11 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
       if (id == 406) idl = 130;
     }
     switch (idl) {
-      case 1: lda_x(r, e, v); break;
+      case 1:
+        lda_x(r, e, v);
+        e *= g_xcp.x_alpha;
+        v *= g_xcp.x_alpha;
+        break;
       case 7: lda_c_vwn(r, e, v); break;
       case 12: lda_c_pw(r, e, v); break;
       case 13: lda_c_pw_mod(r, e, v); break;
@@ -350,7 +361,7 @@ D3 eps_pw(D3 rs, D3 z, bool mod) {
 
 // PBE correlation (libxc gga_c_pbe): e_pw_mod(rs,z) + gamma phi^3 ln(1 + beta/gamma t^2 (1+A t^2)/(1+A t^2+A^2 t^4))
 D3 eps_pbe_c(D3 rho, D3 rs, D3 z, D3 sig) {
-  const double beta = 0.06672455060314922, gamma = (1.0 - log(2.0)) / (PI * PI), B = beta / gamma;
+  const double beta = g_xcp.c_beta, gamma = g_xcp.c_gamma, B = beta / gamma, BB = g_xcp.c_BB;
   D3 ec = eps_pw(rs, z, true);
   D3 phi = 0.5 * (Dpow23(1.0 + z) + Dpow23(1.0 - z));
   D3 phi3 = phi * phi * phi;
@@ -359,7 +370,7 @@ D3 eps_pbe_c(D3 rho, D3 rs, D3 z, D3 sig) {
   D3 t2 = sig / (4.0 * phi * phi * ks2 * rho * rho);
   D3 A = B / Dexpm1(-ec / (gamma * phi3));
   D3 At2 = A * t2;
-  return ec + gamma * phi3 * Dlog1p(B * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2));
+  return ec + gamma * phi3 * Dlog1p(B * t2 * (1.0 + BB * At2) / (1.0 + At2 + BB * At2 * At2));
 }
 }  // namespace
 
@@ -410,6 +421,10 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
         if (id == 1) {
           lda_x(2.0 * ra, ea, va);
           lda_x(2.0 * rb, eb, vb);
+          ea *= g_xcp.x_alpha;
+          va *= g_xcp.x_alpha;
+          eb *= g_xcp.x_alpha;
+          vb *= g_xcp.x_alpha;
         } else if (id == 546 || id == 641) {
           lda_x_sr(2.0 * ra, 0.3, id == 546 ? 2 : 1, ea, va);
           lda_x_sr(2.0 * rb, 0.3, id == 546 ? 2 : 1, eb, vb);
@@ -638,6 +653,26 @@ static int find_func(const std::string &name) {
   std::ostringstream oss;
   oss << "\nError: functional " << name << " is not available in this build!\n";
   throw std::runtime_error(oss.str());
+}
+
+void set_xc_params(const double *x_pars, int nx, int x_func, const double *c_pars, int nc, int c_func) {
+  g_xcp = XCParams();
+  if (nx > 0) {
+    if (x_func == 1 && nx == 1) g_xcp.x_alpha = x_pars[0];
+    else if (x_func == 101 && nx == 2) {
+      g_xcp.x_kappa = x_pars[0];
+      g_xcp.x_mu = x_pars[1];
+    } else
+      throw std::runtime_error("oracle: external parameters not supported for this exchange functional\n");
+  }
+  if (nc > 0) {
+    if (c_func == 130 && nc == 3) {
+      g_xcp.c_beta = c_pars[0];
+      g_xcp.c_gamma = c_pars[1];
+      g_xcp.c_BB = c_pars[2];
+    } else
+      throw std::runtime_error("oracle: external parameters not supported for this correlation functional\n");
+  }
 }
 
 void parse_xc_func(int &x_func, int &c_func, const std::string &xc) {

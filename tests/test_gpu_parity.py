@@ -131,16 +131,30 @@ def test_exchange_indefinite_and_full_rank_inputs(case):
 
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_exchange_shards_sum_to_full(case, hf, nranks):
+    """the shards of hfg_exchange_dev (device-pointer entry point: partial results) sum to the full matrix, and the
+    host-pointer entry point returns the FULL matrix whatever shard the context carries"""
     import common
+    import ctypes
+    import torch
     name, gb, ob, _, _ = case
     tag, P = list(_densities(gb))[1]
     ctx = gb.ctx
     full = gb.exchange(P)
+    N = gb.Nbf()
+    dP = torch.from_numpy(np.ascontiguousarray(P.T)).cuda()  # symmetric: layout does not matter
+    dK = torch.zeros((N, N), dtype=torch.float64, device="cuda")
     acc = np.zeros_like(full)
     try:
         for rk in range(nranks):
             ctx.set_shard(rk, nranks)
-            acc += gb.exchange(P)
+            rc = hf.lib().hfg_exchange_dev(ctx.h, gb.h, ctypes.c_void_p(dP.data_ptr()), ctypes.c_void_p(dK.data_ptr()))
+            assert rc == 0
+            torch.cuda.synchronize()
+            part = dK.cpu().numpy().T
+            assert common.relerr(part, full) > 1e-3  # a shard is not the whole
+            acc += part
+            assert common.relerr(gb.exchange(P), full) < 1e-13  # host-pointer call: complete, shard restored afterwards
+            assert common.relerr(gb.coulomb(P), ob.coulomb(P)) < 1e-11
     finally:
         ctx.set_shard(0, 1)
     assert common.relerr(acc, full) < 1e-12, name
