@@ -165,10 +165,11 @@ def main():
     E0, C0 = hf.scf.eig_gsym_sub(H0, Sinvh, blocks, ctx=ctx)
     P0 = 2.0 * hf.scf.form_density(C0, w["nocc"], ctx=ctx)
     allred = parallel.allreduce_sum_ if (world > 1 or parallel.forced()) else None
+    xblocks = parallel.broadcast_block_slots_ if (world > 1 or parallel.forced()) else None
 
     def one_step():
         step.set_density_scaled = None
-        step.step(allred)
+        step.step(allred, xblocks)
         step.P.mul_(2.0)  # closed shell: P = Pa + Pb
 
     step.set_density(P0)

@@ -673,15 +673,20 @@ class DeviceSCFStep(object):
         _check(lib().hfg_form_density_dev(self.ctx.h, ctypes.c_int64(self.N), ctypes.c_int64(self.N), self._ptr(self.C),
                                           ctypes.c_int64(self.nocc), self._ptr(self.P)))
 
-    def step(self, allreduce=None):
-        """one iteration; allreduce(tensor) sums a tensor over ranks in place (None: single GPU)"""
+    def step(self, allreduce=None, exchange_blocks=None):
+        """one iteration; allreduce(tensor) sums a tensor over ranks in place (None: single GPU);
+        exchange_blocks(buffer, nblk) completes the per-block eigenvector slots on every rank (parallel.
+        broadcast_block_slots_: one broadcast per block from its owner; None: the sum all-reduce, which the zero
+        padding of the slots owned elsewhere also makes correct)"""
         self.fock_partial()
         if allreduce is not None:
             allreduce(self.Fc)
             allreduce(self.scal)
         self.fock_finish()
         self.eig_partial()
-        if allreduce is not None:
+        if exchange_blocks is not None:
+            exchange_blocks(self.blockbuf, len(self.blocks))
+        elif allreduce is not None:
             allreduce(self.blockbuf)
         self.eig_finish()
         self.density()

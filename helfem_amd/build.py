@@ -18,7 +18,7 @@ OBJDIR = os.path.join(ROOT, "helfem_amd", "build")
 
 HOST_SRCS = ["host/fem.cpp", "host/special.cpp", "host/atomic_basis.cpp", "host/diatomic_basis.cpp", "host/scf.cpp", "host/diis.cpp", "host/checkpoint.cpp", "host/dftfuncs.cpp"]
 HIP_SRCS = ["hip/tables.cpp", "hip/capi.cpp", "hip/fock.hip", "hip/exchange.hip", "hip/exchange_lr.hip", "hip/gemm.hip", "hip/eig.hip", "hip/dc.hip", "hip/trd.hip",
-            "hip/misc.hip", "hip/scf_gpu.cpp", "hip/scf_device.hip", "hip/tei_dev.hip"]
+            "hip/misc.hip", "hip/scf_gpu.cpp", "hip/scf_device.hip", "hip/tei_dev.hip", "hip/sb.hip"]
 
 
 # Kernel arguments preloaded into SGPRs at wave launch (gfx940+): every launch of the eigensolver's dependent chains

@@ -16,6 +16,11 @@ void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr);
 void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false);
+void sb_reduce_to_band(hfg_ctx *ctx, int nblk, const int *ns, double *const *A);
+void sb_fetch_band(hfg_ctx *ctx, int blk, int n, double *hostAB);
+int sb_bandwidth();
+int sb_ldb();
+bool sb_supported(int nblk, const int *ns);
 void set_xc_params(hfg_ctx *ctx, int x_func, const double *x_pars, int nx, int c_func, const double *c_pars, int nc);
 void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
                      double *dHa, double *dHb, double *dScal, double thr);
@@ -542,6 +547,43 @@ int hfg_chk_read_diatomic_basis(hfg_chk *chk, int lpad, hfg_basis **out) {
     throw;
   }
   *out = b;
+  HFG_CATCH
+}
+
+// Diagnostic access to the first stage of the two-stage tridiagonalisation (hip/sb.hip): nrep copies of the symmetric
+// matrix A (n x n) are reduced to band form in one batch; AB receives the band storage of the first copy
+// (AB[j * ldb + d] = A_band[j + d][j]), ms the device time of the reduction.
+int hfg_debug_band_reduce(hfg_ctx *ctx, int64_t n, const double *A, int nrep, double *AB, int *bandwidth, int *ldb, double *ms) {
+  HFG_TRY
+  if (nrep < 1 || nrep > 8) throw std::logic_error("hfg_debug_band_reduce: 1..8 copies\n");
+  HFG_HIP_CHECK(hipSetDevice(ctx->device));
+  std::vector<int> ns(nrep, (int)n);
+  if (!sb_supported(nrep, ns.data())) throw std::logic_error("hfg_debug_band_reduce: size outside the kernels' range\n");
+  std::vector<DevBuf<double> > dA(nrep);
+  std::vector<double *> ptr(nrep);
+  for (int k = 0; k < nrep; k++) {
+    dA[k].resize((size_t)n * n + 2);
+    HFG_HIP_CHECK(hipMemcpy(dA[k].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
+    ptr[k] = dA[k].p;
+  }
+  sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());  // warm-up (buffers, task lists)
+  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < nrep; k++) HFG_HIP_CHECK(hipMemcpy(dA[k].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HFG_HIP_CHECK(hipEventCreate(&e0));
+  HFG_HIP_CHECK(hipEventCreate(&e1));
+  HFG_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+  sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());
+  HFG_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+  HFG_HIP_CHECK(hipEventSynchronize(e1));
+  float t = 0.f;
+  HFG_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (ms) *ms = t;
+  if (bandwidth) *bandwidth = sb_bandwidth();
+  if (ldb) *ldb = sb_ldb();
+  if (AB) sb_fetch_band(ctx, 0, (int)n, AB);
   HFG_CATCH
 }
 

@@ -1,0 +1,490 @@
+// Two-stage tridiagonalisation of symmetric matrices on gfx950, batched over problems
+// (the LAPACK dsyevd call behind scf::eig_gsym / eig_gsym_sub, /root/reference/src/general/scf_helpers.cpp:131-186):
+//
+//   stage 1  dense -> band of half-width SB = 32: per panel of SB columns a Householder QR of the block below the band
+//            (one workgroup per problem, the panel in registers), then the two-sided compact-WY update of the trailing
+//            matrix as matrix products:  X = A22 V,  Z = V^T X,  Y = X T,  U = Y - V (T^T Z T)^T,
+//            A22 <- A22 - [Y | V] [V | U]^T.   n / SB dependent steps instead of n.
+//   stage 2  band -> tridiagonal by bulge chasing, one column per sweep (Schwarz / Lang); sweep s + 1 follows sweep s
+//            three tasks behind.  One wavefront per sweep, a 32 x 32 block per task in its registers; consecutive sweeps
+//            talk through HBM/L2 with agent-scope release / acquire counters, the three-task lag hides that latency.
+//   back-transformation  Z <- Q1 (Q2 Z):  Q2 (the SB-long reflectors of stage 2) applied sweep by sweep to column slabs
+//            of Z resident in LDS, Q1 through the compact-WY machinery of eig.hip.
+// tools/two_stage_model.py is the NumPy statement of the same algorithm with the same index conventions.
+#include "common.h"
+#include "wave.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace hfg {
+
+void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
+
+constexpr int SB = 32;             // half-bandwidth of the intermediate band matrix
+constexpr int SB_LDB = 2 * SB;     // band storage: AB[j * SB_LDB + d] = A[j + d][j], d < 2 SB (room for the bulge)
+constexpr int SB_MAXB = 8;
+constexpr int SB_TMAX = 92;        // panel rows per thread (16 row groups): problems up to n = 16 * SB_TMAX + SB = 1504
+constexpr int SB_KS = 4;           // split-K slabs of X = A22 V
+constexpr int SB_RT = 64;          // row tile of the W kernels
+
+struct SbBatch {
+  int nblk;
+  int n[SB_MAXB];
+  double *A[SB_MAXB];     // n x n, ld n (full symmetric storage; on exit the band in its lower part)
+  double *Vx[SB_MAXB];    // n x n: explicit stage-1 reflectors, column c acts on rows c + SB .. n-1 (unit entry at row c + SB)
+  double *tau1[SB_MAXB];  // n
+  double *T1[SB_MAXB];    // [panel][SB x SB] compact-WY factors, column-major
+  double *Xs[SB_MAXB];    // [SB_KS][n x SB] split-K slabs of X, ld n
+  double *X[SB_MAXB];     // n x SB, ld n
+  double *Zp[SB_MAXB];    // [row tile][SB x SB] partial products V^T X
+  double *Lm[SB_MAXB];    // n x 2 SB: [Y | V], ld n
+  double *Rm[SB_MAXB];    // n x 2 SB: [V | U], ld n
+  double *AB[SB_MAXB];    // n x SB_LDB band storage
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage 1, panel: Householder QR of P = A[r0:, j0:j0+SB] (m x SB, r0 = j0 + SB), one workgroup of 1024 threads per problem,
+// the panel in registers.  Thread (c, g): column c = lane & 31, rows g + 32 t with g = 2 wave + (lane >> 5) (t < SB_TMAX):
+// the 32 lanes of a half-wave hold the same rows of the 32 columns, so the column being eliminated is read from LDS with
+// ONE address per half-wave (broadcast) -- with a column per half-wave instead every thread read the whole column and the
+// kernel was bound by the LDS port (377 KB per column).  Per column j, three barriers:
+//   A  the owner lanes have published the column x (double buffered),
+//      every thread forms its share of x^T P[:, c] on the rows below j (the reflector is linear in the unnormalised x:
+//      k_trdf's trick; the share of column j itself is |x|^2),
+//   B  wave 0 sums the 32 shares per column, forms tau, beta and v^T P[:, c] = P[j][c] + scale x^T P[:, c] for all columns
+//      (for c < j that is the Gram entry v_c^T v_j, which gives T = dlarft without another pass),
+//   C  rank-1 update of the columns c > j, column j becomes (R[0:j+1, j]; v).
+// ---------------------------------------------------------------------------------------------------------------
+// The row loops are unrolled over register arrays; left alone, the scheduler issues EVERY LDS read of a column first and
+// the arithmetic afterwards (one register pair per row in flight: the tall instantiations then spill).  Pinning the four
+// values a chunk has just produced, with a memory clobber, keeps the next chunk's reads behind this chunk's arithmetic.
+#define SB_CHUNK_FENCE() asm volatile("" ::: "memory")
+#define SB_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
+
+// TT: rows per thread of this instantiation (the host picks the smallest one that holds the tallest panel of the batch);
+// every loop over the rows is branch-free over TT -- rows beyond a problem's m are zeros in the registers and in LDS.
+// (With run-time trip tests per row the compiler emitted a scalar branch and a full LDS wait per row.)
+// 512 threads = 8 waves, two per SIMD: 256 registers per thread, so that a panel of 1472 x 32 (92 rows per thread) stays in
+// registers (with 1024 threads and 128 registers the tall instantiations spilled 150 registers).
+constexpr int SBP_NT = 512;            // threads of the panel kernel
+constexpr int SBP_NG = SBP_NT / 32;    // row groups: thread (c, g) holds rows g + SBP_NG * t
+template <int TT>
+__global__ __launch_bounds__(SBP_NT) void k_sb_panel(const SbBatch *__restrict__ bp, int j0) {
+  __shared__ double xs[2][TT * SBP_NG];
+  __shared__ double part[SBP_NG][SB + 1];  // [row group][column]
+  __shared__ double sG[SB][SB + 1];
+  __shared__ double stau[SB], spj[SB], sf[SB];
+  __shared__ double sscal[2];  // scale, beta
+  const SbBatch &b = *bp;
+  const int blk = blockIdx.x;
+  const int n = b.n[blk];
+  const int r0 = j0 + SB, m = n - r0;
+  if (m < 2) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c = lane & 31, g = 2 * wave + (lane >> 5);
+  double *A = b.A[blk];
+  double p[TT];
+  {
+    const double *col = A + (size_t)(j0 + c) * n + r0;
+#pragma unroll
+    for (int t = 0; t < TT; t++) {
+      const int r = min(g + SBP_NG * t, m - 1);  // clamped: every load is unconditional, the value is dropped beyond m
+      const double v = col[r];
+      p[t] = (g + SBP_NG * t < m) ? v : 0.0;
+      if ((t & 7) == 7) SB_CHUNK_FENCE();
+    }
+  }
+  for (int t = tid; t < SB * (SB + 1); t += SBP_NT) (&sG[0][0])[t] = 0.0;
+  for (int j = 0; j < SB; j++) {
+    const int buf = j & 1;
+    const double *x = xs[buf];
+    if (c == j) {
+#pragma unroll
+      for (int t = 0; t < TT; t++) xs[buf][g + SBP_NG * t] = p[t];
+    }
+    if (g == (j & (SBP_NG - 1))) spj[c] = (j >= SBP_NG) ? p[1] : p[0];  // P[j][c]: row j = g + 16 t, t = j >> 4
+    __syncthreads();                                                    // A
+    // x^T P[:, c] on the rows below j: the rows 0 .. 31 (t = 0, 1) are the only ones that can lie at or above row j
+    double s0 = (g > j) ? x[g] * p[0] : 0.0, s1 = (g + SBP_NG > j) ? x[g + SBP_NG] * p[1] : 0.0;
+#pragma unroll
+    for (int t = 2; t < TT; t += 2) {
+      s0 += x[g + SBP_NG * t] * p[t];
+      if (t + 1 < TT) s1 += x[g + SBP_NG * (t + 1)] * p[t + 1];
+      if ((t & 7) == 6) SB_CHUNK_FENCE();
+    }
+    part[g][c] = s0 + s1;
+    __syncthreads();  // B
+    if (wave == 0 && lane < 32) {
+      double S = 0.0;
+#pragma unroll 4
+      for (int gg = 0; gg < SBP_NG; gg++) S += part[gg][lane];
+      const double q = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S), j), __builtin_amdgcn_readlane(__double2loint(S), j));
+      const double alpha = x[j];
+      double tau, beta, scale;
+      if (q == 0.0) {
+        tau = 0.0;
+        beta = alpha;
+        scale = 0.0;
+      } else {
+        const double nrm = sqrt(alpha * alpha + q);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      const double wdot = spj[lane] + scale * S;  // v^T P[:, lane]
+      sf[lane] = (lane > j) ? tau * wdot : 0.0;
+      if (lane < j) sG[lane][j] = wdot;
+      if (lane == j) {
+        stau[j] = tau;
+        sscal[0] = scale;
+        sscal[1] = beta;
+        b.tau1[blk][j0 + j] = tau;
+      }
+    }
+    __syncthreads();  // C
+    const double f = sf[c], scale = sscal[0];
+    // one code path for all lanes: mul = scale and sub = 0 for the column itself (it becomes v), mul = 1 and
+    // sub = f scale x for the others (f = 0 for the columns already done)
+    const bool own = (c == j);
+    const double mul = own ? scale : 1.0, fs = own ? 0.0 : f * scale;
+    static_assert(TT % 4 == 0, "rows per thread in chunks of four");
+    p[2] = p[2] * mul - fs * x[g + SBP_NG * 2];
+    p[3] = p[3] * mul - fs * x[g + SBP_NG * 3];
+#pragma unroll
+    for (int t = 4; t < TT; t += 4) {
+      p[t] = p[t] * mul - fs * x[g + SBP_NG * t];
+      p[t + 1] = p[t + 1] * mul - fs * x[g + SBP_NG * (t + 1)];
+      p[t + 2] = p[t + 2] * mul - fs * x[g + SBP_NG * (t + 2)];
+      p[t + 3] = p[t + 3] * mul - fs * x[g + SBP_NG * (t + 3)];
+      SB_PIN4(p[t], p[t + 1], p[t + 2], p[t + 3]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int r = g + SBP_NG * t;
+      const double xr = x[r];
+      double pr = p[t];
+      if (r > j) pr = pr * mul - fs * xr;
+      else if (r == j) pr = own ? sscal[1] : pr - f;  // row j: R[j][j] = beta for the column itself, v_j = 1 for the others
+      p[t] = pr;
+    }
+  }
+  __syncthreads();
+  // results: R into the panel of A (rows <= column inside the band), the explicit reflectors into Vx and into the
+  // operand blocks [Y | V] and [V | U] of the trailing update
+  double *Vx = b.Vx[blk], *Lm = b.Lm[blk], *Rm = b.Rm[blk];
+  {
+    double *v0 = Vx + (size_t)(j0 + c) * n + r0, *v1 = Lm + (size_t)(SB + c) * n + r0, *v2 = Rm + (size_t)c * n + r0;
+    // rows 0 .. 31 (t = 0, 1) hold R on and above the diagonal and the unit diagonal of V; all other rows are plain v
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int r = g + SBP_NG * t;
+      if (r < m) {
+        const double val = p[t];
+        if (r <= c) A[(size_t)(j0 + c) * n + r0 + r] = val;  // R (upper triangle of the first SB rows)
+        const double v = (r > c) ? val : ((r == c) ? 1.0 : 0.0);
+        v0[r] = v;
+        v1[r] = v;
+        v2[r] = v;
+      }
+    }
+#pragma unroll
+    for (int t = 2; t < TT; t++) {
+      const int rr = g + SBP_NG * t;
+      if (rr < m) {
+        v0[rr] = p[t];
+        v1[rr] = p[t];
+        v2[rr] = p[t];
+      }
+      if ((t & 7) == 7) SB_CHUNK_FENCE();
+    }
+  }
+  // T = dlarft(forward, columnwise) from the Gram entries: T(i,i) = tau_i, T(0:i, i) = -tau_i T(0:i,0:i) G(0:i, i);
+  // lane = row of T, the rows in LDS (xs is free by now)
+  if (wave == 0 && lane < SB) {
+    double (*sT)[SB + 1] = reinterpret_cast<double (*)[SB + 1]>(&xs[0][0]);
+    for (int i = 0; i < SB; i++) sT[lane][i] = 0.0;
+    for (int i = 0; i < SB; i++) {
+      const double ti = stau[i];
+      double acc = 0.0;
+      for (int k = lane; k < i; k++) acc += sT[lane][k] * sG[k][i];  // T is upper triangular: T(lane, k) = 0 for k < lane
+      if (lane < i) sT[lane][i] = -ti * acc;
+      else if (lane == i) sT[lane][i] = ti;
+    }
+    double *Tp = b.T1[blk] + (size_t)(j0 / SB) * SB * SB;
+    for (int i = 0; i < SB; i++) Tp[(size_t)i * SB + lane] = sT[lane][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage 1, W kernels (row tiles of SB_RT rows): w1 sums the split-K slabs of X and forms the tile's share of Z = V^T X;
+// w2 sums Z, forms M2 = T^T Z T and the operand blocks  Y = X T (into Lm[:, 0:SB]),  U = Y - V M2^T (into Rm[:, SB:2SB]).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sb_w1(const SbBatch *__restrict__ bp, int j0) {
+  __shared__ double sX[SB_RT][SB + 1], sV[SB_RT][SB + 1];
+  const SbBatch &b = *bp;
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  const int r0 = j0 + SB, m = n - r0;
+  if (m < 2) return;
+  const int tile = blockIdx.x;
+  const int row0 = tile * SB_RT;
+  if (row0 >= m) return;
+  const int tid = threadIdx.x, rl = tid & 63, cg = tid >> 6;
+  const int row = row0 + rl;
+  const bool live = row < m;
+  const double *Vx = b.Vx[blk];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int c = 8 * cg + u;
+    double x = 0.0, v = 0.0;
+    if (live) {
+#pragma unroll
+      for (int s = 0; s < SB_KS; s++) x += b.Xs[blk][((size_t)s * SB + c) * n + r0 + row];
+      v = Vx[(size_t)(j0 + c) * n + r0 + row];
+      b.X[blk][(size_t)c * n + r0 + row] = x;
+    }
+    sX[rl][c] = x;
+    sV[rl][c] = v;
+  }
+  __syncthreads();
+  // Zp[tile][c'][c] = sum_rows V[row][c'] X[row][c]; thread -> c' = tid & 31, c = (tid >> 5) * 4 .. + 3
+  const int cp = tid & 31, c4 = (tid >> 5) * 4;
+  double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+#pragma unroll 8
+  for (int r = 0; r < SB_RT; r++) {
+    const double v = sV[r][cp];
+    z0 += v * sX[r][c4];
+    z1 += v * sX[r][c4 + 1];
+    z2 += v * sX[r][c4 + 2];
+    z3 += v * sX[r][c4 + 3];
+  }
+  double *Zp = b.Zp[blk] + (size_t)tile * SB * SB;
+  Zp[(size_t)(c4)*SB + cp] = z0;
+  Zp[(size_t)(c4 + 1) * SB + cp] = z1;
+  Zp[(size_t)(c4 + 2) * SB + cp] = z2;
+  Zp[(size_t)(c4 + 3) * SB + cp] = z3;
+}
+
+__global__ __launch_bounds__(256) void k_sb_w2(const SbBatch *__restrict__ bp, int j0) {
+  __shared__ double sT[SB][SB + 1], sZ[SB][SB + 1], sW[SB][SB + 1], sM[SB][SB + 1];
+  __shared__ double sX[SB_RT][SB + 1], sV[SB_RT][SB + 1];
+  const SbBatch &b = *bp;
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  const int r0 = j0 + SB, m = n - r0;
+  if (m < 2) return;
+  const int row0 = blockIdx.x * SB_RT;
+  if (row0 >= m) return;
+  const int ntile = (m + SB_RT - 1) / SB_RT;
+  const int tid = threadIdx.x;
+  const double *Tp = b.T1[blk] + (size_t)(j0 / SB) * SB * SB;
+  // Z = sum of the tiles' shares (fixed order), T
+  for (int e = tid; e < SB * SB; e += 256) {
+    double z = 0.0;
+    for (int t = 0; t < ntile; t++) z += b.Zp[blk][(size_t)t * SB * SB + e];
+    sZ[e % SB][e / SB] = z;           // column-major source: element (row e % SB, col e / SB)
+    sT[e % SB][e / SB] = Tp[e];
+  }
+  const int rl = tid & 63, cg = tid >> 6;
+  const int row = row0 + rl;
+  const bool live = row < m;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int c = 8 * cg + u;
+    sX[rl][c] = live ? b.X[blk][(size_t)c * n + r0 + row] : 0.0;
+    sV[rl][c] = live ? b.Vx[blk][(size_t)(j0 + c) * n + r0 + row] : 0.0;
+  }
+  __syncthreads();
+  // W = Z T, then M2 = T^T W   (32 x 32 each; thread -> row tid & 31, columns (tid >> 5) * 4 .. + 3)
+  {
+    const int i = tid & 31, c4 = (tid >> 5) * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < SB; k++) {
+      const double z = sZ[i][k];
+#pragma unroll
+      for (int u = 0; u < 4; u++) a[u] += z * sT[k][c4 + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) sW[i][c4 + u] = a[u];
+  }
+  __syncthreads();
+  {
+    const int i = tid & 31, c4 = (tid >> 5) * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < SB; k++) {
+      const double t = sT[k][i];  // T^T(i, k)
+#pragma unroll
+      for (int u = 0; u < 4; u++) a[u] += t * sW[k][c4 + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) sM[i][c4 + u] = a[u];
+  }
+  __syncthreads();
+  // Y = X T,  U = Y - V M2^T
+  if (live) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int c = 8 * cg + u;
+      double y = 0.0, vm = 0.0;
+      for (int k = 0; k < SB; k++) {
+        y += sX[rl][k] * sT[k][c];
+        vm += sV[rl][k] * sM[c][k];
+      }
+      b.Lm[blk][(size_t)c * n + r0 + row] = y;
+      b.Rm[blk][(size_t)(SB + c) * n + r0 + row] = y - vm;
+    }
+  }
+}
+
+// band storage from the reduced matrix: AB[j][d] = A[j + d][j] for d <= SB, zero for the bulge rows
+__global__ void k_sb_gather_band(const SbBatch *__restrict__ bp) {
+  const SbBatch &b = *bp;
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), d = threadIdx.x & 63;
+  if (j >= n) return;
+  double v = 0.0;
+  if (d <= SB && j + d < n) v = b.A[blk][(size_t)j * n + j + d];
+  b.AB[blk][(size_t)j * SB_LDB + d] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct SbWork {
+  DevBuf<double> Vx[SB_MAXB], tau1[SB_MAXB], T1[SB_MAXB], Xs[SB_MAXB], X[SB_MAXB], Zp[SB_MAXB], Lm[SB_MAXB], Rm[SB_MAXB], AB[SB_MAXB];
+  DevBuf<SbBatch> desc;
+  std::vector<SbBatch> h_desc;
+  DevBuf<GemmTask> xtasks, utasks;
+  std::vector<GemmTask> h_xtasks, h_utasks;
+};
+static std::map<hfg_ctx *, SbWork *> g_sb;
+void sb_release(hfg_ctx *ctx) {
+  auto it = g_sb.find(ctx);
+  if (it != g_sb.end()) {
+    delete it->second;
+    g_sb.erase(it);
+  }
+}
+static SbWork &sb_work(hfg_ctx *ctx) {
+  auto it = g_sb.find(ctx);
+  if (it != g_sb.end()) return *it->second;
+  SbWork *w = new SbWork();
+  g_sb[ctx] = w;
+  return *w;
+}
+
+bool sb_supported(int nblk, const int *ns) {
+  if (nblk > SB_MAXB) return false;
+  for (int i = 0; i < nblk; i++)
+    if (ns[i] - SB > SBP_NG * SB_TMAX || ns[i] < 4 * SB) return false;
+  return true;
+}
+
+/// stage 1 for a batch: A[blk] (n x n full symmetric, ld n) -> band form in place + band storage AB; reflectors in the
+/// work area (read by the back-transformation)
+void sb_reduce_to_band(hfg_ctx *ctx, int nblk, const int *ns, double *const *A) {
+  if (!sb_supported(nblk, ns)) throw std::logic_error("sb_reduce_to_band: problem size outside the two-stage kernels' range");
+  SbWork &w = sb_work(ctx);
+  hipStream_t s = ctx->stream;
+  SbBatch b{};
+  b.nblk = nblk;
+  int nmax = 0;
+  for (int i = 0; i < nblk; i++) {
+    const int n = ns[i];
+    nmax = std::max(nmax, n);
+    const int npanel = n / SB + 1, ntile = (n + SB_RT - 1) / SB_RT + 1;
+    w.Vx[i].resize((size_t)n * n);
+    w.tau1[i].resize(n + SB);
+    w.T1[i].resize((size_t)npanel * SB * SB);
+    w.Xs[i].resize((size_t)SB_KS * n * SB);
+    w.X[i].resize((size_t)n * SB);
+    w.Zp[i].resize((size_t)ntile * SB * SB);
+    w.Lm[i].resize((size_t)n * 2 * SB);
+    w.Rm[i].resize((size_t)n * 2 * SB);
+    w.AB[i].resize((size_t)n * SB_LDB + SB_LDB);
+    b.n[i] = n;
+    b.A[i] = A[i];
+    b.Vx[i] = w.Vx[i].p;
+    b.tau1[i] = w.tau1[i].p;
+    b.T1[i] = w.T1[i].p;
+    b.Xs[i] = w.Xs[i].p;
+    b.X[i] = w.X[i].p;
+    b.Zp[i] = w.Zp[i].p;
+    b.Lm[i] = w.Lm[i].p;
+    b.Rm[i] = w.Rm[i].p;
+    b.AB[i] = w.AB[i].p;
+    HFG_HIP_CHECK(hipMemsetAsync(w.Vx[i].p, 0, sizeof(double) * (size_t)n * n, s));
+    HFG_HIP_CHECK(hipMemsetAsync(w.tau1[i].p, 0, sizeof(double) * (n + SB), s));
+  }
+  upload_cached(w.desc, w.h_desc, std::vector<SbBatch>(1, b), s);
+  const SbBatch *db = w.desc.p;
+  // task lists of all panels: X slabs (SB_KS per block) and the rank-2SB update
+  const int npan = (nmax - SB - 2) / SB + 1;  // panels with m = n - (p+1) SB >= 2 for the largest problem
+  GemmTask none;
+  none.A = none.B = nullptr;
+  none.C = nullptr;
+  none.M = none.N = none.K = 0;
+  none.lda = none.ldb = none.ldc = 1;
+  std::vector<GemmTask> xt((size_t)npan * SB_KS * nblk, none), ut((size_t)npan * nblk, none);
+  for (int p = 0; p < npan; p++)
+    for (int k = 0; k < nblk; k++) {
+      const int n = ns[k], j0 = p * SB, r0 = j0 + SB, m = n - r0;
+      if (m < 2) continue;
+      const int chunk = (((m + SB_KS - 1) / SB_KS) + 15) / 16 * 16;
+      for (int sl = 0; sl < SB_KS; sl++) {
+        GemmTask g = none;
+        const int k0 = sl * chunk, kk = std::max(0, std::min(chunk, m - k0));
+        g.A = A[k] + (size_t)(r0 + (kk > 0 ? k0 : 0)) * n + r0;           // A22[:, k0:k0+kk]
+        g.B = w.Vx[k].p + (size_t)j0 * n + r0 + (kk > 0 ? k0 : 0);        // V[k0:k0+kk, :]
+        g.C = w.Xs[k].p + (size_t)sl * SB * n + r0;
+        g.M = m;
+        g.N = SB;
+        g.K = kk;  // K = 0 writes zeros
+        g.lda = g.ldb = g.ldc = n;
+        xt[((size_t)p * SB_KS + sl) * nblk + k] = g;
+      }
+      GemmTask u = none;
+      u.A = w.Lm[k].p + r0;
+      u.B = w.Rm[k].p + r0;
+      u.C = A[k] + (size_t)r0 * n + r0;
+      u.M = u.N = m;
+      u.K = 2 * SB;
+      u.lda = u.ldb = u.ldc = n;
+      u.tB = 1;
+      u.alpha = -1.0;
+      u.beta = 1.0;
+      ut[(size_t)p * nblk + k] = u;
+    }
+  upload_cached(w.xtasks, w.h_xtasks, xt, s);
+  upload_cached(w.utasks, w.h_utasks, ut, s);
+  for (int p = 0; p < npan; p++) {
+    const int j0 = p * SB, mmax = nmax - j0 - SB;
+    {
+      const int TTn = (mmax + SBP_NG - 1) / SBP_NG;
+      if (TTn <= 16) hipLaunchKernelGGL(k_sb_panel<16>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
+      else if (TTn <= 32) hipLaunchKernelGGL(k_sb_panel<32>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
+      else if (TTn <= 48) hipLaunchKernelGGL(k_sb_panel<48>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
+      else if (TTn <= 64) hipLaunchKernelGGL(k_sb_panel<64>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
+      else if (TTn <= 80) hipLaunchKernelGGL(k_sb_panel<80>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
+      else hipLaunchKernelGGL(k_sb_panel<SB_TMAX>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
+    }
+    gemm_tasklist64_dev(ctx, w.xtasks.p + (size_t)p * SB_KS * nblk, SB_KS * nblk, mmax, SB);
+    const int ntile = (mmax + SB_RT - 1) / SB_RT;
+    hipLaunchKernelGGL(k_sb_w1, dim3(ntile, nblk), dim3(256), 0, s, db, j0);
+    hipLaunchKernelGGL(k_sb_w2, dim3(ntile, nblk), dim3(256), 0, s, db, j0);
+    gemm_tasklist_acc_dev(ctx, w.utasks.p + (size_t)p * nblk, nblk, mmax, mmax, mmax < 1024);
+  }
+  hipLaunchKernelGGL(k_sb_gather_band, dim3((nmax + 3) / 4, nblk), dim3(256), 0, s, db);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+/// test access: band storage (n x SB_LDB, column j at [j * SB_LDB]) of the last reduction of this context, block blk
+void sb_fetch_band(hfg_ctx *ctx, int blk, int n, double *hostAB) {
+  SbWork &w = sb_work(ctx);
+  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HFG_HIP_CHECK(hipMemcpy(hostAB, w.AB[blk].p, sizeof(double) * (size_t)n * SB_LDB, hipMemcpyDeviceToHost));
+}
+int sb_bandwidth() { return SB; }
+int sb_ldb() { return SB_LDB; }
+
+}  // namespace hfg

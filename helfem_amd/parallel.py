@@ -4,8 +4,10 @@ The hot path shards naturally:
   * Coulomb: (L,|M|) channels are independent (basis.cpp:1414)      -> rank r owns channels ilm % nranks == r
   * XC: radial quadrature points are independent (dftgrid.cpp:779)  -> rank r owns points Q % nranks == r
   * eigensolve: symmetry blocks are independent (scf_helpers.cpp:148) -> rank r owns blocks ib % nranks == r
-Each rank produces partial results in a zero-padded buffer; one sum all-reduce of the *compact*
-(block-banded) Fock buffer and one of the eigenvector block buffer complete them on every rank.
+Each rank produces partial Fock contributions in a zero-padded buffer; one sum all-reduce of the *compact*
+(block-banded) Fock buffer completes them on every rank.  The eigenvector blocks have ONE owner each, so they are not
+summed: every block slot is broadcast from its owner (all broadcasts in flight together) -- half the bytes of a sum
+all-reduce of the zero-padded buffer and no additions; ranks beyond the number of blocks own nothing and only receive.
 No other data-path collective exists.  The same functions run on CPU tensors with the gloo backend,
 which is how the N>1 logic is tested without GPUs (tests/test_parallel_gloo.py).
 """
@@ -60,6 +62,19 @@ def allreduce_sum_(t):
     if _active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def broadcast_block_slots_(buf, nblk, nranks=None):
+    """buf: nblk equal slots, slot ib complete on rank owner(ib) -> complete on every rank.  One broadcast per block, all
+    issued before the first wait (different roots: they travel concurrently over different xGMI links)."""
+    if not _active():
+        return buf
+    world = dist.get_world_size() if nranks is None else nranks
+    slot = buf.numel() // nblk
+    work = [dist.broadcast(buf[ib * slot:(ib + 1) * slot], src=owner(ib, world), async_op=True) for ib in range(nblk)]
+    for w in work:
+        w.wait()
+    return buf
 
 
 def barrier():

@@ -29,10 +29,11 @@ def main(out_path):
     E0, C0 = hf.scf.eig_gsym_sub(H0, Sinvh, step.blocks, ctx=ctx)
     P0 = 2.0 * hf.scf.form_density(C0, w["nocc"], ctx=ctx)
     allred = parallel.allreduce_sum_ if world > 1 else None
+    xblocks = parallel.broadcast_block_slots_ if world > 1 else None
     res = []
     for it in range(3):
         step.set_density(P0)
-        step.step(allred)
+        step.step(allred, xblocks)
         step.P.mul_(2.0)  # a torch operation on the same stream, no synchronisation in between
         res.append(dict(E=step.E.cpu().numpy()[:12].tolist(), exc=float(step.scal[0].item()),
                         trPS=float((step.P.view(N, N).cpu().numpy() * S).sum())))

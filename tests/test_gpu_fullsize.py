@@ -126,3 +126,89 @@ def test_fullsize_xc_without_density_threshold(full):
         assert abs(E - E0) < 1e-9 * abs(E0) and abs(N - N0) < 1e-9 * N0
         Ha, Hb, Ep, _, _ = grid.eval_Fxc_pol(x, c, half, half, 0.0)
         assert np.all(np.isfinite(Ha)) and np.all(np.isfinite(Hb)) and abs(Ep - E) < 1e-11 * abs(E), (x, c)
+
+
+# ---- BASELINE config 5 sizing: LiF, lmmax = [29, 29], 5 x 15 -> Nbf = 6102, symmetry blocks 2100 / 2001 / 2001 ----------
+@pytest.fixture(scope="module")
+def lif(native_libs):
+    import helfem_amd as hf
+    if hf.device_count() < 1:
+        pytest.fail("no HIP device: the full-size checks need a real MI355X")
+    sys.path.insert(0, ROOT)
+    import bench
+    w = dict(bench.WORKLOADS["lif_pbe_nbf6102"])
+    basis, bval, lval, mval, ldft, mdft = bench.build_basis(hf, w)
+    basis.compute_tei(True, device=True)
+    basis.upload(ldft, mdft)
+    N = basis.Nbf()
+    assert N == 6102
+    S = basis.overlap()
+    H0 = np.asfortranarray(basis.kinetic() + basis.nuclear())
+    blocks = basis.get_sym_idx(1)
+    assert sorted(len(b) for b in blocks) == [2001, 2001, 2100]
+    X = hf.scf.form_Sinvh(S, False, blocks)
+    E, C = hf.scf.eig_gsym_sub(H0, X, blocks)
+    return dict(hf=hf, basis=basis, ldft=ldft, mdft=mdft, N=N, S=S, H0=H0, X=X, blocks=blocks, E=E, C=C, w=w)
+
+
+def test_lif_nbf6102_eigensolve(lif):
+    """blocks of 2100 / 2001 / 2001: the regime where the symmetric sweep of the tridiagonalisation covers most columns"""
+    S, X, H0, E, C, N = lif["S"], lif["X"], lif["H0"], lif["E"], lif["C"], lif["N"]
+    assert np.max(np.abs(X.T @ S @ X - np.eye(N))) < 1e-9
+    assert np.all(np.diff(E) >= 0.0)
+    SC = S @ C
+    assert np.max(np.abs(C.T @ SC - np.eye(N))) < 1e-9
+    assert np.max(np.abs(H0 @ C - SC * E)) < 1e-9 * np.max(np.abs(E))
+    for b in lif["blocks"]:
+        other = np.setdiff1d(np.arange(N), b)
+        cols = np.where(np.max(np.abs(C[b, :]), axis=0) > 1e-8)[0]
+        assert len(cols) == len(b) and np.max(np.abs(C[np.ix_(other, cols)])) < 1e-10
+    # heteronuclear: the two lowest core levels are the fluorine and lithium 1s, E ~ -Z^2/2 - Z'/R
+    R = lif["w"]["Rbond"]
+    assert abs(E[0] - (-40.5 - 3.0 / R)) < 0.1 and abs(E[1] - (-4.5 - 9.0 / R)) < 0.1
+
+
+def test_lif_nbf6102_coulomb_exchange_xc(lif):
+    hf, basis, S, C, N = lif["hf"], lif["basis"], lif["S"], lif["C"], lif["N"]
+    nocc = lif["w"]["nocc"]
+    P = hf.scf.form_density(C, nocc)
+    assert abs(np.sum(P * S) - nocc) < 1e-9
+    P2 = hf.scf.form_density(np.asfortranarray(C[:, 2:]), 4)
+    J1, J2 = basis.coulomb(P), basis.coulomb(P2)
+    J12 = basis.coulomb(np.asfortranarray(P + 2.0 * P2))
+    sc = np.max(np.abs(J12))
+    assert np.max(np.abs(J12 - J1 - 2.0 * J2)) < 1e-12 * sc and np.max(np.abs(J1 - J1.T)) < 1e-12 * sc
+    assert abs(np.sum(P * J2) - np.sum(P2 * J1)) < 1e-11 * abs(np.sum(P * J2))
+    K1, K2 = basis.exchange(P), basis.exchange(P2)
+    K12 = basis.exchange(np.asfortranarray(P + 2.0 * P2))
+    sk = np.max(np.abs(K12))
+    assert np.max(np.abs(K12 - K1 - 2.0 * K2)) < 1e-11 * sk and np.max(np.abs(K1 - K1.T)) < 1e-11 * sk
+    assert np.sum(P * K1) < 0.0
+    c0 = np.asfortranarray(C[:, :1])
+    p0 = hf.scf.form_density(c0, 1)
+    assert abs(np.sum(p0 * basis.coulomb(p0)) + np.sum(p0 * basis.exchange(p0))) < 1e-10 * np.sum(p0 * basis.coulomb(p0))
+    grid = hf.DFTGrid(basis, lif["ldft"], lif["mdft"])
+    Pt = np.asfortranarray(2.0 * P)
+    H, Exc, Nel, _ = grid.eval_Fxc(101, 130, Pt)
+    assert abs(Nel - 2.0 * nocc) < 1e-7 * nocc and Exc < 0.0
+    assert np.max(np.abs(H - H.T)) < 1e-11 * np.max(np.abs(H))
+    D = np.asfortranarray(hf.scf.form_density(np.asfortranarray(C[:, nocc - 1:nocc + 2]), 3))
+    h = 1e-4
+    Ep = grid.eval_Fxc(101, 130, np.asfortranarray(Pt + h * D))[1]
+    Em = grid.eval_Fxc(101, 130, np.asfortranarray(Pt - h * D))[1]
+    fd, an = (Ep - Em) / (2 * h), float(np.sum(H * D))
+    assert abs(fd - an) < 1e-6 * abs(an), (fd, an)
+
+
+def test_symmetry0_single_4230_eigenproblem(full):
+    """--symmetry 0 (scf::eig_gsym, scf_helpers.cpp:131): ONE unsymmetrised 4230-dimensional problem instead of the three m
+    blocks; same levels as the blocked solve, and the residual / orthonormality of every column"""
+    hf, S, H0, N = full["hf"], full["S"], full["H0"], full["N"]
+    X0 = hf.scf.form_Sinvh(S, False, [np.arange(N)])
+    assert np.max(np.abs(X0.T @ S @ X0 - np.eye(N))) < 1e-9
+    E0, C0 = hf.scf.eig_gsym(H0, X0)
+    assert np.all(np.diff(E0) >= 0.0)
+    SC = S @ C0
+    assert np.max(np.abs(C0.T @ SC - np.eye(N))) < 1e-9
+    assert np.max(np.abs(H0 @ C0 - SC * E0)) < 1e-9 * np.max(np.abs(E0))
+    assert np.max(np.abs(E0 - full["E"])) < 1e-9 * np.max(np.abs(E0))  # the m-blocked solve finds the same spectrum

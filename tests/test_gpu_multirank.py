@@ -1,4 +1,4 @@
-"""N>1 path on a real GPU: two and three gloo ranks sharing the one device must reproduce the single-rank step.
+"""N>1 path on a real GPU: two, three and four gloo ranks sharing the one device must reproduce the single-rank step.
 (Covers the stream ordering between the HIP kernels and torch's collectives, which CPU tests cannot see.)"""
 import json
 import os
@@ -24,9 +24,10 @@ def _run(nranks, out):
     return json.load(open(out))
 
 
-def test_two_and_three_ranks_reproduce_one(native_libs, tmp_path):
+def test_two_three_and_four_ranks_reproduce_one(native_libs, tmp_path):
+    """4 ranks, 3 symmetry blocks: the fourth rank owns no block, it only receives the owners' broadcasts"""
     ref = _run(1, str(tmp_path / "r1.json"))
-    for n in (2, 3):
+    for n in (2, 3, 4):
         got = _run(n, str(tmp_path / ("r%d.json" % n)))
         for a, b in zip(ref, got):
             assert abs(a["exc"] - b["exc"]) < 1e-10 * abs(a["exc"])

@@ -1,7 +1,7 @@
-"""N>1 path on CPU: two gloo ranks, the same sharding rules and the same collectives as the multi-GPU run
+"""N>1 path on CPU: two and four gloo ranks, the same sharding rules and the same collectives as the multi-GPU run
 (helfem_amd/parallel.py), with the CPU oracle standing in for the kernels.  Checks that summing the shards'
 zero-padded partial results with ONE all-reduce reproduces the unsharded Fock matrix / energies, and that the
-block-distributed eigensolve + all-reduce + global sort reproduces scf::eig_gsym_sub."""
+block-distributed eigensolve + owner broadcasts + global sort reproduces scf::eig_gsym_sub."""
 import os
 import socket
 import sys
@@ -61,7 +61,8 @@ def _worker(rank, world, port, out):
         bb[ib * slot:ib * slot + n * n] = Cb.ravel(order="F")
         bb[ib * slot + nmax * nmax:ib * slot + nmax * nmax + n] = Eb
     tb = torch.from_numpy(bb)
-    parallel.allreduce_sum_(tb)
+    # every block has ONE owner: broadcast from the owners (ranks beyond the number of blocks own nothing and only receive)
+    parallel.broadcast_block_slots_(tb, len(blocks))
     Eall = np.concatenate([bb[ib * slot + nmax * nmax:ib * slot + nmax * nmax + len(blocks[ib])] for ib in range(len(blocks))])
     order = np.argsort(Eall, kind="stable")
     C = np.zeros((N, N))
@@ -77,11 +78,13 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_step_matches_unsharded(tmp_path, native_libs):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_matches_unsharded(tmp_path, native_libs, world):
+    """world 4 with 3 symmetry blocks: rank 3 owns no block and no eigenvector slot (idle-rank logic of the exchange)"""
     import torch.multiprocessing as mp
     out = str(tmp_path / "res.npz")
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     res = np.load(out)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import common
@@ -94,7 +97,7 @@ def test_two_rank_sharded_step_matches_unsharded(tmp_path, native_libs):
     H, Exc, Nel, _ = ob.eval_Fxc(24, 13, 101, 130, P)
     assert np.max(np.abs(res["F_part"] - (J + H))) < 1e-12 * np.max(np.abs(J + H))
     assert abs(res["Exc"] - Exc) < 1e-12 * max(1.0, abs(Exc)) and abs(res["Nel"] - Nel) < 1e-12 * max(1.0, abs(Nel))
-    assert res["tmax"] == 1.0  # MAX over ranks of the rank id
+    assert res["tmax"] == world - 1.0  # MAX over ranks of the rank id
     S = gb.overlap()
     X = orc.form_Sinvh(S, False, blocks)
     Eo, Co = orc.eig_gsym_sub(res["F"], X, blocks)
