@@ -41,6 +41,12 @@ struct SbBatch {
   double *Lm[SB_MAXB];    // n x 2 SB: [Y | V], ld n
   double *Rm[SB_MAXB];    // n x 2 SB: [V | U], ld n
   double *AB[SB_MAXB];    // n x SB_LDB band storage
+  // stage 2
+  double *VV[SB_MAXB];    // n x n: column s holds the reflectors of sweep s on rows s+1 .. n-1 (one per SB rows, each with its unit entry)
+  double *tau2[SB_MAXB];  // [sweep][task]: SB2_KT per sweep
+  int *prog[SB_MAXB];     // [sweep]: tasks completed (SB2_DONE when the sweep has ended); slot 0 of prog is sweep -1 (always done)
+  double *d[SB_MAXB], *e[SB_MAXB];
+  int *status;            // != 0: a wait ran out (the chain is broken), every wave leaves
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(SBP_NT) void k_sb_panel(const SbBatch *__restrict__
   __shared__ double sG[SB][SB + 1];
   __shared__ double stau[SB], spj[SB], sf[SB];
   __shared__ double sscal[2];  // scale, beta
+  __shared__ double sT[SB][SB + 1];
   const SbBatch &b = *bp;
   const int blk = blockIdx.x;
   const int n = b.n[blk];
@@ -200,9 +207,8 @@ __global__ __launch_bounds__(SBP_NT) void k_sb_panel(const SbBatch *__restrict__
     }
   }
   // T = dlarft(forward, columnwise) from the Gram entries: T(i,i) = tau_i, T(0:i, i) = -tau_i T(0:i,0:i) G(0:i, i);
-  // lane = row of T, the rows in LDS (xs is free by now)
+  // lane = row of T, the rows in LDS
   if (wave == 0 && lane < SB) {
-    double (*sT)[SB + 1] = reinterpret_cast<double (*)[SB + 1]>(&xs[0][0]);
     for (int i = 0; i < SB; i++) sT[lane][i] = 0.0;
     for (int i = 0; i < SB; i++) {
       const double ti = stau[i];
@@ -350,8 +356,227 @@ __global__ void k_sb_gather_band(const SbBatch *__restrict__ bp) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stage 2: band -> tridiagonal by bulge chasing (tools/two_stage_model.py: task()).  Sweep s eliminates column s below
+// the subdiagonal with a reflector on rows s+1 .. s+SB and chases the bulge down the band: task k works on the rows
+// R_k = s + (k-1) SB + 1 .. s + k SB -- the reflector that zeroes the first column of the bulge block B = A[R_k, R_{k-1}]
+// is applied from the left to B, from both sides to D = A[R_k, R_k] and from the right to Bn = A[R_{k+1}, R_k], which
+// becomes the next task's bulge block.  Task (s, k) needs (s-1, k+2): consecutive sweeps run three tasks apart, about
+// n / (3 SB) of them at a time.
+//
+// One wavefront (a workgroup of 64) per sweep in flight; wave g owns the sweeps g, g + G, ...  A 32 x 32 block lives in
+// 16 registers per lane ("row layout": lane = (row a = lane & 31, half h = lane >> 5), register u = column 16 h + u), so
+// that a block's columns are contiguous 256-byte runs of the band storage.  Row sums (Bn v, D v) are in-lane sums plus one
+// swap across the halves; column sums (v^T B and the strictly lower part of D under its diagonal) go through a padded
+// LDS tile written in row layout and read down the columns.  Vectors needed "by register index" (v, w, q) are broadcast
+// through LDS.  Sweeps hand data over through the band storage in HBM/L2: a wave releases (agent scope) after its stores
+// and publishes its task count; the follower polls that count and acquires before it loads.  The publication runs one
+// task behind the stores (they have drained by then), which costs one more task of lag but no stall per task.
+// Every wait is bounded; a wait that runs out raises the batch's status word and every wave leaves.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SB2_DONE = 1 << 30;
+constexpr int SB2_KT = 64;  // tau2 slots per sweep (>= n / SB + 2)
+
+__device__ __forceinline__ void sb2_load(const double *__restrict__ AB, int n, int rbase, int cbase, int lane, double (&blk)[16]) {
+  const int a = lane & 31, c16 = (lane >> 5) * 16, i = rbase + a;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int j = cbase + c16 + u, dd = i - j;
+    const bool ok = (i < n) && (j < n) && (dd >= 0) && (dd < SB_LDB);
+    const double v = AB[(size_t)min(j, n - 1) * SB_LDB + min(max(dd, 0), SB_LDB - 1)];
+    blk[u] = ok ? v : 0.0;
+  }
+}
+__device__ __forceinline__ void sb2_store(double *__restrict__ AB, int n, int rbase, int cbase, int lane, const double (&blk)[16]) {
+  const int a = lane & 31, c16 = (lane >> 5) * 16, i = rbase + a;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int j = cbase + c16 + u, dd = i - j;
+    if ((i < n) && (j < n) && (dd >= 0) && (dd < SB_LDB)) AB[(size_t)j * SB_LDB + dd] = blk[u];
+  }
+}
+// 16 values vec[16 h .. 16 h + 15] of a 32-vector in LDS, for the lane's half h
+__device__ __forceinline__ void sb2_bcast(const double *vec, int lane, double (&out)[16]) {
+  const int c16 = (lane >> 5) * 16;
+#pragma unroll
+  for (int u = 0; u < 16; u++) out[u] = vec[c16 + u];
+}
+// column sums  sum_r w_r M[r][c]  of a block in row layout through the LDS tile; strict: only the rows r > c (the part of a
+// lower-triangular block under its diagonal).  wb = the weights by register index (sb2_bcast of w).  Returned in BOTH
+// halves of lane c = lane & 31.
+__device__ __forceinline__ double sb2_colsum(double (*tile)[SB + 1], int lane, const double (&blk)[16], const double (&wb)[16], bool strict) {
+  const int a = lane & 31, h = lane >> 5, c16 = h * 16;
+#pragma unroll
+  for (int u = 0; u < 16; u++) tile[a][c16 + u] = blk[u];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes are done (one wave per workgroup: no barrier)
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int r = c16 + u;
+    const double m = tile[r][a];
+    s += ((!strict || r > a) ? m : 0.0) * wb[u];
+  }
+  __builtin_amdgcn_wave_barrier();
+  return swap32_sum(s, s);
+}
+
+__global__ __launch_bounds__(64) void k_sb_chase(const SbBatch *__restrict__ bp, int G, int delayed) {
+  __shared__ double tile[SB][SB + 1];
+  __shared__ double vecv[SB], vecw[SB], vecq[SB];
+  const SbBatch &b = *bp;
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  const int lane = threadIdx.x, a = lane & 31, h = lane >> 5;
+  double *AB = b.AB[blk];
+  int *prog = b.prog[blk] + 1;  // prog[-1] = sweep -1, always done
+  volatile int *status = b.status;
+  for (int s = blockIdx.x; s <= n - 3; s += G) {
+    double B[16], D[16], Bn[16], vb[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) B[u] = 0.0;
+    int published = 0;  // tasks of this sweep already published
+    int k = 1;
+    for (;; k++) {
+      const int rf = s + (k - 1) * SB + 1;  // first row of R_k
+      if (rf > n - 2) break;                // fewer than two rows: the sweep has ended
+      const int c0 = (k == 1) ? s : rf - SB;
+      // ---- wait for sweep s-1 to be k+2 tasks in (or done) ----
+      {
+        const int need = k + 2;
+        int spins = 0;
+        while (true) {
+          const int got = __hip_atomic_load(&prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (got >= need) break;
+          if (*status != 0) return;
+          if (++spins > (1 << 22)) {
+            if (lane == 0) atomicExch((int *)b.status, 1);
+            return;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      // ---- operands ----
+      if (k == 1) {
+        // the column s itself: x = A[s+1 .. s+SB, s], carried as column 0 of B
+        const int i = rf + a;
+        const double x0 = (h == 0 && i < n) ? AB[(size_t)s * SB_LDB + 1 + a] : 0.0;
+        B[0] = (h == 0) ? x0 : 0.0;
+      }
+      sb2_load(AB, n, rf, rf, lane, D);        // lower triangle (with the diagonal); zeros above
+      sb2_load(AB, n, rf + SB, rf, lane, Bn);
+      // ---- reflector from x = column 0 of B (lanes 0 .. 31, register 0) ----
+      const double xa = (h == 0) ? B[0] : 0.0;
+      const double xn2 = wave_sum((h == 0 && a >= 1) ? xa * xa : 0.0);
+      const double alpha = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xa)), __builtin_amdgcn_readfirstlane(__double2loint(xa)));
+      double tau, beta, scale;
+      if (xn2 == 0.0) {
+        tau = 0.0;
+        beta = alpha;
+        scale = 0.0;
+      } else {
+        const double nrm = sqrt(alpha * alpha + xn2);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      if (h == 0) vecv[a] = (a == 0) ? 1.0 : xa * scale;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      const double va = vecv[a];  // v by row, in both halves
+      sb2_bcast(vecv, lane, vb);  // v by register index
+      // reflectors for the back-transformation
+      if (h == 0 && rf + a < n) b.VV[blk][(size_t)s * n + rf + a] = va;
+      if (lane == 0) b.tau2[blk][(size_t)s * SB2_KT + (k - 1)] = tau;
+      // ---- left application to the bulge block: B <- (I - tau v v^T) B; its first column becomes (beta, 0, ...) ----
+      if (k >= 2) {
+        const double w = sb2_colsum(tile, lane, B, vb, false);  // v^T B by column, in lane c
+        if (h == 0) vecw[a] = w;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        double wb[16];
+        sb2_bcast(vecw, lane, wb);
+        const double tv = tau * va;
+#pragma unroll
+        for (int u = 0; u < 16; u++) B[u] -= tv * wb[u];
+        if (h == 0) B[0] = (a == 0) ? beta : 0.0;
+        sb2_store(AB, n, rf, c0, lane, B);
+      } else if (h == 0) {
+        const int i = rf + a;
+        if (i < n) AB[(size_t)s * SB_LDB + 1 + a] = (a == 0) ? beta : 0.0;
+      }
+      // ---- two-sided application to the diagonal block (lower triangle in registers) ----
+      {
+        double rowp = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) rowp += D[u] * vb[u];
+        rowp = swap32_sum(rowp, rowp);                               // sum_{c <= a} D[a][c] v_c
+        const double colp = sb2_colsum(tile, lane, D, vb, true);      // sum_{r > a} D[r][a] v_r
+        const double pa = tau * (rowp + colp);
+        const double pv = wave_sum((h == 0) ? pa * va : 0.0);
+        const double qa = pa - 0.5 * tau * pv * va;
+        if (h == 0) vecq[a] = qa;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        double qb[16];
+        sb2_bcast(vecq, lane, qb);
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int c = h * 16 + u;
+          if (c <= a) D[u] -= va * qb[u] + qa * vb[u];
+        }
+        sb2_store(AB, n, rf, rf, lane, D);
+      }
+      // ---- right application to the next block: Bn <- Bn (I - tau v v^T); it is the next task's bulge block ----
+      {
+        double y = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) y += Bn[u] * vb[u];
+        y = swap32_sum(y, y);
+        const double ty = tau * y;
+#pragma unroll
+        for (int u = 0; u < 16; u++) B[u] = Bn[u] - ty * vb[u];
+      }
+      // ---- publish ----
+      if (!delayed) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(&prog[s], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        published = k;
+      } else if (k >= 2) {
+        // the stores of task k-1 were issued a whole task ago
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(&prog[s], k - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        published = k - 1;
+      }
+    }
+    // the pending block (rows of the last R_{k}: at most one row is left below the last reflector)
+    {
+      const int rf = s + (k - 1) * SB + 1;
+      if (k >= 2 && rf <= n - 1) sb2_store(AB, n, rf, rf - SB, lane, B);
+    }
+    (void)published;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&prog[s], SB2_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// d, e of the tridiagonal matrix from the band storage after the last sweep
+__global__ void k_sb_finish(const SbBatch *__restrict__ bp) {
+  const SbBatch &b = *bp;
+  const int blk = blockIdx.y;
+  const int n = b.n[blk];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  b.d[blk][j] = b.AB[blk][(size_t)j * SB_LDB];
+  b.e[blk][j] = (j + 1 < n) ? b.AB[blk][(size_t)j * SB_LDB + 1] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct SbWork {
   DevBuf<double> Vx[SB_MAXB], tau1[SB_MAXB], T1[SB_MAXB], Xs[SB_MAXB], X[SB_MAXB], Zp[SB_MAXB], Lm[SB_MAXB], Rm[SB_MAXB], AB[SB_MAXB];
+  DevBuf<double> VV[SB_MAXB], tau2[SB_MAXB];
+  DevBuf<int> prog[SB_MAXB], status;
+  SbBatch hb{};  // the batch as last described (stage 2 and the back-transformation read it)
   DevBuf<SbBatch> desc;
   std::vector<SbBatch> h_desc;
   DevBuf<GemmTask> xtasks, utasks;
@@ -457,7 +682,14 @@ void sb_reduce_to_band(hfg_ctx *ctx, int nblk, const int *ns, double *const *A) 
     }
   upload_cached(w.xtasks, w.h_xtasks, xt, s);
   upload_cached(w.utasks, w.h_utasks, ut, s);
+  // diagnostics: HELFEM_SB_NPANEL stops after that many panels, HELFEM_SB_STEP inside the last one (1 panel QR only, 2 + X,
+  // 3 + W kernels); sb_fetch_debug() then returns the intermediate arrays
+  const int dbg_npan = getenv("HELFEM_SB_NPANEL") ? atoi(getenv("HELFEM_SB_NPANEL")) : -1;
+  const int dbg_step = getenv("HELFEM_SB_STEP") ? atoi(getenv("HELFEM_SB_STEP")) : 4;
+  w.hb = b;
   for (int p = 0; p < npan; p++) {
+    if (dbg_npan >= 0 && p >= dbg_npan) break;
+    const int last_step = (dbg_npan >= 0 && p == dbg_npan - 1) ? dbg_step : 4;
     const int j0 = p * SB, mmax = nmax - j0 - SB;
     {
       const int TTn = (mmax + SBP_NG - 1) / SBP_NG;
@@ -468,14 +700,59 @@ void sb_reduce_to_band(hfg_ctx *ctx, int nblk, const int *ns, double *const *A) 
       else if (TTn <= 80) hipLaunchKernelGGL(k_sb_panel<80>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
       else hipLaunchKernelGGL(k_sb_panel<SB_TMAX>, dim3(nblk), dim3(SBP_NT), 0, s, db, j0);
     }
+    if (last_step < 2) break;
     gemm_tasklist64_dev(ctx, w.xtasks.p + (size_t)p * SB_KS * nblk, SB_KS * nblk, mmax, SB);
+    if (last_step < 3) break;
     const int ntile = (mmax + SB_RT - 1) / SB_RT;
     hipLaunchKernelGGL(k_sb_w1, dim3(ntile, nblk), dim3(256), 0, s, db, j0);
     hipLaunchKernelGGL(k_sb_w2, dim3(ntile, nblk), dim3(256), 0, s, db, j0);
+    if (last_step < 4) break;
     gemm_tasklist_acc_dev(ctx, w.utasks.p + (size_t)p * nblk, nblk, mmax, mmax, mmax < 1024);
   }
   hipLaunchKernelGGL(k_sb_gather_band, dim3((nmax + 3) / 4, nblk), dim3(256), 0, s, db);
   HFG_HIP_CHECK(hipGetLastError());
+}
+
+/// stage 2 for the batch last reduced by sb_reduce_to_band: band storage -> tridiagonal (d, e device arrays of n each);
+/// G sweeps in flight per block.  Throws when a wave's bounded wait ran out (status word).
+void sb_chase(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, double *const *e, int G, int delayed) {
+  SbWork &w = sb_work(ctx);
+  hipStream_t s = ctx->stream;
+  SbBatch b = w.hb;
+  if (b.nblk != nblk) throw std::logic_error("sb_chase: no band reduction of this batch precedes");
+  int nmax = 0;
+  w.status.resize(4);
+  for (int i = 0; i < nblk; i++) {
+    const int n = ns[i];
+    nmax = std::max(nmax, n);
+    if (n / SB + 3 > SB2_KT) throw std::logic_error("sb_chase: too many tasks per sweep");
+    w.VV[i].resize((size_t)n * n);
+    w.tau2[i].resize((size_t)n * SB2_KT);
+    w.prog[i].resize(n + 2);
+    b.VV[i] = w.VV[i].p;
+    b.tau2[i] = w.tau2[i].p;
+    b.prog[i] = w.prog[i].p;
+    b.d[i] = d[i];
+    b.e[i] = e[i];
+    HFG_HIP_CHECK(hipMemsetAsync(w.prog[i].p, 0, sizeof(int) * (n + 2), s));
+    const int done = SB2_DONE;
+    HFG_HIP_CHECK(hipMemcpyAsync(w.prog[i].p, &done, sizeof(int), hipMemcpyHostToDevice, s));  // sweep -1
+    HFG_HIP_CHECK(hipMemsetAsync(w.VV[i].p, 0, sizeof(double) * (size_t)n * n, s));
+  }
+  b.status = w.status.p;
+  HFG_HIP_CHECK(hipMemsetAsync(w.status.p, 0, sizeof(int) * 4, s));
+  w.hb = b;
+  upload_cached(w.desc, w.h_desc, std::vector<SbBatch>(1, b), s);
+  hipLaunchKernelGGL(k_sb_chase, dim3(G, nblk), dim3(64), 0, s, w.desc.p, G, delayed);
+  hipLaunchKernelGGL(k_sb_finish, dim3((nmax + 255) / 256, nblk), dim3(256), 0, s, w.desc.p);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+int sb_chase_status(hfg_ctx *ctx) {
+  SbWork &w = sb_work(ctx);
+  int st = 0;
+  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HFG_HIP_CHECK(hipMemcpy(&st, w.status.p, sizeof(int), hipMemcpyDeviceToHost));
+  return st;
 }
 
 /// test access: band storage (n x SB_LDB, column j at [j * SB_LDB]) of the last reduction of this context, block blk
@@ -483,6 +760,14 @@ void sb_fetch_band(hfg_ctx *ctx, int blk, int n, double *hostAB) {
   SbWork &w = sb_work(ctx);
   HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   HFG_HIP_CHECK(hipMemcpy(hostAB, w.AB[blk].p, sizeof(double) * (size_t)n * SB_LDB, hipMemcpyDeviceToHost));
+}
+/// diagnostics: the work arrays of block 0 (which: 0 A, 1 Vx, 2 T1, 3 X, 4 Lm, 5 Rm), whole arrays
+void sb_fetch_debug(hfg_ctx *ctx, int which, int n, double *host, size_t count) {
+  SbWork &w = sb_work(ctx);
+  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const double *src = which == 0 ? w.hb.A[0] : which == 1 ? w.Vx[0].p : which == 2 ? w.T1[0].p : which == 3 ? w.X[0].p : which == 4 ? w.Lm[0].p : w.Rm[0].p;
+  (void)n;
+  HFG_HIP_CHECK(hipMemcpy(host, src, sizeof(double) * count, hipMemcpyDeviceToHost));
 }
 int sb_bandwidth() { return SB; }
 int sb_ldb() { return SB_LDB; }

@@ -1,5 +1,5 @@
 // Restricted closed-shell SCF driver for the diatomic program, written against an abstract
-// backend so that the same loop runs on the GPU entry points (product: src/diatomic_main.cpp)
+// backend so that the same loop runs on the GPU entry points (product: hip/scf_gpu.cpp, hfg_scf_*)
 // and on the CPU oracle (tests).  Mirrors the control flow, energy expression and printed lines
 // of the reference driver (/root/reference/src/diatomic/main.cpp:402-1009):
 //   S,T,Vnuc -> Sinvh -> guess (core Hamiltonian, --iguess 0) -> compute_tei ->

@@ -348,6 +348,9 @@ int hfg_chk_read_diatomic_basis(hfg_chk *chk, int lpad, hfg_basis **basis);
 /* Diagnostic: first stage of the two-stage tridiagonalisation alone (dense -> band, hip/sb.hip) on nrep copies of A;
  * AB (n x ldb, may be NULL) receives the band storage AB[j*ldb + d] = A_band[j+d][j] of the first copy. */
 int hfg_debug_band_reduce(hfg_ctx *ctx, int64_t n, const double *A, int nrep, double *AB, int *bandwidth, int *ldb, double *ms);
+int hfg_debug_two_stage(hfg_ctx *ctx, int64_t n, const double *A, int nrep, int G, int delayed, double *d, double *e, double *ms1, double *ms2);
+int hfg_debug_band_reduce_keep(hfg_ctx *ctx, int64_t n, const double *A, double *Aout);
+int hfg_debug_band_fetch(hfg_ctx *ctx, int which, int64_t n, double *out, int64_t count);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every kernel family is bracketed by hipEvents on the context's stream; the
@@ -365,7 +368,9 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
                    int verbose, double *out /* 12 */);
 
 /* Replays every launch of the named kernel of the last eigensolve back to back between two HIP events on the
- * context's stream (the roofline leg of bench.py).  Supported: "k_trdb_gemv". */
+ * context's stream (the roofline leg of bench.py).  Supported: "k_trdf" (the tridiagonalisation sweep of the default
+ * path; "k_trdb_gemv" is accepted as an alias and replays the same launches -- with HELFEM_TRD=twokernel those are the
+ * launches of k_trdb_gemv).  Any other name: status 1. */
 int hfg_measure_kernel(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches);
 
 /* pinned host memory for arma-owned buffers ("Armadillo matrices pinned and mirrored to HBM") */

@@ -334,7 +334,7 @@ def test_edge_case_bases(hf):
 
 
 def test_eig_gsym_sub_many_small_and_odd_blocks(hf):
-    """ragged symmetry blocks (sizes 1, 2, odd, > 8 blocks is rejected loudly by the batch) through eig_gsym_sub"""
+    """ragged symmetry blocks (sizes 1, 2, odd; more than 8 blocks go through the batch in groups of 8) through eig_gsym_sub"""
     import oracle_lib as orc
     rng = np.random.RandomState(3)
     sizes = [1, 2, 7, 33, 129, 5]

@@ -32,3 +32,21 @@ for n, nrep in ((200, 1), (333, 2), (1380, 1), (1470, 3), (1400, 3)):
     w0, w1 = np.linalg.eigvalsh(A), np.linalg.eigvalsh(B)
     print("n=%d x%d: stage 1 %.3f ms, max eigenvalue error %.2e (scale %.1f), bulge rows zero: %s" % (
         n, nrep, ms.value, np.max(np.abs(w0 - w1)), np.max(np.abs(w0)), bool(np.all(AB[:, b + 1:] == 0.0))), flush=True)
+
+# both stages: eigenvalues of the tridiagonal matrix against the input's
+import scipy.linalg as sl
+L.hfg_debug_two_stage.argtypes = [ctypes.c_void_p, ctypes.c_int64, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp]
+for n, nrep, G, delayed in ((200, 1, 4, 0), (333, 2, 8, 0), (1470, 3, 16, 0), (1470, 3, 16, 1), (1470, 3, 24, 0), (1400, 3, 12, 0)):
+    rng = np.random.RandomState(n)
+    A = rng.standard_normal((n, n))
+    A = np.asfortranarray(A + A.T)
+    d, e = np.zeros(n), np.zeros(n)
+    m1, m2 = ctypes.c_double(), ctypes.c_double()
+    rc = L.hfg_debug_two_stage(ctx.h, n, A.ctypes.data_as(dp), nrep, G, delayed, d.ctypes.data_as(dp), e.ctypes.data_as(dp), ctypes.byref(m1), ctypes.byref(m2))
+    if rc:
+        print("FAILED", n, L.hfg_last_error(), flush=True)
+        break
+    w0 = np.linalg.eigvalsh(A)
+    w1 = sl.eigvalsh_tridiagonal(d, e[:-1])
+    print("n=%d x%d G=%d delayed=%d: stage 1 %.3f ms, stage 2 %.3f ms, max eigenvalue error %.2e (scale %.1f)" % (
+        n, nrep, G, delayed, m1.value, m2.value, np.max(np.abs(w0 - w1)), np.max(np.abs(w0))), flush=True)
