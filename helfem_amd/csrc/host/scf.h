@@ -1,11 +1,12 @@
-// Restricted closed-shell SCF driver for the diatomic program, written against an abstract
-// backend so that the same loop runs on the GPU entry points (product: hip/scf_gpu.cpp, hfg_scf_*)
-// and on the CPU oracle (tests).  Mirrors the control flow, energy expression and printed lines
+// SCF driver loops (diatomic and atomic, restricted / unrestricted / restricted open shell) written against an abstract
+// backend whose compute methods are the GPU entry points (hip/scf_gpu.cpp, hfg_scf_*): the host-pointer variant of the
+// product's SCF, kept as the checker of the device-resident loop (hip/scf_device.hip).  The CPU oracle has its OWN
+// driver (oracle/oracle_scf.cpp) and does not compile this file.  Mirrors the control flow, energy expression and printed lines
 // of the reference driver (/root/reference/src/diatomic/main.cpp:402-1009):
 //   S,T,Vnuc -> Sinvh -> guess (core Hamiltonian, --iguess 0) -> compute_tei ->
 //   loop { P = C_occ C_occ^T; J; K; XC; F; E; DIIS; eig_gsym_sub } -> energy table.
-// External fields, finite nuclei, checkpoints and the SAP/GSZ/TF
-// guesses are outside the hot-path scope and are rejected loudly.
+// External fields, finite nuclei and the SAP guess are outside the hot-path scope and are
+// rejected loudly; checkpoints (host/checkpoint.cpp) and the GSZ / Thomas-Fermi guesses are supported.
 #pragma once
 #include "atomic_basis.h"
 #include "diatomic_basis.h"
