@@ -45,6 +45,36 @@ def build_basis(hf, w):
     return b, bval, lval, mval, ldft, mdft
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a GPU box
+    hands a 256-core host's affinity to a job that owns 16 CPUs' worth of time: 256 spinning BLAS threads on that are
+    slower than one)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, int(q / float(fh.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 64))
+
+
+def _progress(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(w, bval, lval, mval, ldft, mdft, P, F, Sinvh, blocks):
     """The CPU path timed on this host's cores, on a bounded sample of the same workload, extrapolated to one SCF
     iteration (kind "port+lapack"):
@@ -58,10 +88,7 @@ def cpu_baseline(w, bval, lval, mval, ldft, mdft, P, F, Sinvh, blocks):
     import threading
     import torch
     import oracle_lib as orc
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = usable_cores()
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -73,16 +100,18 @@ def cpu_baseline(w, bval, lval, mval, ldft, mdft, P, F, Sinvh, blocks):
         pass
     torch.set_num_threads(cores)
     Rh = 0.5 * w["Rbond"]
-    os.environ["HELFEM_NUM_THREADS"] = str(min(cores, 64))
+    os.environ["HELFEM_NUM_THREADS"] = str(cores)
+    _progress("cpu_baseline on %d cores (%s): tables" % (cores, cpu_model))
     ob = orc.OracleBasis(w["Z1"], w["Z2"], Rh, w["nnodes"], 5 * w["nnodes"], bval, lval, mval, 10)
     ob.compute_tei(False)
     t0 = time.time()
     ob.coulomb(P)
     tJ = time.time() - t0
+    _progress("cpu_baseline: Coulomb %.2f s; XC sample" % tJ)
     # XC: one radial point per thread, points spread over the elements
     NQ = w["nelem"] * 5 * w["nnodes"]
     nth = max(1, min(cores, 32, NQ))
-    npts = max(8, nth) if NQ >= 8 else NQ
+    npts = nth if NQ >= nth else NQ
     pts = sorted(set(int(round((k + 0.5) * NQ / npts)) % NQ for k in range(npts)))
     work = list(pts)
     lock = threading.Lock()
@@ -103,6 +132,7 @@ def cpu_baseline(w, bval, lval, mval, ldft, mdft, P, F, Sinvh, blocks):
         t.join()
     tXC_sample = time.time() - t0
     tXC = tXC_sample * NQ / float(len(pts))
+    _progress("cpu_baseline: XC sample %.2f s for %d points; eigensolve" % (tXC_sample, len(pts)))
     # eigensolve: every block, LAPACK on all cores
     Ft = torch.from_numpy(np.ascontiguousarray(F))
     Xt = torch.from_numpy(np.ascontiguousarray(Sinvh))
@@ -118,6 +148,7 @@ def cpu_baseline(w, bval, lval, mval, ldft, mdft, P, F, Sinvh, blocks):
         Cb = Xb @ Zb
         del Cb, Eb
     tE = time.time() - t0
+    _progress("cpu_baseline: eigensolve %.2f s" % tE)
     total = tJ + tXC + tE
     return dict(value=total * 1e3, unit="ms", cores=cores, kind="port+lapack", cpu=cpu_model,
                 parts_ms=dict(coulomb=tJ * 1e3, xc=tXC * 1e3, eig=tE * 1e3),
@@ -231,9 +262,12 @@ def main():
         # (tools/gpu_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as the gfx950 guide
         # prescribes; tools/pmc_traffic.py).  The counters cannot be collected from inside this process.
         traffic = None
+        traffic_file = None
         try:
             if args.workload == "n2_pbe_nbf4230" and world == 1:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                import glob
+                traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]
+                with open(traffic_file) as fh:
                     for kname, rec in json.load(fh).items():  # "void hfg::k_trdf<1024>" (template) or "hfg::k_trdb_gemv"
                         if ("hfg::" + TRD_KERNEL) in kname:
                             traffic = rec.get("traffic_bytes_per_launch")
@@ -250,11 +284,14 @@ def main():
                                    "eig_gsym_sub + density per step" % (
                                        w["Z1"], w["Z2"], w["Rbond"], w["nelem"], w["nnodes"], 5 * w["nnodes"],
                                        str(w["lmmax"]).replace(" ", ""), N, basis.Nang(), basis.Nrad(), ldft, mdft, sizes),
-                       "name": args.workload, "parallelism": "shard%d" % world},
+                       "name": args.workload, "parallelism": "shard%d" % world,
+                       "timed_path": "device-resident step (hfg_*_dev entry points on HBM buffers: the loop body of hfg_scf_run, "
+                                     "which the diatomic/atomic executables and helfem::gpu::run_scf call); the host-pointer "
+                                     "entry points (hfg_coulomb, hfg_eig_gsym_sub, ...) add ~12 ms of PCIe per call"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "traffic_source": ("profiles/r01_pmc_traffic.json (committed rocprofv3 --pmc passes of this command, not "
-                                            "measured in this run)") if traffic is not None else None,
+                         "traffic_source": ("profiles/%s (committed rocprofv3 --pmc passes of this command, not "
+                                            "measured in this run)" % os.path.basename(traffic_file)) if traffic is not None else None,
                          "kernel": "hfg::" + TRD_KERNEL, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_ms * 1e3, "launches_per_step": launches_per_step,
                          "note": "latency-bound: one dependent launch per Householder column (see DESIGN.md 3.4)"},

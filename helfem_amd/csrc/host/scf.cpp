@@ -1,4 +1,6 @@
 #include "scf.h"
+#include <cfloat>
+#include <climits>
 #include "diis.h"
 #include <chrono>
 #include <cmath>
@@ -94,6 +96,129 @@ struct Problem {
   // --maverage (atomic): groups of equally sized index lists whose diagonal blocks of F are averaged
   std::vector<std::vector<std::vector<size_t> > > avg_idx;
 };
+
+// ---- forced occupations -----------------------------------------------------------------------------------------
+static void check_occupation_sums(const OccupationPlan &pl, int nela, int nelb) {
+  int sa = 0, sb = 0;
+  for (int v : pl.na) sa += v;
+  for (int v : pl.nb) sb += v;
+  // diatomic/main.cpp:369-380 (the beta message says "alpha" in the reference too)
+  if (sa != nela)
+    throw std::logic_error("Specified alpha occupations don't match wanted spin state.\nOccupying " + std::to_string(sa) +
+                           " orbitals but should have " + std::to_string(nela) + " orbitals.\n");
+  if (sb != nelb)
+    throw std::logic_error("Specified alpha occupations don't match wanted spin state.\nOccupying " + std::to_string(sb) +
+                           " orbitals but should have " + std::to_string(nelb) + " orbitals.\n");
+}
+
+OccupationPlan occupation_plan(const Options &opt, const diatomic::TwoDBasis &basis, int nela, int nelb) {
+  OccupationPlan pl;
+  if (!opt.readocc) return pl;
+  pl.until = opt.readocc < 0 ? INT_MAX : opt.readocc;
+  if (opt.occs.empty() || opt.occs[0].size() < 3) throw std::logic_error("Must have at least three columns in occupation data.\n");
+  const size_t ncol = opt.occs[0].size();
+  const bool hetero = basis.Z1 != basis.Z2;
+  if (hetero && ncol != 3) throw std::logic_error("Heteronuclear molecule orbital occupations must have three columns.\n");
+  if (!hetero && ncol != 3 && ncol != 4) throw std::logic_error("Homonuclear molecule orbital occupations must have three or four columns.\n");
+  if (ncol == 4 && opt.symmetry != 2) throw std::logic_error("For use of homonuclear orbital occupations, must turn on use of full symmetry.\n");
+  for (size_t i = 0; i < opt.occs.size(); i++) {
+    const std::vector<int> &row = opt.occs[i];
+    if (row.size() != ncol) throw std::logic_error("Ragged occupation data.\n");
+    pl.na.push_back(row[0]);
+    pl.nb.push_back(row[1]);
+    if (ncol == 3)
+      pl.sym.push_back(basis.m_indices(row[2]));
+    else {
+      if (row[3] != 1 && row[3] != -1)
+        throw std::logic_error("Error on line " + std::to_string(i + 1) + " of orbital occupations: parity must be +1 or -1\n");
+      pl.sym.push_back(basis.m_indices(row[2], row[3] == -1));
+    }
+  }
+  check_occupation_sums(pl, nela, nelb);
+  return pl;
+}
+
+OccupationPlan occupation_plan(const Options &opt, const atomic::TwoDBasis &basis, int nela, int nelb) {
+  OccupationPlan pl;
+  if (!opt.readocc) return pl;
+  pl.until = opt.readocc < 0 ? INT_MAX : opt.readocc;
+  const size_t ncol = opt.occs.empty() ? 0 : opt.occs[0].size();
+  if (opt.symmetry == 2 && ncol != 4) throw std::logic_error("Must have four columns in occupation data to use full atomic symmetry.\n");
+  if (opt.symmetry == 1 && ncol != 3) throw std::logic_error("Must have three columns in occupation data to use axial symmetry.\n");
+  if (opt.symmetry != 1 && opt.symmetry != 2) throw std::logic_error("Not implemented!\n");
+  for (const std::vector<int> &row : opt.occs) {
+    if (row.size() != ncol) throw std::logic_error("Ragged occupation data.\n");
+    pl.na.push_back(row[0]);
+    pl.nb.push_back(row[1]);
+    pl.sym.push_back(opt.symmetry == 1 ? basis.m_indices(row[2]) : basis.lm_indices(row[2], row[3]));
+  }
+  check_occupation_sums(pl, nela, nelb);
+  return pl;
+}
+
+std::vector<size_t> occupation_order(const Vec &E, const std::vector<std::vector<double> > &w, const std::vector<int> &nocc) {
+  if (nocc.size() != w.size()) throw std::logic_error("nocc vector and symmetry indices don't match!\n");
+  const size_t norb = E.size();
+  std::vector<char> occupied(norb, 0);
+  std::vector<size_t> occ;
+  for (size_t isym = 0; isym < w.size(); isym++) {
+    if (!nocc[isym]) continue;
+    int taken = 0;
+    for (size_t o = 0; o < norb && taken < nocc[isym]; o++)
+      if (w[isym][o] > 10 * DBL_EPSILON) {
+        if (occupied[o]) throw std::logic_error("Duplicates in occupied orbital list!\n");
+        occupied[o] = 1;
+        occ.push_back(o);
+        taken++;
+      }
+    if (taken < nocc[isym]) throw std::logic_error("Not enough orbitals of the requested symmetry to occupy!\n");
+  }
+  std::vector<size_t> virt;
+  for (size_t o = 0; o < norb; o++)
+    if (!occupied[o]) virt.push_back(o);
+  auto by_energy = [&E](size_t a, size_t b) { return E[a] < E[b]; };
+  std::stable_sort(occ.begin(), occ.end(), by_energy);
+  std::stable_sort(virt.begin(), virt.end(), by_energy);
+  occ.insert(occ.end(), virt.begin(), virt.end());
+  return occ;
+}
+
+void enforce_occupations(Mat &C, Vec &E, const Mat &S, const std::vector<int> &nocc, const std::vector<std::vector<size_t> > &sym) {
+  // the symmetries must not share basis functions (scf_helpers.cpp:35-50)
+  {
+    std::vector<char> seen(S.n_rows, 0);
+    for (const auto &idx : sym)
+      for (size_t i : idx) {
+        if (seen[i]) throw std::logic_error("Duplicate basis functions in symmetry list!\n");
+        seen[i] = 1;
+      }
+  }
+  const size_t norb = C.n_cols;
+  std::vector<std::vector<double> > w(sym.size(), std::vector<double>(norb, 0.0));
+  for (size_t isym = 0; isym < sym.size(); isym++) {
+    if (!nocc[isym]) continue;
+    const std::vector<size_t> &idx = sym[isym];
+    std::vector<double> sc(idx.size());
+    for (size_t o = 0; o < norb; o++) {
+      double nrm = 0.0;
+      for (size_t a = 0; a < idx.size(); a++) {
+        double t = 0.0;
+        for (size_t b = 0; b < idx.size(); b++) t += S(idx[a], idx[b]) * C(idx[b], o);
+        nrm += C(idx[a], o) * t;
+      }
+      w[isym][o] = nrm;
+    }
+  }
+  const std::vector<size_t> order = occupation_order(E, w, nocc);
+  Mat Cn(C.n_rows, norb);
+  Vec En(norb);
+  for (size_t o = 0; o < norb; o++) {
+    En[o] = E[order[o]];
+    for (size_t i = 0; i < C.n_rows; i++) Cn(i, o) = C(i, order[o]);
+  }
+  C = Cn;
+  E = En;
+}
 
 // scf::fock_symmetry_average (src/general/scf_helpers.cpp:263-284)
 Mat fock_symmetry_average(const Mat &Fin, const std::vector<std::vector<std::vector<size_t> > > &sym_idx) {

@@ -80,6 +80,12 @@ struct Options {
   double dampfock = 1.0, dampthr = 0.1;
   int iguess = 0;  // --iguess: 0 core Hamiltonian, 1 GSZ (needs gsz_d), 3 Thomas-Fermi; 2 (SAP) is not available
   double gsz_d1 = 0.0, gsz_d2 = 0.0;  // screening lengths of the GSZ guess for the two centres (atomic: gsz_d1)
+  // --readocc (diatomic/main.cpp:215-222, 338-382; atomic/main.cpp:209-221, 317-345): rows of occs.dat = occupied alpha
+  // orbitals, occupied beta orbitals, then m (diatomic, atomic --symmetry 1), m and parity +-1 (homonuclear diatomic with
+  // --symmetry 2) or l and m (atomic --symmetry 2); enforced after the guess and after the eigensolves of the iterations
+  // i < readocc (negative: always)
+  int readocc = 0;
+  std::vector<std::vector<int> > occs;
   bool keep_matrices = false;  // fill Result::mats with what the reference's drivers write to their checkpoint
   bool verbose = true;
 };
@@ -112,6 +118,24 @@ struct AtomicOptions {
 /// charge and multiplicity from explicit occupations; Ztot = total nuclear charge.  Throws std::runtime_error like the
 /// reference.
 void parse_nela_nelb(int &nela, int &nelb, int &Q, int &M, int Ztot);
+
+/// forced occupations in the form scf::enforce_occupations takes them (scf_helpers.cpp:31): per row of occs.dat the number
+/// of occupied alpha / beta orbitals and the basis-function indices of the symmetry
+struct OccupationPlan {
+  int until = 0;  // enforce while iteration < until (INT_MAX: always; 0: never)
+  std::vector<int> na, nb;
+  std::vector<std::vector<size_t> > sym;
+  bool active(int iteration) const { return iteration < until; }
+};
+/// the drivers' parsing and checks of occs.dat, with their error texts; nela / nelb: the wanted spin state
+OccupationPlan occupation_plan(const Options &opt, const diatomic::TwoDBasis &basis, int nela, int nelb);
+OccupationPlan occupation_plan(const Options &opt, const atomic::TwoDBasis &basis, int nela, int nelb);
+/// the orbital order scf::enforce_occupations produces (scf_helpers.cpp:52-128): per symmetry the first nocc orbitals
+/// with weight in that symmetry (w[isym][orbital] = diag(Csub^T S_sub Csub), counted when > 10 DBL_EPSILON) are occupied;
+/// occupied orbitals first, each group by ascending energy.  Throws like the reference on duplicates.
+std::vector<size_t> occupation_order(const Vec &E, const std::vector<std::vector<double> > &w, const std::vector<int> &nocc);
+/// C, E reordered accordingly (host matrices; the device loop gathers on the device)
+void enforce_occupations(Mat &C, Vec &E, const Mat &S, const std::vector<int> &nocc, const std::vector<std::vector<size_t> > &sym);
 
 std::vector<std::vector<std::vector<size_t> > > atomic_average_groups(const atomic::TwoDBasis &basis);
 Result run_diatomic(const Options &opt, Backend &be);
