@@ -552,7 +552,7 @@ def scf_set_iguess(iguess):
 
 
 def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0, igrid=4, zexp=1.0, lpad=10, ldft=0,
-                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1):
+                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1, occs=None, readocc=-1):
     """Restricted closed-shell (M=1) or unrestricted (M=2S+1>1) diatomic SCF with every per-iteration step on the GPU
     (the loop of src/diatomic/main.cpp:780-995; flags as in main.cpp:89-133)."""
     ctx = ctx or default_context()
@@ -563,8 +563,12 @@ def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_double_p]
     out = np.zeros(12)
     lm = (ctypes.c_int * len(lmmax))(*lmmax)
-    _check(L.hfg_scf_diatomic(ctx.h, Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
-                              method.encode(), ldft, mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
+    scf_set_occupations(occs, readocc)
+    try:
+        _check(L.hfg_scf_diatomic(ctx.h, Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
+                                  method.encode(), ldft, mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
+    finally:
+        scf_set_occupations(None)
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])
@@ -573,8 +577,20 @@ def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0
     return r
 
 
+def scf_set_occupations(occs=None, readocc=-1):
+    """--readocc for the following scf_diatomic / scf_atomic calls of this thread: occs = rows of occs.dat (nalpha, nbeta, m
+    [, parity | l, m]); None switches it off"""
+    L = lib()
+    L.hfg_scf_set_occupations.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    if occs is None:
+        _check(L.hfg_scf_set_occupations(0, 0, 0, None))
+        return
+    a = np.ascontiguousarray(np.asarray(occs, dtype=np.int32))
+    _check(L.hfg_scf_set_occupations(int(readocc), a.shape[0], a.shape[1], a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+
+
 def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
-               symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1, maverage=False):
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0, ctx=None, M=1, maverage=False, occs=None, readocc=-1):
     """Restricted closed-shell (M=1), unrestricted (M=2S+1>1) or restricted open-shell (M<0) atomic SCF with every per-iteration step on the GPU
     (the loop of src/atomic/main.cpp:760-1005; flags as in main.cpp:66-100)."""
     ctx = ctx or default_context()
@@ -583,8 +599,12 @@ def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, ig
                                 ctypes.c_double, ctypes.c_char_p] + [ctypes.c_int] * 6 + [ctypes.c_double,
                                 ctypes.c_int, c_double_p]
     out = np.zeros(12)
-    _check(L.hfg_scf_atomic(ctx.h, Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft,
-                            mdft, symmetry, M, 1 if maverage else 0, maxit, convthr, verbose, _p(out)))
+    scf_set_occupations(occs, readocc)
+    try:
+        _check(L.hfg_scf_atomic(ctx.h, Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft,
+                                mdft, symmetry, M, 1 if maverage else 0, maxit, convthr, verbose, _p(out)))
+    finally:
+        scf_set_occupations(None)
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])

@@ -110,6 +110,14 @@ int main(int argc, char **argv) {
     o.diisthr = parser.real("diisthr");
     o.diisorder = parser.integer("diisorder");
     o.readocc = parser.integer("readocc");
+    static std::vector<int> occ_table;  // occs.dat of the working directory (main.cpp: occs.load("occs.dat", arma::raw_ascii))
+    if (o.readocc) {
+      int rows = 0, cols = 0;
+      if (!cli::read_int_table("occs.dat", occ_table, rows, cols)) fail("Could not read occupation data from occs.dat\n");
+      o.occs = occ_table.data();
+      o.occ_rows = rows;
+      o.occ_cols = cols;
+    }
     o.perturb = parser.real("perturb");
     o.iguess = parser.integer("iguess");
     snprintf(o.load, sizeof(o.load), "%s", parser.str("load").c_str());

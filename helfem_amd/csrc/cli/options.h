@@ -12,6 +12,33 @@
 
 namespace cli {
 
+/// arma::imat::load(raw_ascii): whitespace-separated integers, one row per line, equal row lengths
+inline bool read_int_table(const char *path, std::vector<int> &tab, int &rows, int &cols) {
+  FILE *f = fopen(path, "r");
+  if (!f) return false;
+  tab.clear();
+  rows = cols = 0;
+  char line[4096];
+  bool ok = true;
+  while (fgets(line, sizeof(line), f)) {
+    int n = 0;
+    char *p = line, *end = nullptr;
+    while (true) {
+      const long v = strtol(p, &end, 10);
+      if (end == p) break;
+      tab.push_back((int)v);
+      n++;
+      p = end;
+    }
+    if (!n) continue;  // blank line
+    if (cols && n != cols) ok = false;
+    cols = n;
+    rows++;
+  }
+  fclose(f);
+  return ok && rows > 0;
+}
+
 struct Option {
   std::string name, desc, value;
   bool required = false, given = false, is_bool = false;

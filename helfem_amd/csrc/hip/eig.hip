@@ -23,6 +23,7 @@
 namespace hfg {
 
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
 void gemm_mirror_lower_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxN);
@@ -1101,14 +1102,18 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
         hipLaunchKernelGGL(k_gather_block, dim3((n + 255) / 256, n), dim3(256), 0, s, dF, dS, N, drows + blk_ptr[ib],
                            dcols + blk_ptr[ib], n, Fb.p + (size_t)k * nmax * nmax, Xall.p + (size_t)k * nmax * nmax);
       }
-      gemm_tasklist_dev(ctx, w.gtasks.p, nb, nm, nm);
+      static const bool rect = getenv("HELFEM_GEMM_RECT") && atoi(getenv("HELFEM_GEMM_RECT"));
+      if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p, nb, nm, nm);
+      else gemm_tasklist_dev(ctx, w.gtasks.p, nb, nm, nm);
       gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);      // lower tiles of X^T (F X) only (GemmTask::sym)
       gemm_mirror_lower_dev(ctx, w.gtasks.p + nb, nb, nm);        // the tridiagonalisation sweeps the full square
     }
     eig_sym_batch(ctx, w, nb, ns.data());
     {
       ProfScope ps(ctx, "eig_backtransform");
-      gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+      static const bool rect = getenv("HELFEM_GEMM_RECT") && atoi(getenv("HELFEM_GEMM_RECT"));
+      if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+      else gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
       for (int k = 0; k < nb; k++) {
         int ib = mine[c0 + k];
         int n = ns[k];

@@ -409,6 +409,16 @@ void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int m
 }
 
 /// launches the task list with 128 x 128 tiles; max_mn = largest (M, N) over the tasks
+/// the same with 128 x 64 tiles (no symmetric tasks): twice as many, half as large workgroups -- for batches whose
+/// 128 x 128 tiles do not divide evenly over the CUs
+void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
+  if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  const int tiles = ((maxM + 127) / 128) * ((maxN + 63) / 64);
+  hipLaunchKernelGGL((k_dgemm_tasklist<128, 64>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
   if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
   ProfScope ps(ctx, "gemm");

@@ -5,6 +5,7 @@
 // driver (host/scf.cpp with GPUBackend, scf_gpu.cpp) computes the same numbers and is kept as the checker of
 // this one (HELFEM_SCF=host).
 #include "tables.h"
+#include "wave.h"
 #include "../host/dftfuncs.h"
 #include "../host/diis.h"
 #include "../host/scf.h"
@@ -118,6 +119,30 @@ double wall() {
 
 constexpr int RED_BLOCKS = 512;
 
+// forced occupations (scf::enforce_occupations, scf_helpers.cpp:61-75): weight of every orbital in one symmetry,
+// w[o] = sum_{i in sym} C[i][o] (S C)[i][o]  -- S has no elements between a symmetry and the rest, so the rows of S C
+// restricted to the symmetry are S_sub C_sub.  One wave per orbital.
+__global__ __launch_bounds__(256) void k_sym_weight(const double *__restrict__ C, const double *__restrict__ SC, int n, const int *__restrict__ rows,
+                                                    int nrows, double *__restrict__ w) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= n) return;
+  double acc = 0.0;
+  for (int k = lane; k < nrows; k += 64) {
+    const size_t i = (size_t)o * n + rows[k];
+    acc += C[i] * SC[i];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) w[o] = acc;
+}
+// Cn[:, o] = C[:, order[o]], En[o] = E[order[o]]
+__global__ __launch_bounds__(256) void k_gather_columns(const double *__restrict__ C, const double *__restrict__ E, int n, const int *__restrict__ order,
+                                                        double *__restrict__ Cn, double *__restrict__ En) {
+  const int o = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int src = order[o];
+  if (i < n) Cn[(size_t)o * n + i] = C[(size_t)src * n + i];
+  if (i == 0) En[o] = E[src];
+}
+
 struct DevSCF {
   hfg_ctx *ctx;
   hipStream_t s;
@@ -183,6 +208,9 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   const bool restr = restr_req && !rohf;
   res.nela = nela;
   res.nelb = nelb;
+  helfem::scf::Options oocc = opt;
+  oocc.symmetry = symm;
+  const helfem::scf::OccupationPlan focc = hb->kind ? helfem::scf::occupation_plan(oocc, hb->ab, nela, nelb) : helfem::scf::occupation_plan(oocc, hb->b, nela, nelb);
 
   DevSCF d(ctx);
   hipStream_t s = d.s;
@@ -295,7 +323,9 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   // guess (main.cpp:650-712): core Hamiltonian, or T + the model potential of the screened nuclei by quadrature on the
   // device (diatomic) / radial integrals (atomic); the quadrature needs the tables, so they come first in that case
   const double *Hg = d.H0.p;
-  if (opt.iguess != 0) {
+  if (opt.have_guess) {
+    // --load: orbitals of a previous run (checked and re-orthonormalised on the host), nothing to evaluate
+  } else if (opt.iguess != 0) {
     prepare_tables();
     if (verbose) printf("Guess orbitals from %s nucleus\n", opt.iguess == 3 ? "Thomas-Fermi" : "screened");
     if (opt.iguess != 3) throw std::logic_error("Unsupported guess\n");
@@ -311,12 +341,81 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     Hg = d.T1.p;
   } else if (verbose)
     printf("Guess orbitals from core Hamiltonian\n");
-  eig_gsym_sub_dev(ctx, n, Hg, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), d.Ea.p, d.Ca.p);
-  if (!restr) {
-    HFG_HIP_CHECK(hipMemcpyAsync(d.Cb.p, d.Ca.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
-    HFG_HIP_CHECK(hipMemcpyAsync(d.Eb.p, d.Ea.p, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
+  // forced occupations on the device: S C by one product, the symmetry weights of all orbitals by one small kernel per
+  // occupied symmetry, the order on the host from the weights and the energies (the reference's rule), one gather
+  DevBuf<int> occ_rows, occ_order;
+  DevBuf<double> occ_w;
+  std::vector<int> occ_rowptr(1, 0);
+  if (focc.until) {
+    std::vector<char> seen(N, 0);
+    std::vector<int> rows;
+    for (const auto &ix : focc.sym) {
+      for (size_t i : ix) {
+        if (seen[i]) throw std::logic_error("Duplicate basis functions in symmetry list!\n");
+        seen[i] = 1;
+        rows.push_back((int)i);
+      }
+      occ_rowptr.push_back((int)rows.size());
+    }
+    occ_rows.resize(rows.size() + 1);
+    HFG_HIP_CHECK(hipMemcpyAsync(occ_rows.p, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));
+    occ_order.resize(N);
+    occ_w.resize(focc.sym.size() * N);
   }
-  if (opt.iguess == 0) prepare_tables();
+  auto enforce_occupations = [&](double *C, double *E, const std::vector<int> &nocc) {
+    gemm_dev(ctx, false, false, n, n, n, 1.0, d.S.p, n, C, n, 0.0, d.T2.p, n);  // S C
+    HFG_HIP_CHECK(hipMemsetAsync(occ_w.p, 0, sizeof(double) * focc.sym.size() * N, s));
+    for (size_t isym = 0; isym < focc.sym.size(); isym++)
+      if (nocc[isym])
+        hipLaunchKernelGGL(k_sym_weight, dim3((n + 3) / 4), dim3(256), 0, s, C, d.T2.p, n, occ_rows.p + occ_rowptr[isym],
+                           occ_rowptr[isym + 1] - occ_rowptr[isym], occ_w.p + isym * N);
+    std::vector<double> hw(focc.sym.size() * N);
+    helfem::Vec hE(N);
+    HFG_HIP_CHECK(hipMemcpyAsync(hw.data(), occ_w.p, sizeof(double) * hw.size(), hipMemcpyDeviceToHost, s));
+    HFG_HIP_CHECK(hipMemcpyAsync(hE.data(), E, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<std::vector<double> > w(focc.sym.size());
+    for (size_t isym = 0; isym < focc.sym.size(); isym++) w[isym].assign(hw.begin() + isym * N, hw.begin() + (isym + 1) * N);
+    const std::vector<size_t> order = helfem::scf::occupation_order(hE, w, nocc);
+    std::vector<int> io(order.begin(), order.end());
+    HFG_HIP_CHECK(hipMemcpyAsync(occ_order.p, io.data(), sizeof(int) * N, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_columns, dim3((n + 255) / 256, n), dim3(256), 0, s, C, E, n, occ_order.p, d.T2.p, d.T1.p);
+    HFG_HIP_CHECK(hipMemcpyAsync(C, d.T2.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+    HFG_HIP_CHECK(hipMemcpyAsync(E, d.T1.p, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));  // io is a local
+  };
+  if (opt.have_guess) {
+    if (verbose) printf("Guess orbitals from checkpoint\nGuess orbitals from previous calculation\n");
+    Mat Sh0 = hb->kind ? hb->ab.overlap() : hb->b.overlap();
+    Mat gCa, gCb;
+    helfem::Vec gEa, gEb;
+    helfem::scf::guess_from_checkpoint(opt, Sh0, (size_t)nela, (size_t)nelb, gCa, gCb, gEa, gEb);
+    auto put = [&](DevBuf<double> &dC, DevBuf<double> &dE, const Mat &C, const helfem::Vec &E) {
+      // the checkpoint may hold fewer columns than basis functions (Cholesky-reduced runs): the rest stays zero
+      Mat Cfull(N, N);
+      for (size_t j = 0; j < std::min(C.n_cols, N); j++)
+        for (size_t i = 0; i < N; i++) Cfull(i, j) = C(i, j);
+      helfem::Vec Efull(N, 0.0);
+      for (size_t j = 0; j < std::min(E.size(), N); j++) Efull[j] = E[j];
+      HFG_HIP_CHECK(hipMemcpyAsync(dC.p, Cfull.memptr(), sizeof(double) * NN, hipMemcpyHostToDevice, s));
+      HFG_HIP_CHECK(hipMemcpyAsync(dE.p, Efull.data(), sizeof(double) * N, hipMemcpyHostToDevice, s));
+      HFG_HIP_CHECK(hipStreamSynchronize(s));
+    };
+    put(d.Ca, d.Ea, gCa, gEa);
+    if (!restr) put(d.Cb, d.Eb, gCb, gEb);
+  } else {
+    eig_gsym_sub_dev(ctx, n, Hg, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), d.Ea.p, d.Ca.p);
+    if (!restr) {
+      HFG_HIP_CHECK(hipMemcpyAsync(d.Cb.p, d.Ca.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
+      HFG_HIP_CHECK(hipMemcpyAsync(d.Eb.p, d.Ea.p, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  if (focc.until && !opt.have_guess) {  // main.cpp:716-722
+    enforce_occupations(d.Ca.p, d.Ea.p, focc.na);
+    if (!restr) enforce_occupations(d.Cb.p, d.Eb.p, focc.nb);
+  }
+  if (opt.iguess == 0 || opt.have_guess) prepare_tables();
 
   // ADIIS + CDIIS weights of the reference (diis.cpp:214-290) on the host from inner products of the stored matrices;
   // the restricted driver counts its one spin twice, as the reference does by passing Fa = Fb, Pa = Pb to uDIIS
@@ -506,6 +605,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       }
       eig_gsym_sub_dev(ctx, n, Fd, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), sp ? d.Eb.p : d.Ea.p,
                        sp ? d.Cb.p : d.Ca.p);
+      if (focc.active(it)) enforce_occupations(sp ? d.Cb.p : d.Ca.p, sp ? d.Eb.p : d.Ea.p, sp ? focc.nb : focc.na);  // main.cpp:942-958
     }
     if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
     res.tdiag = wall() - t0;

@@ -114,6 +114,7 @@ struct GPUBackend : public helfem::scf::Backend {
 }  // namespace
 
 namespace hfg {
+void set_xc_params(hfg_ctx *ctx, int x_func, const double *x_pars, int nx, int c_func, const double *c_pars, int nc);  // fock.hip
 helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::scf::Options &opt, int nel, double Enucr,
                                     int symm, const std::vector<std::vector<size_t> > &dsym, int ldft, int mdft,
                                     const std::vector<std::vector<std::vector<size_t> > > &avg_idx =
@@ -121,6 +122,8 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
 }
 
 namespace {
+thread_local int g_readocc = 0;  // --readocc of the following hfg_scf_diatomic / hfg_scf_atomic calls (hfg_scf_set_occupations)
+thread_local std::vector<std::vector<int> > g_occs;
 thread_local int g_iguess = 0;  // --iguess of the following hfg_scf_* calls of this thread (hfg_scf_set_iguess)
 
 bool host_driver() {
@@ -208,6 +211,12 @@ helfem::scf::Result run_atomic_device(hfg_ctx *ctx, const helfem::scf::AtomicOpt
 }  // namespace
 
 extern "C" {
+int hfg_scf_set_occupations(int readocc, int nrows, int ncols, const int *rows) {
+  g_readocc = readocc;
+  g_occs.clear();
+  for (int r = 0; r < nrows; r++) g_occs.push_back(std::vector<int>(rows + (size_t)r * ncols, rows + (size_t)(r + 1) * ncols));
+  return 0;
+}
 int hfg_scf_set_iguess(int iguess) {
   if (iguess != 0 && iguess != 3) {
     hfg::set_error(iguess == 2 ? "Unsupported guess (SAP needs the reference's tabulated potentials)\n"
@@ -242,6 +251,8 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
     o.method = method;
     helfem::parse_xc_func(o.x_func, o.c_func, o.method);
     o.iguess = g_iguess;
+    o.readocc = g_readocc;
+    o.occs = g_occs;
     helfem::range_separation(o.x_func, o.omega, o.kfrac, o.kshort);
     {
       bool erf, yuk;
@@ -309,6 +320,8 @@ int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, in
     o.method = method;
     helfem::parse_xc_func(o.x_func, o.c_func, o.method);
     o.iguess = g_iguess;
+    o.readocc = g_readocc;
+    o.occs = g_occs;
     helfem::range_separation(o.x_func, o.omega, o.kfrac, o.kshort);
     {
       bool erf, yuk;
@@ -485,17 +498,16 @@ static void check_options(const hfg_scf_options &p) {
     // features outside the hot-path scope: refuse loudly rather than compute something else
   if (p.Ez != 0.0 || p.Qzz != 0.0 || p.Bz != 0.0) throw std::logic_error("External electric / magnetic fields are not supported by this build.\n");
   if (p.finitenuc != 0) throw std::logic_error("Finite nuclear models are not supported by this build.\n");
-  if (p.readocc != 0) throw std::logic_error("Forced occupations (--readocc) are not supported by this build.\n");
+  if (p.readocc != 0 && (!p.occs || p.occ_rows <= 0 || p.occ_cols < 3))
+    throw std::logic_error(p.program == 0 ? "Must have at least three columns in occupation data.\n"
+                                          : "Must have three columns in occupation data to use axial symmetry.\n");
   if (p.perturb != 0.0) throw std::logic_error("Random perturbation of the guess (--perturb) is not supported by this build.\n");
   if (p.primbas != 4) throw std::logic_error("Only the LIP primitive basis (--primbas 4) is supported by this build.\n");
   if (p.iconf != 0) throw std::logic_error("Confinement potentials (--iconf) are not supported by this build.\n");
   if (p.zeroder != 0) throw std::logic_error("--zeroder is not supported by this build.\n");
-  if (p.load[0]) throw std::logic_error("Loading a guess from a checkpoint (--load) is not supported by this build.\n");
   if (p.iguess == 2) throw std::logic_error("Unsupported guess (SAP needs the reference's tabulated potentials)\n");
   if (p.iguess == 1) throw std::logic_error("Unsupported guess (GSZ needs the reference's per-element parameters)\n");
   if (p.iguess != 0 && p.iguess != 3) throw std::logic_error("Unsupported guess\n");
-  if (p.n_x_pars > 0 || p.n_c_pars > 0)
-    throw std::logic_error("External functional parameters (--x_pars / --c_pars) are not supported by the SCF driver of this build.\n");
 
   if (p.nelem <= 0) throw std::logic_error("need option: --nelem\n");
   if (p.program == 0) {
@@ -511,6 +523,19 @@ static void check_options(const hfg_scf_options &p) {
   int nela = p.nela, nelb = p.nelb, Q = p.Q, M = p.M > 0 ? p.M : 1;
   helfem::scf::parse_nela_nelb(nela, nelb, Q, M, p.program == 0 ? p.Z1 + p.Z2 : p.Z1);
   if (nela + nelb <= 0) throw std::logic_error("No electrons.\n");
+  if (p.readocc) {  // diatomic/main.cpp:369-380
+    int sa = 0, sb = 0;
+    for (int r = 0; r < p.occ_rows; r++) {
+      sa += p.occs[(size_t)r * p.occ_cols];
+      sb += p.occs[(size_t)r * p.occ_cols + 1];
+    }
+    if (sa != nela)
+      throw std::logic_error("Specified alpha occupations don't match wanted spin state.\nOccupying " + std::to_string(sa) +
+                             " orbitals but should have " + std::to_string(nela) + " orbitals.\n");
+    if (sb != nelb)
+      throw std::logic_error("Specified alpha occupations don't match wanted spin state.\nOccupying " + std::to_string(sb) +
+                             " orbitals but should have " + std::to_string(nelb) + " orbitals.\n");
+  }
 }
 
 /* validates an options structure the way hfg_scf_run does before it touches the device (usable without a GPU) */
@@ -570,6 +595,9 @@ int hfg_scf_run(hfg_ctx *ctx, const hfg_scf_options *in, hfg_scf_result *res, do
     o.diisthr = p.diisthr;
     o.diisorder = p.diisorder;
     o.iguess = p.iguess;
+    o.readocc = p.readocc;
+    if (p.readocc)
+      for (int r = 0; r < p.occ_rows; r++) o.occs.push_back(std::vector<int>(p.occs + (size_t)r * p.occ_cols, p.occs + (size_t)(r + 1) * p.occ_cols));
     o.dampfock = p.program ? p.dampfock : 1.0;
     o.dampthr = p.dampthr;
     o.verbose = p.verbose != 0;
@@ -578,6 +606,27 @@ int hfg_scf_run(hfg_ctx *ctx, const hfg_scf_options *in, hfg_scf_result *res, do
       std::string why;
       if (!helfem::hdf5_available(&why))  // before the run, not after it
         throw std::runtime_error("Checkpoint: no usable HDF5 library in this process (" + why + "set HELFEM_HDF5_LIB, or run with --save \"\")\n");
+    }
+    // --x_pars / --c_pars (main.cpp:150-157, xc_func_set_ext_params at dftgrid.cpp:399-417): in force for this run only
+    struct ResetPars {
+      hfg_ctx *c;
+      bool on;
+      ~ResetPars() {
+        if (on) try {
+            hfg::set_xc_params(c, 0, nullptr, 0, 0, nullptr, 0);
+          } catch (...) {
+          }
+      }
+    } reset_pars{ctx, p.n_x_pars > 0 || p.n_c_pars > 0};
+    if (reset_pars.on) hfg::set_xc_params(ctx, o.x_func, p.x_pars, p.n_x_pars, o.c_func, p.c_pars, p.n_c_pars);
+    if (p.load[0]) {  // main.cpp:552-648
+      helfem::Checkpoint chk(p.load, false);
+      chk.read("S", o.guessS);
+      chk.read("Ca", o.guessCa);
+      chk.read("Ea", o.guessEa);
+      if (chk.exist("Cb")) chk.read("Cb", o.guessCb);
+      if (chk.exist("Eb")) chk.read("Eb", o.guessEb);
+      o.have_guess = true;
     }
     helfem::scf::Result r;
     if (p.program == 0) {

@@ -84,19 +84,6 @@ Mat enforce_sym(const Mat &F, const std::vector<std::vector<size_t> > &sym) {
 }
 }  // namespace
 
-namespace {
-// the part of the drivers shared by the diatomic and atomic programs: everything from the one-electron matrices on
-struct Problem {
-  Mat S, T, Vnuc;
-  std::vector<std::vector<size_t> > dsym;
-  int symm = 1;
-  int nel = 0;
-  std::function<void()> compute_tei_and_prepare;
-  ModelPotential guess1, guess2;  // screened nuclei of the guess (kind 0: core Hamiltonian, nothing to evaluate)
-  // --maverage (atomic): groups of equally sized index lists whose diagonal blocks of F are averaged
-  std::vector<std::vector<std::vector<size_t> > > avg_idx;
-};
-
 // ---- forced occupations -----------------------------------------------------------------------------------------
 static void check_occupation_sums(const OccupationPlan &pl, int nela, int nelb) {
   int sa = 0, sb = 0;
@@ -154,6 +141,50 @@ OccupationPlan occupation_plan(const Options &opt, const atomic::TwoDBasis &basi
   }
   check_occupation_sums(pl, nela, nelb);
   return pl;
+}
+
+void guess_from_checkpoint(const Options &opt, const Mat &S, size_t nela, size_t nelb, Mat &Ca, Mat &Cb, Vec &Ea, Vec &Eb) {
+  const size_t N = S.n_rows;
+  bool same = opt.guessS.n_rows == N && opt.guessS.n_cols == N && opt.guessCa.n_rows == N;
+  if (same) {
+    double dmax = 0.0, smax = 0.0;
+    for (size_t k = 0; k < S.d.size(); k++) {
+      dmax = std::max(dmax, std::fabs(S.d[k] - opt.guessS.d[k]));
+      smax = std::max(smax, std::fabs(S.d[k]));
+    }
+    same = dmax <= 1e-10 * smax;
+  }
+  if (!same)
+    throw std::logic_error("The checkpoint to load was made in a different basis set; projection between basis sets "
+                           "(interbasis overlap) is not supported by this build.\n");
+  Ca = opt.guessCa;
+  Cb = opt.guessCb.n_rows == N ? opt.guessCb : opt.guessCa;
+  Ea = opt.guessEa;
+  Eb = opt.guessEb.size() ? opt.guessEb : opt.guessEa;
+  if (Ca.n_cols < nela || Cb.n_cols < nelb) throw std::logic_error("The checkpoint holds fewer orbitals than are to be occupied.\n");
+  auto gram_schmidt = [&](Mat &C, size_t nocc) {
+    std::vector<double> Sc(N);
+    for (size_t i = 0; i < nocc; i++) {
+      for (size_t j = 0; j <= i; j++) {
+        // S c_i with the current c_i
+        for (size_t a = 0; a < N; a++) {
+          double t = 0.0;
+          for (size_t b = 0; b < N; b++) t += S(a, b) * C(b, i);
+          Sc[a] = t;
+        }
+        double dot = 0.0;
+        for (size_t a = 0; a < N; a++) dot += C(a, j) * Sc[a];
+        if (j < i)
+          for (size_t a = 0; a < N; a++) C(a, i) -= C(a, j) * dot;
+        else {
+          const double inv = 1.0 / std::sqrt(dot);
+          for (size_t a = 0; a < N; a++) C(a, i) *= inv;
+        }
+      }
+    }
+  };
+  gram_schmidt(Ca, nela);
+  gram_schmidt(Cb, nelb);
 }
 
 std::vector<size_t> occupation_order(const Vec &E, const std::vector<std::vector<double> > &w, const std::vector<int> &nocc) {
@@ -220,6 +251,22 @@ void enforce_occupations(Mat &C, Vec &E, const Mat &S, const std::vector<int> &n
   E = En;
 }
 
+
+namespace {
+// the part of the drivers shared by the diatomic and atomic programs: everything from the one-electron matrices on
+struct Problem {
+  Mat S, T, Vnuc;
+  std::vector<std::vector<size_t> > dsym;
+  int symm = 1;
+  int nel = 0;
+  std::function<void()> compute_tei_and_prepare;
+  ModelPotential guess1, guess2;  // screened nuclei of the guess (kind 0: core Hamiltonian, nothing to evaluate)
+  // --maverage (atomic): groups of equally sized index lists whose diagonal blocks of F are averaged
+  std::vector<std::vector<std::vector<size_t> > > avg_idx;
+  // --readocc: the plan once the spin state is known
+  std::function<OccupationPlan(int, int)> occupations;
+};
+
 // scf::fock_symmetry_average (src/general/scf_helpers.cpp:263-284)
 Mat fock_symmetry_average(const Mat &Fin, const std::vector<std::vector<std::vector<size_t> > > &sym_idx) {
   Mat Fout(Fin);
@@ -276,6 +323,7 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   const bool restr = restr_req && !rohf;
   res.nela = (int)nela;
   res.nelb = (int)nelb;
+  const OccupationPlan occ = pb.occupations ? pb.occupations((int)nela, (int)nelb) : OccupationPlan();
   const int symm = pb.symm;
   const Mat &S = pb.S, &T = pb.T, &Vnuc = pb.Vnuc;
   const std::vector<std::vector<size_t> > &dsym = pb.dsym;
@@ -292,7 +340,9 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
   Mat Ca, Cb;
   bool prepared = false;
   Mat Hguess(H0);
-  if (opt.iguess != 0) {
+  if (opt.have_guess) {
+    // orbitals of a previous run, nothing to evaluate
+  } else if (opt.iguess != 0) {
     if (verbose) printf("Computing two-electron integrals\n");
     t0 = wall();
     pb.compute_tei_and_prepare();
@@ -303,10 +353,19 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
     Hguess = T + be.model_potential(pb.guess1, pb.guess2);
   } else if (verbose)
     printf("Guess orbitals from core Hamiltonian\n");
-  be.eig_gsym_sub(Ea, Ca, Hguess, Sinvh, dsym);
-  if (!restr) {
-    Eb = Ea;
-    Cb = Ca;
+  if (opt.have_guess) {
+    if (verbose) printf("Guess orbitals from checkpoint\nGuess orbitals from previous calculation\n");
+    guess_from_checkpoint(opt, S, nela, nelb, Ca, Cb, Ea, Eb);
+  } else {
+    be.eig_gsym_sub(Ea, Ca, Hguess, Sinvh, dsym);
+    if (!restr) {
+      Eb = Ea;
+      Cb = Ca;
+    }
+  }
+  if (occ.until && !opt.have_guess) {  // main.cpp:716-722
+    enforce_occupations(Ca, Ea, S, occ.na, occ.sym);
+    if (!restr) enforce_occupations(Cb, Eb, S, occ.nb, occ.sym);
   }
 
   if (!prepared) {
@@ -474,12 +533,17 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
     t0 = wall();
     if (restr) {
       be.eig_gsym_sub(Ea, Ca, Fd, Sinvh, dsym);
+      if (occ.active(it)) enforce_occupations(Ca, Ea, S, occ.na, occ.sym);  // main.cpp:942-944
     } else {
       Mat Fda(Nb, Nb), Fdb(Nb, Nb);
       std::copy(Fd.d.begin(), Fd.d.begin() + Nb * Nb, Fda.d.begin());
       std::copy(Fd.d.begin() + Nb * Nb, Fd.d.end(), Fdb.d.begin());
       be.eig_gsym_sub(Ea, Ca, Fda, Sinvh, dsym);
       be.eig_gsym_sub(Eb, Cb, Fdb, Sinvh, dsym);
+      if (occ.active(it)) {
+        enforce_occupations(Ca, Ea, S, occ.na, occ.sym);
+        enforce_occupations(Cb, Eb, S, occ.nb, occ.sym);  // main.cpp:956-958
+      }
     }
     res.tdiag = wall() - t0;
     if (verbose) {
@@ -619,6 +683,9 @@ Result run_diatomic(const Options &opt, Backend &be) {
     basis.compute_tei(opt.kfrac != 0.0);
     be.prepare(basis, opt.kfrac != 0.0, ldft, mdft);
   };
+  Options oo = opt;
+  oo.symmetry = symm;
+  pb.occupations = [oo, &basis](int na, int nb) { return occupation_plan(oo, basis, na, nb); };
   return scf_loop(opt, be, pb, res);
 }
 
@@ -686,6 +753,7 @@ Result run_atomic(const AtomicOptions &aopt, Backend &be) {
     }
     be.prepare_atomic(basis, opt.kfrac != 0.0, ldft, mdft);
   };
+  pb.occupations = [&opt, &basis](int na, int nb) { return occupation_plan(opt, basis, na, nb); };
   return scf_loop(opt, be, pb, res);
 }
 

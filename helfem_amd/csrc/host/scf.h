@@ -86,6 +86,13 @@ struct Options {
   // i < readocc (negative: always)
   int readocc = 0;
   std::vector<std::vector<int> > occs;
+  // --load (main.cpp:552-648, the "project lowest orbitals" branch): orbitals and the overlap matrix of a previous run.
+  // The reference projects between different bases through the interbasis overlap; here the checkpoint must be of the SAME
+  // basis (its S must equal this run's S), for which the projection is the identity; the occupied orbitals are
+  // re-orthonormalised by Gram-Schmidt as in main.cpp:630-640.
+  bool have_guess = false;
+  Mat guessS, guessCa, guessCb;
+  Vec guessEa, guessEb;
   bool keep_matrices = false;  // fill Result::mats with what the reference's drivers write to their checkpoint
   bool verbose = true;
 };
@@ -136,6 +143,9 @@ OccupationPlan occupation_plan(const Options &opt, const atomic::TwoDBasis &basi
 std::vector<size_t> occupation_order(const Vec &E, const std::vector<std::vector<double> > &w, const std::vector<int> &nocc);
 /// C, E reordered accordingly (host matrices; the device loop gathers on the device)
 void enforce_occupations(Mat &C, Vec &E, const Mat &S, const std::vector<int> &nocc, const std::vector<std::vector<size_t> > &sym);
+/// --load: checks that the stored overlap is this basis' and returns the stored orbitals with the first nela / nelb columns
+/// S-orthonormalised (main.cpp:618-646); throws std::logic_error for a checkpoint of another basis
+void guess_from_checkpoint(const Options &opt, const Mat &S, size_t nela, size_t nelb, Mat &Ca, Mat &Cb, Vec &Ea, Vec &Eb);
 
 std::vector<std::vector<std::vector<size_t> > > atomic_average_groups(const atomic::TwoDBasis &basis);
 Result run_diatomic(const Options &opt, Backend &be);

@@ -258,7 +258,7 @@ int hfg_scf_diatomic(hfg_ctx *ctx, int Z1, int Z2, double Rbond, const int *lmma
 /* ---- complete runs: what `diatomic` (src/diatomic/main.cpp) and `atomic` (src/atomic/main.cpp) do between parsing their
  * command line and printing the energy table.  Field names are the reference's flag names (main.cpp:89-133 /
  * atomic/main.cpp:63-119); hfg_scf_options_default() fills in the reference's defaults.  Flags of features outside the
- * hot-path scope (external fields, finite nuclei, confinement, forced occupations, non-LIP primitive bases) are carried so
+ * hot-path scope (external fields, finite nuclei, confinement, non-LIP primitive bases) are carried so
  * that the drivers can reject non-default values with the reference's wording instead of ignoring them. -------------- */
 #define HFG_MAX_LMMAX 16
 typedef struct hfg_scf_options {
@@ -298,7 +298,10 @@ typedef struct hfg_scf_options {
   /* out of scope, must keep their defaults: */
   double Ez, Qzz, Bz;        /* external fields */
   int finitenuc;             /* finite nuclear model */
-  int readocc;               /* forced occupations */
+  int readocc;               /* --readocc = 0: forced occupations from occs (the drivers read occs.dat), enforced after the
+                                guess and after the eigensolves of the iterations i < readocc; negative: always */
+  const int *occs;           /* occ_rows x occ_cols, row-major: nalpha, nbeta, m [, parity +-1 | atomic --symmetry 2: l, m] */
+  int occ_rows, occ_cols;
   double perturb;            /* random perturbation of the guess */
   int iconf;                 /* atomic: confinement potential */
   int zeroder;               /* atomic: zero derivative at Rmax */
@@ -314,6 +317,9 @@ typedef struct hfg_scf_result {
 } hfg_scf_result;
 
 int hfg_scf_options_default(hfg_scf_options *opt, int program);
+/* --readocc for the following hfg_scf_diatomic / hfg_scf_atomic calls of this thread (the short entry points have no
+ * options structure); readocc = 0 switches it off */
+int hfg_scf_set_occupations(int readocc, int nrows, int ncols, const int *rows);
 /* the validation hfg_scf_run performs before it touches the device (no GPU needed): 0 = acceptable */
 int hfg_scf_options_check(const hfg_scf_options *opt);
 /* runs the calculation on ctx's device; E / C (alpha orbital energies Nbf, orbitals Nbf x Nbf) may be NULL */

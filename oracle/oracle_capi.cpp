@@ -10,6 +10,8 @@ using namespace oracle;
 using helfem::diatomic::TwoDBasis;
 
 static thread_local std::string g_err;
+static thread_local int g_orc_readocc = 0;
+static thread_local std::vector<std::vector<int> > g_orc_occs;
 static thread_local int g_orc_iguess = 0;  // --iguess of the following orc_scf_* calls
 static thread_local double g_orc_diiseps = 1e-2, g_orc_diisthr = 1e-3;  // --diiseps / --diisthr of the following calls
 #define ORC_TRY try {
@@ -224,6 +226,8 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
   parse_xc_func(o.x_func, o.c_func, method);
   o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
   o.iguess = g_orc_iguess;
+  o.readocc = g_orc_readocc;
+  o.occs = g_orc_occs;
   o.diiseps = g_orc_diiseps;
   o.diisthr = g_orc_diisthr;
   o.ldft = ldft;
@@ -311,6 +315,13 @@ int orc_atomic_rs_exchange(void *h, const double *P, double *K) {
   Mat Km = atomic_rs_exchange(*b, to_mat(P, N, N));
   memcpy(K, Km.memptr(), sizeof(double) * N * N);
   ORC_CATCH
+}
+/// --readocc + the rows of occs.dat for the following orc_scf_* calls of this thread (readocc = 0 switches it off)
+int orc_scf_set_occupations(int readocc, int nrows, int ncols, const int *rows) {
+  g_orc_readocc = readocc;
+  g_orc_occs.clear();
+  for (int r = 0; r < nrows; r++) g_orc_occs.push_back(std::vector<int>(rows + (size_t)r * ncols, rows + (size_t)(r + 1) * ncols));
+  return 0;
 }
 /// --iguess for the following orc_scf_* calls of this thread (0 core, 3 Thomas-Fermi)
 int orc_scf_set_iguess(int iguess) {
@@ -437,6 +448,8 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
     o.rs_kind = 2;
   }
   o.iguess = g_orc_iguess;
+  o.readocc = g_orc_readocc;
+  o.occs = g_orc_occs;
   o.diiseps = g_orc_diiseps;
   o.diisthr = g_orc_diisthr;
   o.ldft = ldft;

@@ -13,6 +13,7 @@
 #include "oracle_scf.h"
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -362,8 +363,53 @@ struct Engine {  // what differs between the two programs
   std::function<void()> compute_tei;
 };
 
+// scf::enforce_occupations (scf_helpers.cpp:31-128), the checker's own statement of it: an orbital belongs to a symmetry
+// when its S-norm restricted to that symmetry's functions exceeds 10 eps; the first nocc of them (in the current order,
+// i.e. by energy) are occupied; the occupied set comes first, both sets in ascending energy.
+struct ForcedOcc {
+  int until = 0;
+  std::vector<int> na, nb;
+  std::vector<std::vector<size_t> > sym;
+};
+void apply_forced_occupations(Mat &C, Vec &E, const Mat &S, const std::vector<int> &nocc, const std::vector<std::vector<size_t> > &sym) {
+  if (nocc.size() != sym.size()) throw std::logic_error("nocc vector and symmetry indices don't match!\n");
+  const size_t norb = C.n_cols;
+  std::vector<int> state(norb, 0);  // 1: occupied
+  for (size_t g = 0; g < sym.size(); g++) {
+    int want = nocc[g];
+    for (size_t o = 0; o < norb && want > 0; o++) {
+      double nrm = 0.0;
+      for (size_t a : sym[g]) {
+        double sc = 0.0;
+        for (size_t b : sym[g]) sc += S(a, b) * C(b, o);
+        nrm += sc * C(a, o);
+      }
+      if (nrm <= 10 * DBL_EPSILON) continue;
+      if (state[o]) throw std::logic_error("Duplicates in occupied orbital list!\n");
+      state[o] = 1;
+      want--;
+    }
+    if (want > 0) throw std::logic_error("Not enough orbitals of the requested symmetry to occupy!\n");
+  }
+  std::vector<std::pair<double, size_t> > occ, virt;
+  for (size_t o = 0; o < norb; o++) (state[o] ? occ : virt).push_back(std::make_pair(E[o], o));
+  auto less = [](const std::pair<double, size_t> &x, const std::pair<double, size_t> &y) { return x.first < y.first; };
+  std::stable_sort(occ.begin(), occ.end(), less);
+  std::stable_sort(virt.begin(), virt.end(), less);
+  occ.insert(occ.end(), virt.begin(), virt.end());
+  Mat Cn(C.n_rows, norb);
+  Vec En(norb);
+  for (size_t o = 0; o < norb; o++) {
+    En[o] = occ[o].first;
+    for (size_t i = 0; i < C.n_rows; i++) Cn(i, o) = C(i, occ[o].second);
+  }
+  C = Cn;
+  E = En;
+}
+
 ScfOut iterate(const ScfIn &in, const Mat &S, const Mat &T, const Mat &Vnuc, const std::vector<std::vector<size_t> > &dsym,
-               const std::vector<std::vector<std::vector<size_t> > > &avg, int nel, double Enucr, Engine &en) {
+               const std::vector<std::vector<std::vector<size_t> > > &avg, int nel, double Enucr, Engine &en,
+               const ForcedOcc &focc = ForcedOcc()) {
   ScfOut out;
   out.Enucr = Enucr;
   const bool verbose = in.verbose;
@@ -398,6 +444,14 @@ ScfOut iterate(const ScfIn &in, const Mat &S, const Mat &T, const Mat &Vnuc, con
   eig_gsym_sub(Ea, Ca, Hguess, Sinvh, dsym);
   Eb = Ea;
   Cb = Ca;
+  if (focc.until) {
+    int sa = 0, sb = 0;
+    for (int v : focc.na) sa += v;
+    for (int v : focc.nb) sb += v;
+    if (sa != nela || sb != nelb) throw std::logic_error("Specified alpha occupations don't match wanted spin state.\n");
+    apply_forced_occupations(Ca, Ea, S, focc.na, focc.sym);
+    apply_forced_occupations(Cb, Eb, S, focc.nb, focc.sym);
+  }
   if (!have_tei) en.compute_tei();
 
   UDIIS diis(S, Sinvh, in.diiseps, in.diisthr, verbose, (size_t)in.diisorder);
@@ -493,11 +547,13 @@ ScfOut iterate(const ScfIn &in, const Mat &S, const Mat &T, const Mat &Vnuc, con
     }
 
     eig_gsym_sub(Ea, Ca, Fda, Sinvh, dsym);
+    if (it < focc.until) apply_forced_occupations(Ca, Ea, S, focc.na, focc.sym);
     if (closed) {
       Eb = Ea;
       Cb = Ca;
     } else
       eig_gsym_sub(Eb, Cb, Fdb, Sinvh, dsym);
+    if (it < focc.until) apply_forced_occupations(Cb, Eb, S, focc.nb, focc.sym);
     out.iterations = it;
     if (convd) {
       out.converged = true;
@@ -560,8 +616,18 @@ ScfOut scf_diatomic(const ScfIn &in) {
     return model_potential(basis, ldft, mdft, guess_nucleus(in.iguess, in.Z1, in.gsz_d1), guess_nucleus(in.iguess, in.Z2, in.gsz_d2));
   };
   std::vector<std::vector<std::vector<size_t> > > none;
+  ForcedOcc focc;
+  if (in.readocc) {  // diatomic/main.cpp:338-366
+    focc.until = in.readocc < 0 ? INT_MAX : in.readocc;
+    for (const std::vector<int> &row : in.occs) {
+      if (row.size() < 3) throw std::logic_error("Must have at least three columns in occupation data.\n");
+      focc.na.push_back(row[0]);
+      focc.nb.push_back(row[1]);
+      focc.sym.push_back(row.size() == 3 ? basis.m_indices(row[2]) : basis.m_indices(row[2], row[3] == -1));
+    }
+  }
   ScfOut out = iterate(in2, basis.overlap(), basis.kinetic(), basis.nuclear(), basis.get_sym_idx(symm), none, in.Z1 + in.Z2 - in.Q,
-                       in.Z1 * in.Z2 / in.Rbond, en);
+                       in.Z1 * in.Z2 / in.Rbond, en, focc);
   out.Nbf = basis.Nbf();
   return out;
 }
@@ -612,7 +678,17 @@ ScfOut scf_atomic(const ScfIn &in) {
       for (size_t a = 0; a < basis.Nang(); a++)
         if (basis.lval[a] == l) avg[l].push_back(basis.lm_indices(l, basis.mval[a]));
   }
-  ScfOut out = iterate(in, basis.overlap(), basis.kinetic(), basis.nuclear(), basis.get_sym_idx(in.symmetry), avg, nel, 0.0, en);
+  ForcedOcc focc;
+  if (in.readocc) {  // atomic/main.cpp:317-330
+    focc.until = in.readocc < 0 ? INT_MAX : in.readocc;
+    for (const std::vector<int> &row : in.occs) {
+      if (row.size() != (in.symmetry == 2 ? 4u : 3u)) throw std::logic_error("Wrong number of columns in occupation data.\n");
+      focc.na.push_back(row[0]);
+      focc.nb.push_back(row[1]);
+      focc.sym.push_back(in.symmetry == 2 ? basis.lm_indices(row[2], row[3]) : basis.m_indices(row[2]));
+    }
+  }
+  ScfOut out = iterate(in, basis.overlap(), basis.kinetic(), basis.nuclear(), basis.get_sym_idx(in.symmetry), avg, nel, 0.0, en, focc);
   out.Nbf = basis.Nbf();
   return out;
 }

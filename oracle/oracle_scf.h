@@ -2,6 +2,7 @@
 #pragma once
 #include "oracle.h"
 #include <string>
+#include <vector>
 
 namespace oracle {
 
@@ -33,6 +34,9 @@ struct ScfIn {
   double gsz_d1 = 0.0, gsz_d2 = 0.0;
   bool maverage = false;
   double dampfock = 1.0, dampthr = 0.1;  // atomic program: 0.7 / 0.1 by default (atomic/main.cpp:111-112)
+  // --readocc: rows (nalpha, nbeta, m [, parity | l, m]) of occs.dat; enforced while iteration < readocc (negative: always)
+  int readocc = 0;
+  std::vector<std::vector<int> > occs;
   bool verbose = false;
 };
 

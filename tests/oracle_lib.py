@@ -318,11 +318,25 @@ def xc_polarized(func_id, rho, sigma, thr=1e-12):
     return exc, vrho, vsigma
 
 
+def scf_set_occupations(occs=None, readocc=-1):
+    L = lib()
+    L.orc_scf_set_occupations.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    if occs is None:
+        _check(L.orc_scf_set_occupations(0, 0, 0, None))
+        return
+    a = np.ascontiguousarray(np.asarray(occs, dtype=np.int32))
+    _check(L.orc_scf_set_occupations(int(readocc), a.shape[0], a.shape[1], a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+
+
 def scf_atomic(Z, lmax, mmax, nelem, nnodes, method, Q=0, nquad=0, Rmax=40.0, igrid=4, zexp=2.0, ldft=0, mdft=0,
-               symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1, maverage=False):
+               symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1, maverage=False, occs=None, readocc=-1):
     out = np.zeros(8)
-    _check(lib().orc_scf_atomic(Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft, mdft,
-                                symmetry, M, 1 if maverage else 0, maxit, convthr, verbose, _p(out)))
+    scf_set_occupations(occs, readocc)
+    try:
+        _check(lib().orc_scf_atomic(Z, Q, lmax, mmax, nelem, nnodes, nquad, Rmax, igrid, zexp, method.encode(), ldft, mdft,
+                                    symmetry, M, 1 if maverage else 0, maxit, convthr, verbose, _p(out)))
+    finally:
+        scf_set_occupations(None)
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])
@@ -387,11 +401,15 @@ def xc_unpolarized(func_id, rho, sigma, thr=1e-12):
 
 
 def scf_diatomic(Z1, Z2, Rbond, lmmax, nelem, nnodes, method, nquad=0, Rmax=40.0, igrid=4, zexp=1.0, lpad=10, ldft=0,
-                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1):
+                 mdft=0, symmetry=1, maxit=50, convthr=1e-7, verbose=0, M=1, occs=None, readocc=-1):
     out = np.zeros(8)
     lm = (ctypes.c_int * len(lmmax))(*lmmax)
-    _check(lib().orc_scf_diatomic(Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
-                                  method.encode(), ldft, mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
+    scf_set_occupations(occs, readocc)
+    try:
+        _check(lib().orc_scf_diatomic(Z1, Z2, Rbond, lm, len(lmmax), nelem, nnodes, nquad, Rmax, igrid, zexp, lpad,
+                                      method.encode(), ldft, mdft, symmetry, M, maxit, convthr, verbose, _p(out)))
+    finally:
+        scf_set_occupations(None)
     keys = ["Etot", "Ekin", "Epot", "Ecoul", "Exx", "Exc", "Enucr"]
     r = dict(zip(keys, out[:7]))
     r["iterations"] = int(out[7])

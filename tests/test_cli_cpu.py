@@ -88,8 +88,8 @@ def test_required_and_unknown_options(hf):
 
 
 @pytest.mark.parametrize("extra,msg", [(["--Ez", "0.01"], "fields are not supported"), (["--finitenuc", "1"], "Finite nuclear"),
-                                       (["--readocc", "3"], "Forced occupations"), (["--primbas", "3"], "LIP primitive basis"),
-                                       (["--iguess", "2"], "SAP"), (["--load", "x.chk"], "--load"),
+                                       (["--readocc", "3"], "occs.dat"), (["--primbas", "3"], "LIP primitive basis"),
+                                       (["--iguess", "2"], "SAP"),
                                        (["--method", "hyb_lda_xc_cam_lda0"], "Range separated functionals are not supported"),
                                        (["--M", "2"], "Requested multiplicity 2 with 2 electrons"),
                                        (["--method", "no_such_functional"], "")])
@@ -97,6 +97,18 @@ def test_out_of_scope_options_are_refused_before_any_device_work(hf, extra, msg)
     rc, out, err = run("diatomic", "--Z1", "H", "--Z2", "H", "--Rbond", "1.4", "--lmax", "4", "--nelem", "2", *extra)
     assert rc == 1 and msg in err, err
     assert "no usable HIP device" not in err  # refused by the option check, not by the missing GPU
+
+
+def test_readocc_reads_and_checks_occs_dat(hf, tmp_path):
+    """--readocc: occs.dat of the working directory (diatomic/main.cpp:219-224), its sums against the spin state (:369-380)"""
+    (tmp_path / "occs.dat").write_text("1 1 0\n1 0 1\n0 0 -1\n")
+    p = subprocess.run([os.path.join(BIN, "diatomic"), "--Z1", "H", "--Z2", "H", "--Rbond", "1.4", "--lmax", "4", "--mmax", "1", "--nelem", "2",
+                        "--readocc", "-1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, cwd=str(tmp_path))
+    assert p.returncode == 1 and "Occupying 2 orbitals but should have 1 orbitals" in p.stderr.decode(), p.stderr.decode()
+    (tmp_path / "occs.dat").write_text("1 1\n")
+    p = subprocess.run([os.path.join(BIN, "diatomic"), "--Z1", "H", "--Z2", "H", "--Rbond", "1.4", "--lmax", "4", "--nelem", "2",
+                        "--readocc", "-1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, cwd=str(tmp_path))
+    assert p.returncode == 1 and "three columns" in p.stderr.decode(), p.stderr.decode()
 
 
 def test_options_structure_defaults(hf):

@@ -167,6 +167,66 @@ def test_diatomic_executable_h2_hf_and_its_checkpoint(hf, tmp_path):
     assert abs(np.trace(mats["P"] @ mats["T"]) - ekin) < 1e-9
 
 
+def _run_cli(exe, args, cwd):
+    p = subprocess.run([os.path.join(BIN, exe)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=cwd)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def _etot(out):
+    return float(re.search(r"Total\s+energy:\s+(-[0-9.]+)", out).group(1))
+
+
+def test_restart_from_a_checkpoint_and_refusal_of_another_basis(hf, tmp_path):
+    """--load (main.cpp:552-648): the orbitals of a finished run start the next one, which then converges at once to the
+    same energy; a checkpoint of a different basis is refused (the interbasis projection is not built)"""
+    if not hf.lib().hfg_chk_available():
+        pytest.skip("no libhdf5 on this box")
+    base = ["--Z1", "He", "--Z2", "H", "--Q", "1", "--Rbond", "1.5", "--lmax", "4", "--mmax", "1", "--nnodes", "8", "--method", "gga_x_pbe-gga_c_pbe"]
+    rc, out1, err = _run_cli("diatomic", base + ["--nelem", "2", "--save", "a.chk"], str(tmp_path))
+    assert rc == 0, out1[-2000:] + err[-2000:]
+    it1 = len(re.findall(r"\*\*\*\* Iteration", out1))
+    rc, out2, err = _run_cli("diatomic", base + ["--nelem", "2", "--load", "a.chk", "--save", ""], str(tmp_path))
+    assert rc == 0, out2[-2000:] + err[-2000:]
+    assert "Guess orbitals from checkpoint" in out2
+    it2 = len(re.findall(r"\*\*\*\* Iteration", out2))
+    assert abs(_etot(out1) - _etot(out2)) < 2e-7 and it2 <= 3 and it2 < it1, (it1, it2)
+    rc, out3, err = _run_cli("diatomic", base + ["--nelem", "3", "--load", "a.chk", "--save", ""], str(tmp_path))
+    assert rc == 1 and "different basis set" in err, err
+
+
+def test_functional_parameters_and_forced_occupations_through_the_command_line(hf, tmp_path):
+    """--x_pars / --c_pars files (scf::parse_xc_params) reach the device-resident loop: PBE's own parameters reproduce the
+    plain run, revPBE's kappa changes the energy to the oracle's value with the same parameter; --readocc puts lithium's
+    valence electron into a 2p orbital (occs.dat: nalpha nbeta m)"""
+    import oracle_lib as orc
+    args = ["--Z", "He", "--lmax", "0", "--mmax", "0", "--nelem", "4", "--nnodes", "10", "--method", "gga_x_pbe-gga_c_pbe", "--save", ""]
+    rc, out0, err = _run_cli("atomic", args, str(tmp_path))
+    assert rc == 0, err
+    (tmp_path / "x_default.dat").write_text("0.804\n0.2195149727645171\n")
+    (tmp_path / "x_rev.dat").write_text("1.245\n0.2195149727645171\n")
+    rc, out1, err = _run_cli("atomic", args + ["--x_pars", "x_default.dat"], str(tmp_path))
+    assert rc == 0, err
+    rc, out2, err = _run_cli("atomic", args + ["--x_pars", "x_rev.dat"], str(tmp_path))
+    assert rc == 0, err
+    assert abs(_etot(out0) - _etot(out1)) < 1e-9
+    dp = ctypes.POINTER(ctypes.c_double)
+    OL = orc.lib()
+    OL.orc_set_xc_params.argtypes = [ctypes.c_int, dp, ctypes.c_int, ctypes.c_int, dp, ctypes.c_int]
+    xa = np.array([1.245, 0.2195149727645171])
+    try:
+        assert OL.orc_set_xc_params(101, xa.ctypes.data_as(dp), 2, 130, None, 0) == 0
+        o = orc.scf_atomic(Z=2, lmax=0, mmax=0, nelem=4, nnodes=10, method="gga_x_pbe-gga_c_pbe", convthr=1e-8)
+    finally:
+        OL.orc_set_xc_params(0, None, 0, 0, None, 0)
+    assert abs(_etot(out2) - o["Etot"]) < 2e-7 and abs(_etot(out2) - _etot(out0)) > 1e-3, (_etot(out2), o["Etot"], _etot(out0))
+    # forced occupations
+    (tmp_path / "occs.dat").write_text("1 1 0\n1 0 1\n0 0 -1\n")
+    rc, out3, err = _run_cli("atomic", ["--Z", "Li", "--lmax", "1", "--mmax", "1", "--nelem", "4", "--nnodes", "10", "--method", "HF", "--readocc", "-1",
+                                        "--save", ""], str(tmp_path))
+    assert rc == 0, out3[-2000:] + err[-2000:]
+    assert abs(_etot(out3) - (-7.365070)) < 5e-5, _etot(out3)  # numerical HF, Li 1s2 2p
+
+
 def test_atomic_executable_he_lda(hf, tmp_path):
     """BASELINE config 1's flags through the `atomic` command line (He, LDA, 5 elements): NIST LDA total -2.834836"""
     p = subprocess.run([os.path.join(BIN, "atomic"), "--Z", "He", "--lmax", "0", "--mmax", "0", "--nelem", "5", "--nnodes", "8", "--method",

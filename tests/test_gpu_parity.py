@@ -532,6 +532,19 @@ OPEN_SHELL_CASES = [
     ("B_UHF_maverage", "atomic", dict(Z=5, lmax=1, mmax=1, nelem=4, nnodes=10, method="HF", M=2, maverage=True), None, None),
     # (a DFT run of boron would depend on WHICH of the degenerate p orbitals the aufbau picks: |Y10|^2 and |Y11|^2 are
     # different densities for a density functional; nitrogen 4S fills all three)
+    # the same with the open p shell FORCED into m = 0 / m = +1 on both sides (--readocc, scf::enforce_occupations): no
+    # degeneracy left to rounding noise, so every energy component is compared
+    ("B_UHF_maverage_forced_m0", "atomic", dict(Z=5, lmax=1, mmax=1, nelem=4, nnodes=10, method="HF", M=2, maverage=True,
+                                                occs=[[3, 2, 0], [0, 0, 1], [0, 0, -1]]), None, None),
+    ("B_UHF_maverage_forced_m1", "atomic", dict(Z=5, lmax=1, mmax=1, nelem=4, nnodes=10, method="HF", M=2, maverage=True,
+                                                occs=[[2, 2, 0], [1, 0, 1], [0, 0, -1]]), None, None),
+    # forced occupations reach excited states: Li 1s2 2p (numerical HF -7.365070), and a pi state of HeH
+    ("Li_2P_forced", "atomic", dict(Z=3, lmax=1, mmax=1, nelem=4, nnodes=10, method="HF", M=2, occs=[[1, 1, 0], [0, 0, 1], [1, 0, -1]]),
+     -7.365070, 5e-5),
+    ("Li_2P_forced_lm_blocks", "atomic", dict(Z=3, lmax=1, mmax=1, nelem=4, nnodes=10, method="HF", M=2, symmetry=2,
+                                              occs=[[1, 1, 0, 0], [1, 0, 1, 1], [0, 0, 1, 0], [0, 0, 1, -1]]), -7.365070, 5e-5),
+    ("HeH_pi_forced", "diatomic", dict(Z1=2, Z2=1, Rbond=1.5, lmmax=[4, 3], nelem=2, nnodes=8, method="HF", M=2,
+                                       occs=[[1, 1, 0], [1, 0, 1], [0, 0, -1]]), None, None),
     ("N_LSD_maverage", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=4, nnodes=10, method="lda_x-lda_c_vwn", M=4, maverage=True),
      None, None),
     ("H_PBE0", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh", M=2), None, None),
@@ -556,7 +569,7 @@ def test_unrestricted_scf_energy_parity(hf, name, prog, kw, lit, littol):
     assert g["converged"] and o["converged"]
     assert abs(g["Etot"] - o["Etot"]) < 1e-8 * max(1.0, abs(o["Etot"]) / 10), (name, g["Etot"], o["Etot"])
     # degenerate open shell under --maverage: only boron's single p electron (nitrogen 4S fills m = -1, 0, 1: no choice)
-    if kw.get("maverage") and name.startswith("B_"):
+    if name == "B_UHF_maverage":
         # The averaged Fock operator leaves the open p shell exactly degenerate in m: which member the Aufbau rule
         # occupies (the torus of m = +-1 or the dumbbell of m = 0) is decided by rounding noise in the eigenvalue order.
         # The members share the radial functions, hence Etot, Ekin, Epot and the SUM of the two-electron terms; the
