@@ -221,8 +221,8 @@ def test_functional_parameters_and_forced_occupations_through_the_command_line(h
     assert abs(_etot(out2) - o["Etot"]) < 2e-7 and abs(_etot(out2) - _etot(out0)) > 1e-3, (_etot(out2), o["Etot"], _etot(out0))
     # forced occupations
     (tmp_path / "occs.dat").write_text("1 1 0\n1 0 1\n0 0 -1\n")
-    rc, out3, err = _run_cli("atomic", ["--Z", "Li", "--lmax", "1", "--mmax", "1", "--nelem", "4", "--nnodes", "10", "--method", "HF", "--readocc", "-1",
-                                        "--save", ""], str(tmp_path))
+    rc, out3, err = _run_cli("atomic", ["--Z", "Li", "--lmax", "1", "--mmax", "1", "--nelem", "4", "--nnodes", "10", "--method", "HF", "--M", "2",
+                                        "--readocc", "-1", "--save", ""], str(tmp_path))
     assert rc == 0, out3[-2000:] + err[-2000:]
     assert abs(_etot(out3) - (-7.365070)) < 5e-5, _etot(out3)  # numerical HF, Li 1s2 2p
 
