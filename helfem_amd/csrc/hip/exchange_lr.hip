@@ -29,14 +29,17 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 
 constexpr int EXL_RMAX = 64;
+constexpr int EXL_GMAX = 16;  // factor groups (residual factorisations) at most
 constexpr int EXL_QMAX = 16;  // rows per thread in the factorisation kernel: N <= 1024 * EXL_QMAX
 
 // -------------------------------------------------------------------------------------------------
 // pivoted LDL^T, one workgroup
 // -------------------------------------------------------------------------------------------------
+// dscale: |first pivot| of the first group; the later groups (factorisations of the residual matrices, see
+// exchange_lowrank_dev) stop relative to THAT, not to their own first pivot
 __global__ __launch_bounds__(1024) void k_exl_factor(const double *__restrict__ P, int N, int rmax, double tol,
                                                      double *__restrict__ L, double *__restrict__ sgn,
-                                                     int *__restrict__ info) {
+                                                     int *__restrict__ info, double *__restrict__ dscale, int first) {
   __shared__ double red_v[16];
   __shared__ int red_i[16];
   __shared__ double lrow[EXL_RMAX];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(1024) void k_exl_factor(const double *__restrict__ 
     }
     __syncthreads();
     const double dp = piv_d;
-    if (k == 0) dmax0 = fabs(dp);
+    if (k == 0) dmax0 = first ? fabs(dp) : dscale[0];
     if (!(fabs(dp) > tol * dmax0) || dmax0 == 0.0) break;
     const double sk = (dp > 0.0) ? 1.0 : -1.0;
     const double inv = 1.0 / sqrt(fabs(dp));
@@ -121,13 +124,22 @@ __global__ __launch_bounds__(1024) void k_exl_factor(const double *__restrict__ 
     r = k + 1;
     __syncthreads();
   }
-  if (tid == 0) info[0] = r;
+  if (tid == 0) {
+    info[0] = r;
+    if (first) dscale[0] = dmax0;
+  }
   __syncthreads();
   for (int j = tid; j < r; j += 1024) sgn[j] = ssgn[j];
 }
 
 __device__ inline void atomic_max_nonneg(double *addr, double v) {
   atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// LS[k][i] = sgn[k] L[k][i]  (operand of the residual update P <- P - L S L^T)
+__global__ void k_exl_scale_cols(const double *__restrict__ L, const double *__restrict__ sgn, int N, int r, double *__restrict__ LS) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i < N && k < r) LS[(size_t)k * N + i] = sgn[k] * L[(size_t)k * N + i];
 }
 
 // dinfo[0] = max |P - L S L^T|, dinfo[1] = max |P|.  Workgroup = 256 rows x 32 columns: a thread keeps its row of L
@@ -451,7 +463,7 @@ __global__ void k_exl_reduce(const double *__restrict__ C, const long long *__re
 // G holds, for every element pair e > f, the block G_ef[(j,a),(k,b)] (A p x A p, column-major) at ((e (e-1))/2 + f)
 __global__ void k_exl_assemble(const double *__restrict__ Kin, const double *__restrict__ G, int N, int A, int E, int p,
                                const int *__restrict__ pure_shell, const int *__restrict__ pure_n,
-                               double *__restrict__ K) {
+                               double *__restrict__ K, int accumulate) {
   int row = blockIdx.x * 64 + (threadIdx.x & 63);
   int col = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (row >= N || col >= N) return;
@@ -475,11 +487,12 @@ __global__ void k_exl_assemble(const double *__restrict__ Kin, const double *__r
       else v += G[((size_t)f * (f - 1) / 2 + e) * Ap * Ap + ra * Ap + rb];
     }
   }
-  K[(size_t)col * N + row] = -v;
+  if (accumulate) K[(size_t)col * N + row] -= v;
+  else K[(size_t)col * N + row] = -v;
 }
 
 struct ExLRAux {
-  DevBuf<double> c0tab, c2tab, ktei, L, sgn, dinfo, Ld, V0, V2, aP, aQw, G, RB, C, Kin;
+  DevBuf<double> c0tab, c2tab, ktei, L, sgn, dinfo, Ld, V0, V2, aP, aQw, G, RB, C, Kin, Pwork, LS;
   DevBuf<int> info, LM_L, LM_M, tab_ch_off, tab_ch, S_off, S_list, pos, pure_shell, pure_n;
   DevBuf<long long> rb_off, c_off;
   DevBuf<GemmTask> tasks, ctasks;
@@ -585,24 +598,56 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   const int pp = p * p;
 
   // ---- factorise and verify ----
-  a.L.resize((size_t)N * EXL_RMAX);
-  a.sgn.resize(EXL_RMAX);
+  // Up to EXL_GMAX groups of EXL_RMAX factors: when the first group does not reproduce P, the residual matrix
+  // P - L S L^T is factorised in turn, and so on; K is linear in P, so the groups' exchange matrices add up (a density of
+  // rank 65 costs two passes, not the general kernels' seventy-fold).  All factorisations come first: an input that is not
+  // of low rank is handed to the general kernels before any exchange work is done.
+  static const int gmax = getenv("HELFEM_EXL_GROUPS") ? std::max(1, std::min(EXL_GMAX, atoi(getenv("HELFEM_EXL_GROUPS")))) : 4;
+  a.L.resize((size_t)N * EXL_RMAX * gmax);
+  a.sgn.resize((size_t)EXL_RMAX * gmax);
   a.info.resize(4);
   a.dinfo.resize(4);
-  HFG_HIP_CHECK(hipMemsetAsync(a.dinfo.p, 0, 4 * sizeof(double), s));
-  hipLaunchKernelGGL(k_exl_factor, dim3(1), dim3(1024), 0, s, dP, N, EXL_RMAX, 1e-14, a.L.p, a.sgn.p, a.info.p);
-  hipLaunchKernelGGL(k_exl_resid, dim3((N + 255) / 256, (N + 31) / 32), dim3(256), 0, s, dP, N, a.L.p, a.sgn.p, a.info.p, a.dinfo.p);
-  int r = 0;
-  double dinfo[2] = {0, 0};
-  HFG_HIP_CHECK(hipMemcpyAsync(&r, a.info.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  HFG_HIP_CHECK(hipMemcpyAsync(dinfo, a.dinfo.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  HFG_HIP_CHECK(hipStreamSynchronize(s));
-  if (!(dinfo[0] <= 1e-13 * dinfo[1])) return false;
-  if ((size_t)(4 * a.max_nch * r * p + a.max_nch * r) * sizeof(double) > 150 * 1024) return false;  // LDS tile of k_exl_RB
-  if (r == 0) {  // P == 0
+  std::vector<int> rg;
+  double pmax = 0.0;
+  bool reproduced = false;
+  const double *Pcur = dP;
+  for (int g = 0; g < gmax && !reproduced; g++) {
+    double *Lg = a.L.p + (size_t)g * N * EXL_RMAX, *sg = a.sgn.p + (size_t)g * EXL_RMAX;
+    HFG_HIP_CHECK(hipMemsetAsync(a.dinfo.p, 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_exl_factor, dim3(1), dim3(1024), 0, s, Pcur, N, EXL_RMAX, 1e-14, Lg, sg, a.info.p, a.dinfo.p + 2, g == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_exl_resid, dim3((N + 255) / 256, (N + 31) / 32), dim3(256), 0, s, Pcur, N, Lg, sg, a.info.p, a.dinfo.p);
+    int r = 0;
+    double dinfo[2] = {0, 0};
+    HFG_HIP_CHECK(hipMemcpyAsync(&r, a.info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HFG_HIP_CHECK(hipMemcpyAsync(dinfo, a.dinfo.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HFG_HIP_CHECK(hipStreamSynchronize(s));
+    if (g == 0) pmax = dinfo[1];
+    rg.push_back(r);
+    reproduced = (dinfo[0] <= 1e-13 * pmax);
+    if (reproduced || r == 0 || g + 1 == gmax) break;
+    // residual matrix for the next group
+    a.Pwork.resize((size_t)N * N);
+    a.LS.resize((size_t)N * EXL_RMAX);
+    if (g == 0) HFG_HIP_CHECK(hipMemcpyAsync(a.Pwork.p, dP, sizeof(double) * (size_t)N * N, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_exl_scale_cols, dim3((N + 255) / 256, r), dim3(256), 0, s, Lg, sg, N, r, a.LS.p);
+    gemm_dev(ctx, false, true, N, N, r, -1.0, Lg, N, a.LS.p, N, 1.0, a.Pwork.p, N);
+    Pcur = a.Pwork.p;
+  }
+  if (!reproduced) return false;
+  int rmax_g = 0;
+  for (int r : rg) rmax_g = std::max(rmax_g, r);
+  if ((size_t)(4 * a.max_nch * rmax_g * p + a.max_nch * rmax_g) * sizeof(double) > 150 * 1024) return false;  // LDS tile of k_exl_RB
+  if (rmax_g == 0) {  // P == 0
     HFG_HIP_CHECK(hipMemsetAsync(dK, 0, sizeof(double) * (size_t)N * N, s));
     return true;
   }
+  bool wrote = false;
+  for (size_t g = 0; g < rg.size(); g++) {
+  const int r = rg[g];
+  if (r == 0) continue;
+  const double *Lgrp = a.L.p + g * (size_t)N * EXL_RMAX, *sgrp = a.sgn.p + g * (size_t)EXL_RMAX;
+  const int accumulate = wrote ? 1 : 0;
+  wrote = true;
 
   // ---- angular stage ----
   const size_t ncol = (size_t)NLM * r;
@@ -615,13 +660,13 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   const size_t Ap = (size_t)A * p;
   const bool pair = t->pair_tei != 0;
   a.G.resize(std::max<size_t>((size_t)E * (E - 1) / 2 * Ap * Ap, 1));
-  hipLaunchKernelGGL(k_exl_expand, dim3((Nd + 255) / 256, r), dim3(256), 0, s, a.L.p, N, Nd, R, r, t->shell_off.p,
+  hipLaunchKernelGGL(k_exl_expand, dim3((Nd + 255) / 256, r), dim3(256), 0, s, Lgrp, N, Nd, R, r, t->shell_off.p,
                      t->shell_skip.p, a.Ld.p);
   hipLaunchKernelGGL(k_exl_V, dim3(NLM, A), dim3(256), 0, s, a.Ld.p, Nd, R, A, r, a.LM_L.p, a.LM_M.p, t->shell_m.p,
                      a.c0tab.p, a.c2tab.p, t->Lp1, two, a.V0.p, a.V2.p);
   if (!pair)
     hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol, A), dim3(128), 0, s, a.V0.p, a.V2.p, t->disj.p, t->LM_tab.p,
-                       t->LM_ilm.p, t->LM_fac.p, a.sgn.p, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
+                       t->LM_ilm.p, t->LM_fac.p, sgrp, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
                        a.aQw.p);
   // ---- cross-element part: G_ef = aQw_e aP_f^T for e > f (the other half of K is its transpose) ----
   if (!pair) {
@@ -720,11 +765,11 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
       const int nz = std::min(65535, Ntab - tau0);
       if (pair)
         hipLaunchKernelGGL(k_exl_RB_pair, dim3(max_ns * max_ns, E * (E + 1) / 2, nz), dim3(256), shb, s, a.V0.p, a.V2.p,
-                           a.tab_ch_off.p, a.tab_ch.p, t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E,
+                           a.tab_ch_off.p, a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E,
                            p, r, ntt, a.RB.p);
       else
         hipLaunchKernelGGL(k_exl_RB, dim3(max_ns * (max_ns + 1) / 2, E, nz), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
-                           a.tab_ch.p, t->LM_fac.p, a.sgn.p, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,
+                           a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,
                            a.RB.p);
     }
     gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
@@ -736,9 +781,10 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     hipLaunchKernelGGL(k_exl_reduce, dim3(A * A, E), dim3(256), 0, s, a.C.p, a.c_off.p, a.S_off.p, a.pos.p, A, E, p, Ntab,
                        a.Kin.p);
   dim3 grid((N + 63) / 64, (N + 3) / 4);
-  hipLaunchKernelGGL(k_exl_assemble, grid, dim3(256), 0, s, a.Kin.p, a.G.p, N, A, E, p, a.pure_shell.p, a.pure_n.p, dK);
+  hipLaunchKernelGGL(k_exl_assemble, grid, dim3(256), 0, s, a.Kin.p, a.G.p, N, A, E, p, a.pure_shell.p, a.pure_n.p, dK, accumulate);
   HFG_HIP_CHECK(hipGetLastError());
   HFG_HIP_CHECK(hipStreamSynchronize(s));  // host task list and offsets live on this stack frame
+  }  // factor groups
   return true;
 }
 

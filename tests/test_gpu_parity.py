@@ -129,6 +129,21 @@ def test_exchange_indefinite_and_full_rank_inputs(case):
     assert np.all(K0 == 0.0)
 
 
+def test_exchange_of_a_density_with_more_than_64_factors(case, monkeypatch):
+    """rank 70 ... 150: the fast path factorises the residual matrix again (groups of 64 factors, K is linear in P) instead
+    of handing the density to the general kernels; HELFEM_EXL_GROUPS=1 restores the single-group behaviour (fallback)"""
+    import common
+    name, gb, ob, _, _ = case
+    N = gb.Nbf()
+    for ncol, seed in ((70, 41), (150, 42)):
+        if ncol >= N:
+            continue
+        P = common.random_density(N, ncol, seed=seed) - 0.5 * common.random_density(N, 5, seed=seed + 7)
+        Ko = ob.exchange(P)
+        K = gb.exchange(P)
+        assert common.relerr(K, Ko) < 1e-11, (name, ncol, common.relerr(K, Ko))
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_exchange_shards_sum_to_full(case, hf, nranks):
     """the shards of hfg_exchange_dev (device-pointer entry point: partial results) sum to the full matrix, and the
