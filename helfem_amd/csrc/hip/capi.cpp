@@ -362,8 +362,7 @@ int hfg_compute_rs_tei(hfg_basis *b, int rs_kind, double omega) {
 int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *b, int exchange) {
   HFG_TRY
   (void)exchange;  // the exchange-ordered copies are made on the device when the exchange kernels first need them
-  if (b->kind == 0) compute_tei_dev(ctx, b);
-  else b->ab.compute_tei(exchange != 0);  // the atomic tables are small: host
+  compute_tei_dev(ctx, b);  // diatomic and atomic bases (hip/tei_dev.hip)
   HFG_CATCH
 }
 
@@ -385,7 +384,43 @@ int hfg_basis_lm_map(const hfg_basis *b, int *L, int *M, int *n) {
 // Tables built by hfg_compute_tei_dev are read back from the device layout (hip/tables.h) and unpadded.
 int hfg_basis_get_prim(hfg_ctx *ctx, const hfg_basis *b, int which, int ilm, int iel, double *out, int64_t *rows, int64_t *cols) {
   HFG_TRY
-  if (b->kind) throw std::logic_error("hfg_basis_get_prim: diatomic bases only\n");
+  if (b->kind) {
+    // atomic basis: which 0 = prim_tei[L] (TwoDBasis.cpp:666-739), 8 = disjoint_L, 10 = disjoint_m1L; ilm = L
+    const helfem::atomic::TwoDBasis &B = b->ab;
+    const size_t E = B.Nel(), NL = (size_t)B.N_L();
+    if ((which != 0 && which != 8 && which != 10) || ilm < 0 || (size_t)ilm >= NL || iel < 0 || (size_t)iel >= E)
+      throw std::logic_error("hfg_basis_get_prim: index out of range\n");
+    const size_t idx = (size_t)ilm * E + iel;
+    if (which >= 8) {
+      if (!B.have_tei && !B.have_disjoint) throw std::logic_error("Primitive teis have not been computed!\n");
+      const helfem::Mat &m = (which == 8 ? B.disjoint_L : B.disjoint_m1L)[idx];
+      *rows = (int64_t)m.n_rows;
+      *cols = (int64_t)m.n_cols;
+      if (out) std::copy(m.d.begin(), m.d.end(), out);
+    } else if (b->tei_on_device) {
+      if (!ctx) throw std::logic_error("hfg_basis_get_prim: the tables live on the device, a context is needed\n");
+      const size_t p = B.max_Nprim(), pp = p * p, Ni = B.fem.nprim(iel), Np = Ni * Ni, lo = (iel == 0) ? 1 : 0;
+      *rows = *cols = (int64_t)Np;
+      if (out) {
+        std::vector<double> pad(pp * pp);
+        HFG_HIP_CHECK(hipSetDevice(ctx->device));
+        HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HFG_HIP_CHECK(hipMemcpy(pad.data(), b->dev_tei.p + ((size_t)ilm * E + iel) * pp * pp, sizeof(double) * pp * pp, hipMemcpyDeviceToHost));
+        for (size_t cj = 0; cj < Ni; cj++)
+          for (size_t ci = 0; ci < Ni; ci++)
+            for (size_t rj = 0; rj < Ni; rj++)
+              for (size_t ri = 0; ri < Ni; ri++)
+                out[(cj * Ni + ci) * Np + rj * Ni + ri] = pad[((cj + lo) * p + ci + lo) * pp + (rj + lo) * p + ri + lo];
+      }
+    } else {
+      if (!B.have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
+      const helfem::Mat &m = B.prim_tei[idx];
+      *rows = (int64_t)m.n_rows;
+      *cols = (int64_t)m.n_cols;
+      if (out) std::copy(m.d.begin(), m.d.end(), out);
+    }
+    return 0;
+  }
   const helfem::diatomic::TwoDBasis &B = b->b;
   const size_t E = B.Nel(), Nlm = B.lm_map.size();
   if (which < 0 || which > 11 || ilm < 0 || (size_t)ilm >= Nlm || iel < 0 || (size_t)iel >= E)

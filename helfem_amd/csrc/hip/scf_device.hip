@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <deque>
 #include <memory>
 
@@ -298,8 +299,13 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   auto prepare_tables = [&]() {
     if (verbose) printf("Computing two-electron integrals\n");
     t0 = wall();
-    if (hb->kind) hb->ab.compute_tei(opt.kfrac != 0.0);
-    else compute_tei_dev(ctx, hb);  // in-element tables on the device (tei_dev.hip)
+    static const bool host_tei = getenv("HELFEM_TEI") && !strcmp(getenv("HELFEM_TEI"), "host");  // the checker of tei_dev.hip
+    if (host_tei) {
+      if (hb->kind) hb->ab.compute_tei(opt.kfrac != 0.0);
+      else hb->b.compute_tei(opt.kfrac != 0.0);
+      hb->tei_on_device = false;
+    } else
+      compute_tei_dev(ctx, hb);  // in-element tables on the device (tei_dev.hip)
     if (opt.omega != 0.0) {  // atomic/main.cpp:709-712
       if (!hb->kind) throw std::logic_error("Range separated functionals are not supported.\n");
       if (opt.rs_kind == 1) hb->ab.compute_yukawa(opt.omega);

@@ -258,16 +258,62 @@ Mat yukawa_integral(double rmin, double rmax, const Vec &xq, const Vec &wq, cons
       [L, lambda](double r) { return bessel_kl(r * lambda, L); });
 }
 
-void TwoDBasis::compute_tei(bool exchange) {
-  const size_t Ne = Nel(), NL = (size_t)N_L(), nq = xq.size();
+void TwoDBasis::compute_disjoint() {
+  const size_t Ne = Nel(), NL = (size_t)N_L();
   disjoint_L.assign(Ne * NL, Mat());
   disjoint_m1L.assign(Ne * NL, Mat());
-  prim_tei.assign(Ne * NL, Mat());
   for (size_t L = 0; L < NL; L++)
     for (size_t iel = 0; iel < Ne; iel++) {
       disjoint_L[L * Ne + iel] = radial_integral((int)L, iel);
       disjoint_m1L[L * Ne + iel] = radial_integral(-(int)L - 1, iel);
     }
+  have_disjoint = true;
+}
+
+void TwoDBasis::tei_element_tables(size_t iel, diatomic::TwoDBasis::TeiElementTables &t) const {
+  const size_t nq = xq.size(), NL = (size_t)N_L();
+  const double rmin = fem.element_begin(iel), rmax = fem.element_end(iel);
+  const double rmid0 = 0.5 * (rmax + rmin), rlen0 = 0.5 * (rmax - rmin);
+  LIPBasis poly = fem.get_basis(iel);
+  const size_t Ni = poly.nbf(), Np = Ni * Ni;
+  t.Ni = Ni;
+  t.Np = Np;
+  t.nq = nq;
+  t.Nlm = NL;
+  t.bb0.zeros(Np, nq);
+  t.bbs.zeros(Np, nq * nq);
+  t.wQ.assign(NL * nq, 0.0);
+  t.wP.assign(NL * nq * nq, 0.0);
+  Vec r0(nq);
+  for (size_t q = 0; q < nq; q++) r0[q] = rmid0 + rlen0 * xq[q];
+  Mat bf0 = poly.eval_dnf(xq, 0, rlen0);
+  for (size_t q = 0; q < nq; q++) {
+    const double w = wq[q] * rlen0;
+    for (size_t L = 0; L < NL; L++) t.wQ[L * nq + q] = w * std::pow(r0[q], -(double)L - 1.0);
+    for (size_t j = 0; j < Ni; j++)
+      for (size_t i = 0; i < Ni; i++) t.bb0(j * Ni + i, q) = bf0(q, i) * bf0(q, j);
+  }
+  for (size_t isub = 0; isub < nq; isub++) {
+    const double a = (isub == 0) ? rmin : r0[isub - 1], bnd = r0[isub];
+    const double rmid = 0.5 * (bnd + a), rlen = 0.5 * (bnd - a);
+    Vec xpoly(nq);
+    for (size_t q = 0; q < nq; q++) {
+      const double r = rmid + rlen * xq[q];
+      xpoly[q] = (r - rmid0) / rlen0;
+      const double w = wq[q] * rlen;
+      for (size_t L = 0; L < NL; L++) t.wP[L * nq * nq + isub * nq + q] = w * std::pow(r, (double)L);
+    }
+    Mat bf = poly.eval_dnf(xpoly, 0, rlen0);
+    for (size_t q = 0; q < nq; q++)
+      for (size_t j = 0; j < Ni; j++)
+        for (size_t i = 0; i < Ni; i++) t.bbs(j * Ni + i, isub * nq + q) = bf(q, i) * bf(q, j);
+  }
+}
+
+void TwoDBasis::compute_tei(bool exchange) {
+  const size_t Ne = Nel(), NL = (size_t)N_L();
+  compute_disjoint();
+  prim_tei.assign(Ne * NL, Mat());
   parallel_for(Ne * NL, [&](size_t idx) {
     const size_t L = idx / Ne, iel = idx % Ne;
     prim_tei[L * Ne + iel] =

@@ -15,6 +15,7 @@
 // polynomial and that series is exact; here it is evaluated directly as the Lagrange product with the
 // (x - x_0) factor removed, which is the same polynomial without the cancellation the series avoids.
 #pragma once
+#include "diatomic_basis.h"
 #include "fem.h"
 #include "special.h"
 #include "model_potential.h"
@@ -75,6 +76,15 @@ struct TwoDBasis {
   Mat get_df(size_t iel) const;
   Vec get_wrad(size_t iel) const;
   Vec get_r(size_t iel) const { return fem.eval_coord(xq, iel); }
+  /// per-element operands of the in-element two-electron integrals for the GPU (hip/tei_dev.hip), in the layout of
+  /// diatomic::TwoDBasis::TeiElementTables with ONE operand type and one "channel" per L:
+  /// wP[L][s] = w_s r_s^L at the sub-interval points, wQ[L][q] = w_q r_q^{-L-1} at the main points -- the prefix form of
+  /// quadrature::twoe_inner_integral (libhelfem/src/quadrature.cpp:22-75), which carries the inner integral from point
+  /// to point with the ratio (r_{q-1}/r_q)^{L+1} instead; all terms are positive, the two forms agree to rounding
+  void tei_element_tables(size_t iel, diatomic::TwoDBasis::TeiElementTables &t) const;
+  /// the disjoint (cross-element) integrals only (the cheap part of compute_tei)
+  void compute_disjoint();
+  bool have_disjoint = false;
   /// \int (B_i/r)(B_j/r) r^{Rexp+2} dr over element iel   (RadialBasis::radial_integral)
   Mat radial_integral(int Rexp, size_t iel) const;
 

@@ -253,6 +253,36 @@ def test_tei_tables_built_on_device_match_host_tables(hf):
             assert common.relerr(Jd, Jh) < 1e-13 and common.relerr(Kd, Kh) < 1e-12, (kw, tag)
 
 
+def test_atomic_tei_tables_built_on_device(hf):
+    """hfg_compute_tei_dev for the atomic basis (one operand type, kernel r_<^L / r_>^{L+1}, prefix form of the inner
+    integral): every in-element table against the host tables (quadrature::twoe_integral in its carried-ratio form, pinned
+    by the Maple rationals of src/atomic/inttest.cpp in tests/test_golden_cpu.py), then J and K against the oracle"""
+    import common
+    for kw in (dict(Z=10, lmax=2, mmax=2, nelem=4, nnodes=7), dict(Z=4, lmax=1, mmax=0, nelem=6, nnodes=5, igrid=1)):
+        gh, ob = common.make_atomic_bases(**kw)
+        gd, _ = common.make_atomic_bases(oracle=False, **kw)
+        gh.compute_tei(True)
+        gd.compute_tei(True, device=True)
+        NL = 2 * kw["lmax"] + 1
+        worst = 0.0
+        for L in range(NL):
+            for iel in range(kw["nelem"]):
+                th, td = gh.prim_table("tei00", L, iel), gd.prim_table("tei00", L, iel)
+                assert th.shape == td.shape
+                worst = max(worst, np.max(np.abs(th - td)) / np.max(np.abs(th)))
+                for name in ("P0", "Q0"):
+                    assert np.array_equal(gh.prim_table(name, L, iel), gd.prim_table(name, L, iel))
+        assert worst < 1e-12, (kw, worst)
+        ob.compute_tei(True)
+        gh.upload()
+        gd.upload()
+        N = gh.Nbf()
+        P = common.random_density(N, 3, seed=77)
+        Jo, Ko = ob.coulomb(P), ob.exchange(P)
+        assert common.relerr(gd.coulomb(P), Jo) < 1e-12 and common.relerr(gd.exchange(P), Ko) < 1e-12, kw
+        assert common.relerr(gd.coulomb(P), gh.coulomb(P)) < 1e-13
+
+
 def test_tei_tables_against_the_independent_fixture(hf):
     """hfg_compute_tei_dev and the host tables against tests/golden/diatomic_tei.npz: tables of the NumPy restatement
     oracle/diatomic_tei.py of quadrature.cpp:22-123 / basis.cpp:1166-1302, which shares no code with the product (the
