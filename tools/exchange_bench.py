@@ -16,3 +16,13 @@ ctx.profile(True); ctx.profile_reset()
 K=basis.exchange(P)
 print("exchange dev ms", ctx.profile_get("exchange"))
 t=time.time(); J=basis.coulomb(P); print("coulomb s",time.time()-t)
+# a density of rank 21 + 50 = 71 > 64 factors: two factor groups on the fast path (round 1: general kernels, 1.4 s)
+if len(sys.argv) > 2 and sys.argv[2] == "groups":
+    P2 = P + 0.01 * common.random_density(N, 50, seed=9)
+    K2 = basis.exchange(P2)
+    ctx.profile_reset()
+    K2 = basis.exchange(P2)
+    print("exchange dev ms, 71 factors", ctx.profile_get("exchange"))
+    # linearity as the size-independent check
+    K3 = basis.exchange(0.01 * common.random_density(N, 50, seed=9))
+    print("linearity", np.max(np.abs(K2 - K - K3)) / np.max(np.abs(K2)))
