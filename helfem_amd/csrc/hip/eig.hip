@@ -992,8 +992,17 @@ size_t eig_block_buf_size(int nblk, const int64_t *blk_ptr) {
   return (size_t)nblk * (nmax * nmax + nmax);
 }
 
+// nF Fock matrices at once (the two spins of an unrestricted iteration): their blocks join ONE batch -- the
+// tridiagonalisation is a chain of dependent launches whose length does not depend on the number of blocks in it, so two
+// spins cost about what one costs
+void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs, const double *dS, int nblk, const int64_t *blk_ptr,
+                          const int64_t *blk_idx, double *const *dBlockBufs);
 void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                     const int64_t *blk_idx, double *dBlockBuf) {
+  eig_blocks_multi_dev(ctx, N, 1, &dF, dS, nblk, blk_ptr, blk_idx, &dBlockBuf);
+}
+void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs, const double *dS, int nblk, const int64_t *blk_ptr,
+                          const int64_t *blk_idx, double *const *dBlockBufs) {
   EigWork &w = work_for(ctx);
   hipStream_t s = ctx->stream;
   if (blk_ptr[nblk] != N) throw std::logic_error("Symmetry mismatch in eig_gsym_sub\n");
@@ -1047,11 +1056,13 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
   size_t nmax = 0;
   for (int ib = 0; ib < nblk; ib++) nmax = std::max<size_t>(nmax, blk_ptr[ib + 1] - blk_ptr[ib]);
   const size_t slot = nmax * nmax + nmax;
-  HFG_HIP_CHECK(hipMemsetAsync(dBlockBuf, 0, sizeof(double) * slot * nblk, s));
+  for (int f = 0; f < nF; f++) HFG_HIP_CHECK(hipMemsetAsync(dBlockBufs[f], 0, sizeof(double) * slot * nblk, s));
 
+  // work items: (matrix, block) pairs; `mine` holds matrix * nblk + block
   std::vector<int> mine;
-  for (int ib = 0; ib < nblk; ib++)
-    if (ib % ctx->shard_n == ctx->shard_rank) mine.push_back(ib);
+  for (int f = 0; f < nF; f++)
+    for (int ib = 0; ib < nblk; ib++)
+      if (ib % ctx->shard_n == ctx->shard_rank) mine.push_back(f * nblk + ib);
   DevBuf<double> &Fb = ctx->ws[5];
   DevBuf<double> &T1 = ctx->ws[0];
   DevBuf<double> &Xall = ctx->ws[4];
@@ -1066,7 +1077,8 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
     std::vector<GemmTask> gt(3 * (size_t)nb);
     int nm = 0;
     for (int k = 0; k < nb; k++) {
-      int ib = mine[c0 + k];
+      const int ib = mine[c0 + k] % nblk;
+      double *dBlockBuf = dBlockBufs[mine[c0 + k] / nblk];
       int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
       ns[k] = n;
       nm = std::max(nm, n);
@@ -1097,7 +1109,8 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
     {
       ProfScope ps(ctx, "eig_reduce");
       for (int k = 0; k < nb; k++) {
-        int ib = mine[c0 + k];
+        const int ib = mine[c0 + k] % nblk;
+        const double *dF = dFs[mine[c0 + k] / nblk];
         int n = ns[k];
         hipLaunchKernelGGL(k_gather_block, dim3((n + 255) / 256, n), dim3(256), 0, s, dF, dS, N, drows + blk_ptr[ib],
                            dcols + blk_ptr[ib], n, Fb.p + (size_t)k * nmax * nmax, Xall.p + (size_t)k * nmax * nmax);
@@ -1115,9 +1128,9 @@ void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int
       if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
       else gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
       for (int k = 0; k < nb; k++) {
-        int ib = mine[c0 + k];
+        const int ib = mine[c0 + k] % nblk;
         int n = ns[k];
-        double *slotp = dBlockBuf + (size_t)ib * slot;
+        double *slotp = dBlockBufs[mine[c0 + k] / nblk] + (size_t)ib * slot;
         HFG_HIP_CHECK(hipMemcpyAsync(slotp + nmax * nmax, w.d[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
       }
     }
@@ -1169,6 +1182,31 @@ void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, i
     buf.resize(eig_block_buf_size(nblk, blk_ptr));
     eig_blocks_dev(ctx, N, dF, dS, nblk, blk_ptr, blk_idx, buf.p);
     eig_assemble_dev(ctx, N, nblk, blk_ptr, blk_idx, buf.p, dE, dC);
+  } catch (...) {
+    ctx->shard_rank = save_rank;
+    ctx->shard_n = save_n;
+    throw;
+  }
+  ctx->shard_rank = save_rank;
+  ctx->shard_n = save_n;
+}
+
+// scf::eig_gsym_sub for the two spin matrices of an unrestricted iteration in one batch (diatomic/main.cpp:936-958 calls
+// it twice in a row with the same Sinvh and symmetry blocks)
+void eig_gsym_sub_pair_dev(hfg_ctx *ctx, int N, const double *dFa, const double *dFb, const double *dS, int nblk, const int64_t *blk_ptr,
+                           const int64_t *blk_idx, double *dEa, double *dCa, double *dEb, double *dCb) {
+  int save_rank = ctx->shard_rank, save_n = ctx->shard_n;
+  ctx->shard_rank = 0;
+  ctx->shard_n = 1;
+  try {
+    const size_t sz = eig_block_buf_size(nblk, blk_ptr);
+    DevBuf<double> &buf = ctx->ws[6];
+    buf.resize(2 * sz);
+    const double *Fs[2] = {dFa, dFb};
+    double *bufs[2] = {buf.p, buf.p + sz};
+    eig_blocks_multi_dev(ctx, N, 2, Fs, dS, nblk, blk_ptr, blk_idx, bufs);
+    eig_assemble_dev(ctx, N, nblk, blk_ptr, blk_idx, bufs[0], dEa, dCa);
+    eig_assemble_dev(ctx, N, nblk, blk_ptr, blk_idx, bufs[1], dEb, dCb);
   } catch (...) {
     ctx->shard_rank = save_rank;
     ctx->shard_n = save_n;

@@ -30,6 +30,8 @@ void form_sinvh_dev(hfg_ctx *ctx, int N, const double *dS, bool chol, int nblk, 
                     const int64_t *blk_idx, double *dSinvh);
 void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc, double *dP);
 void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
+void eig_gsym_sub_pair_dev(hfg_ctx *ctx, int N, const double *dFa, const double *dFb, const double *dS, int nblk, const int64_t *blk_ptr,
+                           const int64_t *blk_idx, double *dEa, double *dCa, double *dEb, double *dCb);
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                       const int64_t *blk_idx, double *dE, double *dC);
 void upload_tables(hfg_ctx *ctx, hfg_basis *basis, int ldft, int mdft);
@@ -349,6 +351,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     printf("Guess orbitals from core Hamiltonian\n");
   // forced occupations on the device: S C by one product, the symmetry weights of all orbitals by one small kernel per
   // occupied symmetry, the order on the host from the weights and the energies (the reference's rule), one gather
+  DevBuf<double> FdB;  // the beta spin's extrapolated Fock matrix (the alpha one lives in d.T1)
   DevBuf<int> occ_rows, occ_order;
   DevBuf<double> occ_w;
   std::vector<int> occ_rowptr(1, 0);
@@ -594,8 +597,13 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     t0 = wall();
     const bool damping = (opt.dampfock != 1.0 && diiserr >= opt.dampthr);  // atomic/main.cpp:917-936
     if (damping && verbose) printf("Damping off-diagonal elements of Fock matrix by % .3f\n", opt.dampfock);
+    // both spins' extrapolated (and damped) Fock matrices first, then ONE batched eigensolve for them: the
+    // tridiagonalisation's chain of dependent launches is as long for six blocks as for three
+    static const bool pair_eig = !(getenv("HELFEM_EIG_PAIR") && atoi(getenv("HELFEM_EIG_PAIR")) == 0);
+    if (nspin == 2) FdB.resize(NN);
+    double *Fds[2] = {d.T1.p, nspin == 2 ? FdB.p : nullptr};
     for (int sp = 0; sp < nspin; sp++) {
-      double *Fd = d.T1.p;
+      double *Fd = Fds[sp];
       for (size_t a = 0; a < nh; a++) d.axpby(coef[a], d.histF[slots[a]].p + sp * NN, a ? 1.0 : 0.0, Fd, NN);
       const int nocc = sp ? nelb : nela;
       if (damping && nocc > 0 && n > nocc) {
@@ -609,10 +617,14 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
         gemm_dev(ctx, false, true, n, n, n, 1.0, Fd, n, d.T2.p, n, 0.0, d.Err.p, n);     // S C f (S C)^T
         HFG_HIP_CHECK(hipMemcpyAsync(Fd, d.Err.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
       }
-      eig_gsym_sub_dev(ctx, n, Fd, d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), sp ? d.Eb.p : d.Ea.p,
-                       sp ? d.Cb.p : d.Ca.p);
-      if (focc.active(it)) enforce_occupations(sp ? d.Cb.p : d.Ca.p, sp ? d.Eb.p : d.Ea.p, sp ? focc.nb : focc.na);  // main.cpp:942-958
     }
+    if (nspin == 2 && pair_eig)
+      eig_gsym_sub_pair_dev(ctx, n, Fds[0], Fds[1], d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), d.Ea.p, d.Ca.p, d.Eb.p, d.Cb.p);
+    else
+      for (int sp = 0; sp < nspin; sp++)
+        eig_gsym_sub_dev(ctx, n, Fds[sp], d.Sinvh.p, (int)dsym.size(), ptr.data(), idx.data(), sp ? d.Eb.p : d.Ea.p, sp ? d.Cb.p : d.Ca.p);
+    for (int sp = 0; sp < nspin; sp++)
+      if (focc.active(it)) enforce_occupations(sp ? d.Cb.p : d.Ca.p, sp ? d.Eb.p : d.Ea.p, sp ? focc.nb : focc.na);  // main.cpp:942-958
     if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
     res.tdiag = wall() - t0;
     if (verbose) {
