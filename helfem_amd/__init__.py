@@ -458,6 +458,22 @@ class scf(object):
         return E, C
 
     @staticmethod
+    def eig_gsym_sub_pair(Fa, Fb, Sinvh, m_idx, ctx=None):
+        """the alpha and beta eig_gsym_sub calls of an unrestricted iteration as one batch (hfg_eig_gsym_sub_pair)"""
+        ctx = ctx or default_context()
+        Fa, Fb, Sinvh = _f(Fa), _f(Fb), _f(Sinvh)
+        N = Fa.shape[0]
+        ptr, idx = scf._blocks(m_idx)
+        Ea, Eb = np.zeros(N), np.zeros(N)
+        Ca, Cb = np.zeros((N, N), order="F"), np.zeros((N, N), order="F")
+        f = lib().hfg_eig_gsym_sub_pair
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p, ctypes.c_int, c_i64_p, c_i64_p, c_double_p,
+                      c_double_p, c_double_p, c_double_p]
+        _check(f(ctx.h, N, _p(Fa), _p(Fb), _p(Sinvh), len(m_idx), ptr.ctypes.data_as(c_i64_p), idx.ctypes.data_as(c_i64_p), _p(Ea), _p(Ca),
+                 _p(Eb), _p(Cb)))
+        return Ea, Ca, Eb, Cb
+
+    @staticmethod
     def eig_sym(A, ctx=None):
         ctx = ctx or default_context()
         A = _f(A)

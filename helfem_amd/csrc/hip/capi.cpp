@@ -49,6 +49,8 @@ void eig_gsym_dev(hfg_ctx *ctx, int N, int n, const double *dF, const double *dS
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                       const int64_t *blk_idx, double *dE, double *dC);
 size_t eig_block_buf_size(int nblk, const int64_t *blk_ptr);
+void eig_gsym_sub_pair_dev(hfg_ctx *ctx, int N, const double *dFa, const double *dFb, const double *dS, int nblk, const int64_t *blk_ptr,
+                           const int64_t *blk_idx, double *dEa, double *dCa, double *dEb, double *dCb);
 void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                     const int64_t *blk_idx, double *dBlockBuf);
 void eig_assemble_dev(hfg_ctx *ctx, int N, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
@@ -989,6 +991,20 @@ int hfg_eig_gsym_sub(hfg_ctx *ctx, int64_t N, const double *F, const double *S, 
   eig_gsym_sub_dev(ctx, (int)N, dF, dS, nblk, blk_ptr, blk_idx, dE, dC);
   st.down(E, dE, N);
   st.down(C, dC, N * N);
+  st.sync();
+  HFG_CATCH
+}
+int hfg_eig_gsym_sub_pair(hfg_ctx *ctx, int64_t N, const double *Fa, const double *Fb, const double *S, int nblk, const int64_t *blk_ptr,
+                          const int64_t *blk_idx, double *Ea, double *Ca, double *Eb, double *Cb) {
+  HFG_TRY
+  Stage st(ctx);
+  double *dFa = st.up(Fa, N * N), *dFb = st.up(Fb, N * N), *dS = st.up(S, N * N);
+  double *dEa = st.alloc(N), *dCa = st.alloc(N * N), *dEb = st.alloc(N), *dCb = st.alloc(N * N);
+  eig_gsym_sub_pair_dev(ctx, (int)N, dFa, dFb, dS, nblk, blk_ptr, blk_idx, dEa, dCa, dEb, dCb);
+  st.down(Ea, dEa, N);
+  st.down(Ca, dCa, N * N);
+  st.down(Eb, dEb, N);
+  st.down(Cb, dCb, N * N);
   st.sync();
   HFG_CATCH
 }

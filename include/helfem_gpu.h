@@ -202,6 +202,10 @@ int hfg_eig_gsym(hfg_ctx *ctx, int64_t N, int64_t n, const double *F, const doub
 /* void scf::eig_gsym_sub(E,C,F,Sinvh,m_idx)                           scf_helpers.h:36, .cpp:142 */
 int hfg_eig_gsym_sub(hfg_ctx *ctx, int64_t N, const double *F, const double *Sinvh, int nblk,
                      const int64_t *blk_ptr, const int64_t *blk_idx, double *E, double *C);
+/* the two consecutive scf::eig_gsym_sub calls of an unrestricted iteration (diatomic/main.cpp:936-958: same Sinvh, same
+ * blocks, Fa then Fb) as ONE batch: the blocks of both matrices share the tridiagonalisation's chain of launches */
+int hfg_eig_gsym_sub_pair(hfg_ctx *ctx, int64_t N, const double *Fa, const double *Fb, const double *Sinvh, int nblk,
+                          const int64_t *blk_ptr, const int64_t *blk_idx, double *Ea, double *Ca, double *Eb, double *Cb);
 /* arma::eig_sym(E,C,A) as used by utils::invh                         libhelfem/src/utils.cpp:172 */
 int hfg_eig_sym(hfg_ctx *ctx, int64_t n, const double *A, double *E, double *C);
 /* arma::mat TwoDBasis::Sinvh(bool chol, int sym) -> block-structured S^{-1/2}   basis.cpp:627 */

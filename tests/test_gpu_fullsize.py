@@ -214,3 +214,23 @@ def test_symmetry0_single_4230_eigenproblem(full):
     assert np.max(np.abs(C0.T @ SC - np.eye(N))) < 1e-9
     assert np.max(np.abs(H0 @ C0 - SC * E0)) < 1e-9 * np.max(np.abs(E0))
     assert np.max(np.abs(E0 - full["E"])) < 1e-9 * np.max(np.abs(E0))  # the m-blocked solve finds the same spectrum
+
+
+def test_pair_eigensolve_at_full_size(full):
+    """both spins' blocks (2 x 1380/1470/1380) in one batch: each spin's result satisfies its own eigen-equations, and the
+    alpha result equals the single-matrix solve"""
+    hf, S, H0, X, N, blocks = full["hf"], full["S"], full["H0"], full["X"], full["N"], full["blocks"]
+    rng = np.random.RandomState(2)
+    D = np.zeros((N, N))
+    for b in blocks:  # a perturbation that keeps the block structure
+        v = rng.standard_normal(len(b))
+        D[np.ix_(b, b)] = 0.05 * np.outer(v, v)
+    Fb = H0 + S @ D @ S
+    Ea, Ca, Eb, Cb = hf.scf.eig_gsym_sub_pair(H0, Fb, X, blocks)
+    assert np.max(np.abs(Ea - full["E"])) < 1e-10 * np.max(np.abs(Ea))
+    for F, E, C in ((H0, Ea, Ca), (Fb, Eb, Cb)):
+        SC = S @ C
+        assert np.all(np.diff(E) >= 0.0)
+        assert np.max(np.abs(C.T @ SC - np.eye(N))) < 1e-9
+        assert np.max(np.abs(F @ C - SC * E)) < 1e-9 * np.max(np.abs(E))
+    assert np.max(np.abs(Eb - Ea)) > 1e-6  # the second matrix really is another problem

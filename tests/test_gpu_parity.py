@@ -378,6 +378,41 @@ def test_edge_case_bases(hf):
         assert common.relerr(H, Ho) < 1e-10 and abs(Exc - Exco) < 1e-11 * max(1.0, abs(Exco)), kw
 
 
+def test_eig_gsym_sub_pair_equals_two_calls(hf):
+    """hfg_eig_gsym_sub_pair (both spins of an unrestricted iteration in one batch) against two eig_gsym_sub calls and the
+    oracle; eleven ragged blocks per matrix, so the batch is cut into groups of eight across the two matrices"""
+    import oracle_lib as orc
+    rng = np.random.RandomState(17)
+    sizes = [40, 1, 65, 2, 130, 7, 33, 5, 64, 3, 17]
+    N = sum(sizes)
+    perm = rng.permutation(N)
+    blocks, o = [], 0
+    for sz in sizes:
+        blocks.append(np.sort(perm[o:o + sz]))
+        o += sz
+    A = rng.standard_normal((N, N))
+    S = A @ A.T + N * np.eye(N)
+    Sb = np.zeros_like(S)
+    for b in blocks:
+        Sb[np.ix_(b, b)] = S[np.ix_(b, b)]
+    X = orc.form_Sinvh(Sb, False, blocks)
+    Fs = []
+    for k in range(2):
+        F = rng.standard_normal((N, N))
+        F = F + F.T
+        Fm = np.zeros_like(F)
+        for b in blocks:
+            Fm[np.ix_(b, b)] = F[np.ix_(b, b)]
+        Fs.append(Fm)
+    Ea, Ca, Eb, Cb = hf.scf.eig_gsym_sub_pair(Fs[0], Fs[1], X, blocks)
+    for F, E, C in ((Fs[0], Ea, Ca), (Fs[1], Eb, Cb)):
+        E1, C1 = hf.scf.eig_gsym_sub(F, X, blocks)
+        Eo, _ = orc.eig_gsym_sub(F, X, blocks)
+        assert np.max(np.abs(E - E1)) < 1e-12 * N and np.max(np.abs(E - Eo)) < 1e-10 * max(1.0, np.max(np.abs(Eo)))
+        assert np.max(np.abs(C.T @ Sb @ C - np.eye(N))) < 1e-9
+        assert np.max(np.abs(F @ C - Sb @ C * E)) < 1e-8 * max(1.0, np.max(np.abs(E)))
+
+
 def test_eig_gsym_sub_many_small_and_odd_blocks(hf):
     """ragged symmetry blocks (sizes 1, 2, odd; more than 8 blocks go through the batch in groups of 8) through eig_gsym_sub"""
     import oracle_lib as orc
