@@ -330,6 +330,28 @@ void eig_gsym_sub(const Context &ctx, Vec &E, Mat &C, const Mat &F, const Mat &S
   check(hfg_eig_gsym_sub(ctx.handle(), (int64_t)N, detail::data_of(F, 0), detail::data_of(Sinvh, 0), (int)m_idx.size(), ptr.data(), idx.data(),
                          detail::data_of(E, 0), detail::data_of(C, 0)));
 }
+/// the two eig_gsym_sub calls of an unrestricted iteration (diatomic/main.cpp:936-958) as one batch on the device
+/// (hfg_eig_gsym_sub_pair): in the reference's loop, replace
+///     scf::eig_gsym_sub(Ea,Ca,Fa,Sinvh,dsym); ... scf::eig_gsym_sub(Eb,Cb,Fb,Sinvh,dsym);
+/// by one call of this function -- the results are the same, the time is that of ONE call plus the matrix products
+template <class Vec, class Mat, class UVec>
+void eig_gsym_sub_pair(const Context &ctx, Vec &Ea, Mat &Ca, Vec &Eb, Mat &Cb, const Mat &Fa, const Mat &Fb, const Mat &Sinvh,
+                       const std::vector<UVec> &m_idx) {
+  const size_t N = Fa.n_rows;
+  if ((size_t)Fa.n_cols != N || (size_t)Fb.n_rows != N || (size_t)Fb.n_cols != N || (size_t)Sinvh.n_rows != N || (size_t)Sinvh.n_cols != N)
+    throw std::logic_error("eig_gsym_sub_pair: incompatible dimensions\n");
+  std::vector<int64_t> ptr(1, 0), idx;
+  for (const UVec &b : m_idx) {
+    for (size_t k = 0; k < detail::len_of(b, 0); k++) idx.push_back((int64_t)detail::data_of(b, 0)[k]);
+    ptr.push_back((int64_t)idx.size());
+  }
+  detail::set_len(Ea, N, 0);
+  detail::set_len(Eb, N, 0);
+  Ca = Mat(N, N);
+  Cb = Mat(N, N);
+  check(hfg_eig_gsym_sub_pair(ctx.handle(), (int64_t)N, detail::data_of(Fa, 0), detail::data_of(Fb, 0), detail::data_of(Sinvh, 0), (int)m_idx.size(),
+                              ptr.data(), idx.data(), detail::data_of(Ea, 0), detail::data_of(Ca, 0), detail::data_of(Eb, 0), detail::data_of(Cb, 0)));
+}
 /// TwoDBasis::Sinvh (basis.cpp:627) -> utils::invh per symmetry block
 template <class Mat, class UVec>
 Mat form_Sinvh(const Context &ctx, const Mat &S, bool chol, const std::vector<UVec> &m_idx) {
