@@ -1139,14 +1139,13 @@ static int trd_tail_order() {
   return mode == 0 ? 0 : (mode == 1 ? TT_MAX : TR_MAX);
 }
 
-static int trd_num_cus(hfg_ctx *ctx) {
-  static int ncu = 0;
-  if (!ncu && getenv("HELFEM_TRDF_SYM_MIN")) ncu = atoi(getenv("HELFEM_TRDF_SYM_MIN"));  // A/B runs: switch-over tile count
-  if (!ncu) {
-    hipDeviceProp_t prop;
-    ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return ncu;
+// Switch-over tile count of the symmetric sweep: panels whose full grid has more tiles than this run in symmetric mode.
+// Default 0 = every panel: measured (bench workload, HELFEM_TRDF_SYM_MIN = 16 ... 300 and "always") the step time does
+// not depend on it once the panels that exceed the CU count are symmetric, and sweeping one triangle everywhere halves
+// the sweep's HBM traffic (PMC: 14.4 MB -> what the algorithm needs, one triangle plus the diagonal tiles).
+static int trd_sym_min_tiles(hfg_ctx *) {
+  static const int v = getenv("HELFEM_TRDF_SYM_MIN") ? atoi(getenv("HELFEM_TRDF_SYM_MIN")) : 0;
+  return v;
 }
 
 struct TrdWork {
@@ -1271,7 +1270,7 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
       {
         const int m0 = nmax - j0 - 1;
         const long full = (long)((m0 + 1 + TF_T - 1) / TF_T) * std::max(1, (m0 + TF_T - 1) / TF_T) * nblk;
-        symm = (force_sym >= 0) ? (force_sym != 0) : (full > trd_num_cus(ctx));
+        symm = (force_sym >= 0) ? (force_sym != 0) : (full > trd_sym_min_tiles(ctx));
       }
       for (int i = j0; i <= jend; i++) {
         const int sweep = ((i < jend) ? 1 : 0) | (symm ? 16 : 0);  // the last launch of the panel only finishes column jend-1
@@ -1382,7 +1381,7 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
       {
         const int m0 = nmax - (i - c) - 1;  // the panel's first column decides, as in the factorisation
         const long full = (long)((m0 + 1 + TF_T - 1) / TF_T) * std::max(1, (m0 + TF_T - 1) / TF_T) * nblk;
-        symm = (force_sym >= 0) ? (force_sym != 0) : (full > trd_num_cus(ctx));
+        symm = (force_sym >= 0) ? (force_sym != 0) : (full > trd_sym_min_tiles(ctx));
       }
       const int grid = symm ? nrt * (nrt + 1) / 2 : nrt * ncs;
       const int sw = 1 | ((dbg & 7) << 1) | (symm ? 16 : 0);
