@@ -141,7 +141,9 @@ struct GemmTask {
   int tA = 0, tB = 0;  // op(A), op(B) transposed (k_dgemm_tasklist only)
   double alpha = 1.0, beta = 0.0;  // C = alpha op(A) op(B) + beta C (k_dgemm_tasklist only)
   int sym = 0;  // the product is known to be symmetric (M == N, e.g. X^T (F X)): only the tiles on and below the diagonal
-                // are enumerated and computed (k_dgemm_tasklist with beta == 0), k_mirror_lower fills the rest
+                // are enumerated and computed (k_dgemm_tasklist with beta == 0), k_mirror_lower fills the rest.
+                // 2 (accumulating task lists): only the lower triangle of C and a band of three tile rows above the
+                // diagonal are read afterwards, the other tiles are skipped
   int pad_ = 0;  // no padding bytes: task lists are compared bytewise (upload_cached)
 };
 static_assert(sizeof(GemmTask) == 80, "GemmTask is compared bytewise: keep it free of padding");

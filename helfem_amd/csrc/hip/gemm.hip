@@ -60,13 +60,14 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
   // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
   // contiguous strip of tiles (they share A row panels / B column panels in that XCD's L2)
   int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
-  int nwg = sym ? nbm * (nbm + 1) / 2 : nbm * nbn;
+  const bool lower = !ACC && sym == 1;  // enumerate the lower tiles only
+  int nwg = lower ? nbm * (nbm + 1) / 2 : nbm * nbn;
   {
     int q = nwg / 8, r = nwg % 8, xcd = id % 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
   }
   int bm = (id % nbm) * BM, bn = (id / nbm) * BN;
-  if (sym) {
+  if (lower) {
     // symmetric product (BM == BN, M == N): the grid enumerates the tiles on and below the diagonal only (id counts
     // them row by row: id = i (i + 1) / 2 + j, j <= i); k_mirror_lower fills the upper triangle afterwards.  Skipping
     // the upper tiles of a full grid instead leaves their CU slots empty while other CUs still hold two tiles.
@@ -79,6 +80,12 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
     bn = tj * BN;
   }
 
+  if constexpr (ACC) {
+    // accumulating updates of a matrix of which only the lower triangle and a band above the diagonal are read afterwards
+    // (sym == 2: the symmetric sweep of the tridiagonalisation, trd.hip): tiles more than three tile rows above the
+    // diagonal are left alone
+    if (sym == 2 && bm / BM + 3 < bn / BN) return;
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = (wave & 1) * WM, wn = (wave >> 1) * WN;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -334,9 +341,9 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__res
   __shared__ __attribute__((aligned(16))) double Bs[2][16][BN + 16];
   const GemmTask t = tasks[blockIdx.y];
   if (t.M <= 0 || t.N <= 0) return;
-  const int sym = (!ACC && BM == BN && t.M == t.N && t.beta == 0.0) ? t.sym : 0;
+  const int sym = (!ACC && BM == BN && t.M == t.N && t.beta == 0.0) ? (t.sym == 1) : ((ACC && t.sym == 2) ? 2 : 0);
   const int nbm = (t.M + BM - 1) / BM;
-  const int nt = sym ? nbm * (nbm + 1) / 2 : nbm * ((t.N + BN - 1) / BN);
+  const int nt = (sym == 1) ? nbm * (nbm + 1) / 2 : nbm * ((t.N + BN - 1) / BN);
   if ((int)blockIdx.x >= nt) return;
   dgemm_tile<BM, BN, ACC, MF>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc,
                               As, Bs, sym);
@@ -369,7 +376,7 @@ void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int
 __global__ __launch_bounds__(256) void k_mirror_lower(const GemmTask *__restrict__ tasks) {
   __shared__ double tile[64][65];
   const GemmTask t = tasks[blockIdx.y];
-  if (!t.sym || t.M <= 0 || t.M != t.N) return;
+  if (t.sym != 1 || t.M <= 0 || t.M != t.N) return;
   const int nb = (t.M + 63) / 64;
   // strictly-lower block (bi > bj) number blockIdx.x
   int bi = (int)((1.0 + sqrt(1.0 + 8.0 * (double)blockIdx.x)) * 0.5);

@@ -1226,6 +1226,10 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
   w.last_fused = fused;
   // fused variant: the trailing updates A22 -= [V|W][W|V]^T of all blocks of a full panel are one task-list launch
   const int npanel = (nmax - 3) / TB_NB + 1;
+  static const int force_sym0 = getenv("HELFEM_TRDF_SYM") ? atoi(getenv("HELFEM_TRDF_SYM")) : -1;
+  static const bool band_off = getenv("HELFEM_TRD_BAND_UPDATE") && atoi(getenv("HELFEM_TRD_BAND_UPDATE")) == 0;
+  static const bool acc128 = getenv("HELFEM_ACC_TILE") && atoi(getenv("HELFEM_ACC_TILE")) == 128;
+  const bool band_update = !band_off && !acc128 && (force_sym0 >= 0 ? force_sym0 != 0 : trd_sym_min_tiles(ctx) == 0);
   if (fused) {
     std::vector<GemmTask> pt((size_t)npanel * nblk);
     for (int pi = 0; pi < npanel; pi++)
@@ -1248,6 +1252,10 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
           g.tB = 1;
           g.alpha = -1.0;
           g.beta = 1.0;
+          // every later sweep is symmetric: it reads the tiles on and below the diagonal of its own 128-partition, whose
+          // origin moves by up to 17 within a panel -- at most 144 columns right of the diagonal, i.e. inside the band of
+          // three 64-tile rows that the update keeps; so does the 192 x 192 block handed to the tail kernel
+          g.sym = band_update ? 2 : 0;
         }
         pt[(size_t)pi * nblk + k] = g;
       }
