@@ -1363,12 +1363,22 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
   int nmax = 0;
   for (int n : w.last_ns) nmax = std::max(nmax, n);
   hipStream_t s = ctx->stream;
+  // HELFEM_TRD_GRAPH=1 (measurement only): the same launches captured into a hipGraph on a private stream and replayed
+  // as ONE graph launch -- does the command processor chain dependent kernels faster than a stream of launches?
+  static const bool use_graph = getenv("HELFEM_TRD_GRAPH") && atoi(getenv("HELFEM_TRD_GRAPH")) != 0;
+  hipStream_t cap = nullptr;
+  if (use_graph) {
+    HFG_HIP_CHECK(hipStreamSynchronize(s));
+    HFG_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    HFG_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    s = cap;
+  }
   const TrdBatch *db = w.desc.p;
   size_t shb = (size_t)(nmax + 4 * 128 + 8) * sizeof(double);
   hipEvent_t e0, e1;
   HFG_HIP_CHECK(hipEventCreate(&e0));
   HFG_HIP_CHECK(hipEventCreate(&e1));
-  HFG_HIP_CHECK(hipEventRecord(e0, s));
+  if (!use_graph) HFG_HIP_CHECK(hipEventRecord(e0, s));
   int count = 0;
   int j_tail = nmax;  // the columns of the LDS-resident tail are not launches of this kernel
   if (w.last_fused && trd_tail_order() > 0 && nmax >= 3) {
@@ -1402,8 +1412,24 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
     }
     count++;
   }
-  HFG_HIP_CHECK(hipEventRecord(e1, s));
-  HFG_HIP_CHECK(hipEventSynchronize(e1));
+  if (use_graph) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HFG_HIP_CHECK(hipStreamEndCapture(cap, &graph));
+    HFG_HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HFG_HIP_CHECK(hipGraphLaunch(exec, cap));  // warm-up (uploads the graph)
+    HFG_HIP_CHECK(hipStreamSynchronize(cap));
+    HFG_HIP_CHECK(hipEventRecord(e0, cap));
+    HFG_HIP_CHECK(hipGraphLaunch(exec, cap));
+    HFG_HIP_CHECK(hipEventRecord(e1, cap));
+    HFG_HIP_CHECK(hipEventSynchronize(e1));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    (void)hipStreamDestroy(cap);
+  } else {
+    HFG_HIP_CHECK(hipEventRecord(e1, s));
+    HFG_HIP_CHECK(hipEventSynchronize(e1));
+  }
   float t = 0.f;
   HFG_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
   (void)hipEventDestroy(e0);
