@@ -338,6 +338,138 @@ __global__ void k_exl_RB(const double *__restrict__ V0, const double *__restrict
   }
 }
 
+// The same RB blocks, four shells j against four shells k per workgroup: the factors of the eight shells are staged once
+// for sixteen shell pairs (512 threads: staging with four rounds of loads in flight), and a thread (i', l') of each half
+// keeps 4 x 2 pairs x 4 type combinations = 32 sums in registers -- 13 LDS reads per 32 FMAs instead of 5 per 4.  (The
+// one-pair kernel above moves 20 KB from L2 into LDS per pair and is bound by the LDS port: 14 TFLOP/s.)
+constexpr int EXL_SB = 4;  // shells per side of a block
+constexpr int EXL_CK = 24;  // (channel, factor) columns staged at a time: 2 * 4 shells * 2 types * 24 * p doubles of LDS
+__global__ __launch_bounds__(512) void k_exl_RB4(const double *__restrict__ V0, const double *__restrict__ V2,
+                                                 const int *__restrict__ tab_ch_off, const int *__restrict__ tab_ch,
+                                                 const double *__restrict__ LM_fac, const double *__restrict__ sgn,
+                                                 const int *__restrict__ S_off, const int *__restrict__ S_list,
+                                                 const long long *__restrict__ rb_off, int tau0, int Nd, int R, int E, int p, int r,
+                                                 int ntt, double *__restrict__ RB) {
+  extern __shared__ double sh[];  // vj[SB][2][CK][p], vk[SB][2][CK][p], w[CK]
+  const int e = blockIdx.y;
+  const int tau = tau0 + blockIdx.z;
+  if (rb_off[tau] < 0) return;
+  const int ns = S_off[tau + 1] - S_off[tau];
+  const int nb = (ns + EXL_SB - 1) / EXL_SB;
+  const int nblk = nb * (nb + 1) / 2;
+  if ((int)blockIdx.x >= nblk) return;
+  int bk = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((bk + 1) * (bk + 2) / 2 <= (int)blockIdx.x) bk++;
+  while (bk * (bk + 1) / 2 > (int)blockIdx.x) bk--;
+  const int bj = blockIdx.x - bk * (bk + 1) / 2;  // bj <= bk
+  const int c0 = tab_ch_off[tau], nch = tab_ch_off[tau + 1] - c0;
+  const int nco = nch * r;
+  const bool two = (ntt == 4);
+  const int half_slab = EXL_CK * p, slab = 2 * half_slab;  // doubles per type / per shell
+  double *vj = sh, *vk = sh + EXL_SB * slab, *w = sh + 2 * EXL_SB * slab;
+  const int pp = p * p, Kt = ntt * pp;
+  const int npair = ns * (ns + 1) / 2;
+  // the two halves of the 512 threads take two of the four k shells each: thread (i', l') of a half keeps 4 x 2 pairs x
+  // 4 type combinations = 32 sums across the chunks (one (i', l') per thread: p <= 16)
+  constexpr int KB = EXL_SB / 2;
+  const int half = threadIdx.x >> 8, il = threadIdx.x & 255;
+  const bool act = il < pp;
+  const int ip = act ? il % p : 0, lp = act ? il / p : 0;
+  double acc[EXL_SB][KB][4];
+#pragma unroll
+  for (int a = 0; a < EXL_SB; a++)
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[a][b][q] = 0.0;
+  const double *vkh = vk + (size_t)half * KB * slab;
+  for (int cb = 0; cb < nco; cb += EXL_CK) {
+    const int nck = min(EXL_CK, nco - cb);
+    if (cb) __syncthreads();  // the previous chunk has been consumed
+    // staging: four rounds of loads in flight per thread (a rolled "load, store to LDS" loop pays one L2 round trip per round)
+    {
+      const int total = EXL_SB * nck * p;
+      constexpr int UN = 4;
+      for (int t0 = threadIdx.x; t0 < total; t0 += UN * blockDim.x) {
+        double a0[UN], a2[UN], b0[UN], b2[UN];
+        int at[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+          const int t = t0 + u * blockDim.x;
+          const bool in = t < total;
+          const int tt = in ? t : 0;
+          const int ii = tt % p, cl = (tt / p) % nck, sidx = tt / (p * nck);
+          const int co = cb + cl;
+          const int c = tab_ch[c0 + co / r], o = co % r;
+          const int nn = e * (p - 1) + ii;
+          const size_t col = (size_t)c * r + o;
+          const int pj = EXL_SB * bj + sidx, pk = EXL_SB * bk + sidx;
+          const bool okj = in && nn < R && pj < ns, okk = in && nn < R && pk < ns;
+          const int j = S_list[S_off[tau] + min(pj, ns - 1)], k = S_list[S_off[tau] + min(pk, ns - 1)];
+          const size_t oj = col * Nd + (size_t)j * R + min(nn, R - 1), ok_ = col * Nd + (size_t)k * R + min(nn, R - 1);
+          at[u] = in ? sidx * slab + cl * p + ii : -1;
+          a0[u] = V0[oj];
+          b0[u] = V0[ok_];
+          a2[u] = two ? V2[oj] : 0.0;
+          b2[u] = two ? V2[ok_] : 0.0;
+          if (!okj) a0[u] = a2[u] = 0.0;
+          if (!okk) b0[u] = b2[u] = 0.0;
+          if (in && ii == 0 && sidx == 0) w[cl] = LM_fac[c] * sgn[o];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+          if (at[u] >= 0) {
+            vj[at[u]] = a0[u];
+            vk[at[u]] = b0[u];
+            vj[at[u] + half_slab] = a2[u];
+            vk[at[u] + half_slab] = b2[u];
+          }
+      }
+    }
+    __syncthreads();
+    if (act)
+      for (int cl = 0; cl < nck; cl++) {
+        const double wc = w[cl];
+        double wa0[EXL_SB], wa2[EXL_SB], x0[KB], x2[KB];
+#pragma unroll
+        for (int a = 0; a < EXL_SB; a++) {
+          wa0[a] = wc * vj[a * slab + cl * p + ip];
+          wa2[a] = two ? wc * vj[a * slab + half_slab + cl * p + ip] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < KB; b++) {
+          x0[b] = vkh[b * slab + cl * p + lp];
+          x2[b] = two ? vkh[b * slab + half_slab + cl * p + lp] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < EXL_SB; a++)
+#pragma unroll
+          for (int b = 0; b < KB; b++) {
+            acc[a][b][0] += wa0[a] * x0[b];
+            acc[a][b][1] += wa0[a] * x2[b];
+            acc[a][b][2] += wa2[a] * x0[b];
+            acc[a][b][3] += wa2[a] * x2[b];
+          }
+      }
+  }
+  if (!act) return;
+#pragma unroll
+  for (int a = 0; a < EXL_SB; a++)
+#pragma unroll
+    for (int b = 0; b < KB; b++) {
+      const int pj = EXL_SB * bj + a, pk = EXL_SB * bk + half * KB + b;
+      if (pj > pk || pk >= ns) continue;  // only pj <= pk is stored (K is symmetric)
+      const int n = pk * (pk + 1) / 2 + pj;
+      double *out = RB + rb_off[tau] + ((size_t)e * npair + n) * Kt;
+      out[il] = acc[a][b][0];
+      if (two) {
+        out[pp + il] = -acc[a][b][1];
+        out[2 * pp + il] = -acc[a][b][2];
+        out[3 * pp + il] = acc[a][b][3];
+      }
+    }
+}
+
 // Element-pair variant for kernels that do not factorise over elements (erfc, TwoDBasis.cpp:1262): one block per
 // (e >= f) and ORDERED shell pair,
 //   RB_tau,ef[(tt, i', l'), (pj, pk)] = sign_tt sum_{c in tau} sum_o w V^t[(c,o)][(j,e,i')] V^t'[(c,o)][(k,f,l')]
@@ -636,7 +768,11 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   if (!reproduced) return false;
   int rmax_g = 0;
   for (int r : rg) rmax_g = std::max(rmax_g, r);
-  if ((size_t)(4 * a.max_nch * rmax_g * p + a.max_nch * rmax_g) * sizeof(double) > 150 * 1024) return false;  // LDS tile of k_exl_RB
+  {
+    // the one-pair kernels (erfc pair tables, p > 16, HELFEM_EXL_RB=1) stage all (channel, factor) columns at once
+    const bool one_pair = t->pair_tei || p > 16 || (getenv("HELFEM_EXL_RB") && atoi(getenv("HELFEM_EXL_RB")) == 1);
+    if (one_pair && (size_t)(4 * a.max_nch * rmax_g * p + a.max_nch * rmax_g) * sizeof(double) > 150 * 1024) return false;
+  }
   if (rmax_g == 0) {  // P == 0
     HFG_HIP_CHECK(hipMemsetAsync(dK, 0, sizeof(double) * (size_t)N * N, s));
     return true;
@@ -767,10 +903,21 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
         hipLaunchKernelGGL(k_exl_RB_pair, dim3(max_ns * max_ns, E * (E + 1) / 2, nz), dim3(256), shb, s, a.V0.p, a.V2.p,
                            a.tab_ch_off.p, a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E,
                            p, r, ntt, a.RB.p);
-      else
-        hipLaunchKernelGGL(k_exl_RB, dim3(max_ns * (max_ns + 1) / 2, E, nz), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
-                           a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,
-                           a.RB.p);
+      else {
+        static const bool rb_one = getenv("HELFEM_EXL_RB") && atoi(getenv("HELFEM_EXL_RB")) == 1;  // the one-pair kernel (checker)
+        const size_t shb4 = (size_t)(4 * EXL_SB * EXL_CK * p + EXL_CK) * sizeof(double);
+        if (rb_one || p > 16)
+          hipLaunchKernelGGL(k_exl_RB, dim3(max_ns * (max_ns + 1) / 2, E, nz), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
+                             a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,
+                             a.RB.p);
+        else {
+          if (shb4 > 64 * 1024)
+            HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_RB4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb4));
+          const int nb = (max_ns + EXL_SB - 1) / EXL_SB;
+          hipLaunchKernelGGL(k_exl_RB4, dim3(nb * (nb + 1) / 2, E, nz), dim3(512), shb4, s, a.V0.p, a.V2.p, a.tab_ch_off.p, a.tab_ch.p,
+                             t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt, a.RB.p);
+        }
+      }
     }
     gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
   }
