@@ -625,6 +625,10 @@ OPEN_SHELL_CASES = [
                                               occs=[[1, 1, 0, 0], [1, 0, 1, 1], [0, 0, 1, 0], [0, 0, 1, -1]]), -7.365070, 5e-5),
     ("HeH_pi_forced", "diatomic", dict(Z1=2, Z2=1, Rbond=1.5, lmmax=[4, 3], nelem=2, nnodes=8, method="HF", M=2,
                                        occs=[[1, 1, 0], [1, 0, 1], [0, 0, -1]]), None, None),
+    # homonuclear molecule with --symmetry 2: occupations by m AND parity (fourth column +-1, main.cpp:352-365): the
+    # 1 sigma_g 2 sigma_g triplet of H2 (not the Aufbau state, which is sigma_g sigma_u)
+    ("H2_triplet_forced_parity", "diatomic", dict(Z1=1, Z2=1, Rbond=2.0, lmmax=[6], nelem=3, nnodes=10, method="HF", M=3, symmetry=2,
+                                                  occs=[[2, 0, 0, 1], [0, 0, 0, -1]]), None, None),
     ("N_LSD_maverage", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=4, nnodes=10, method="lda_x-lda_c_vwn", M=4, maverage=True),
      None, None),
     ("H_PBE0", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh", M=2), None, None),
