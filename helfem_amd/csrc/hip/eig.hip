@@ -1191,6 +1191,36 @@ void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, i
   ctx->shard_n = save_n;
 }
 
+/// column supports of the symmetry blocks of a block-structured Sinvh (scf_helpers.cpp:150-157): cols[blk_ptr[ib] ...] =
+/// the columns with support on block ib's rows, ascending; throws like eig_blocks_dev when Sinvh is not block structured
+void eig_block_supports(hfg_ctx *ctx, int N, const double *dS, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
+                        std::vector<int64_t> &cols) {
+  hipStream_t s = ctx->stream;
+  DevBuf<int64_t> drows;
+  DevBuf<int> flag;
+  drows.resize(N);
+  flag.resize((size_t)N * nblk + 8);
+  HFG_HIP_CHECK(hipMemcpyAsync(drows.p, blk_idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
+  for (int ib = 0; ib < nblk; ib++) {
+    const int n = (int)(blk_ptr[ib + 1] - blk_ptr[ib]);
+    hipLaunchKernelGGL(k_col_support, dim3(N), dim3(256), 0, s, dS, N, drows.p + blk_ptr[ib], n, flag.p + (size_t)ib * N);
+  }
+  std::vector<int> hflag((size_t)N * nblk);
+  HFG_HIP_CHECK(hipMemcpyAsync(hflag.data(), flag.p, sizeof(int) * hflag.size(), hipMemcpyDeviceToHost, s));
+  HFG_HIP_CHECK(hipStreamSynchronize(s));
+  cols.clear();
+  for (int ib = 0; ib < nblk; ib++) {
+    int cnt = 0;
+    for (int c = 0; c < N; c++)
+      if (hflag[(size_t)ib * N + c]) {
+        cols.push_back(c);
+        cnt++;
+      }
+    if (cnt != (int)(blk_ptr[ib + 1] - blk_ptr[ib]))
+      throw std::logic_error("eig_gsym_sub: Sinvh is not block structured (columns with support != block size)\n");
+  }
+}
+
 // scf::eig_gsym_sub for the two spin matrices of an unrestricted iteration in one batch (diatomic/main.cpp:936-958 calls
 // it twice in a row with the same Sinvh and symmetry blocks)
 void eig_gsym_sub_pair_dev(hfg_ctx *ctx, int N, const double *dFa, const double *dFb, const double *dS, int nblk, const int64_t *blk_ptr,

@@ -30,6 +30,9 @@ void form_sinvh_dev(hfg_ctx *ctx, int N, const double *dS, bool chol, int nblk, 
                     const int64_t *blk_idx, double *dSinvh);
 void form_density_dev(hfg_ctx *ctx, int N, int ncols, const double *dC, int nocc, double *dP);
 void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
+void eig_block_supports(hfg_ctx *ctx, int N, const double *dS, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
+                        std::vector<int64_t> &cols);
+void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void eig_gsym_sub_pair_dev(hfg_ctx *ctx, int N, const double *dFa, const double *dFb, const double *dS, int nblk, const int64_t *blk_ptr,
                            const int64_t *blk_idx, double *dEa, double *dCa, double *dEb, double *dCb);
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
@@ -56,6 +59,18 @@ __global__ void k_antisym(const double *__restrict__ X, int N, double *__restric
   if (i >= N) return;
   E[(size_t)j * N + i] = X[(size_t)j * N + i] - X[(size_t)i * N + j];
 }
+// out (n x n, column-major) = M(rows, cols) of an N x N matrix
+__global__ void k_gather_rc(const double *__restrict__ M, int N, const int64_t *__restrict__ rows, const int64_t *__restrict__ cols, int n,
+                            double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < n) out[(size_t)j * n + i] = M[(size_t)cols[j] * N + rows[i]];
+}
+// E = X - X^T for a block of order n
+__global__ void k_antisym_block(const double *__restrict__ X, int n, double *__restrict__ E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < n) E[(size_t)j * n + i] = X[(size_t)j * n + i] - X[(size_t)i * n + j];
+}
+
 // F(i,j) = 0 when i and j belong to different symmetry blocks   (scf::enforce_fock_symmetry, scf_helpers.cpp:249)
 __global__ void k_mask_blocks(double *__restrict__ F, int N, const int *__restrict__ blockid) {
   int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
@@ -187,6 +202,103 @@ struct DevSCF {
     hipLaunchKernelGGL(k_antisym, dim3((n + 255) / 256, n), dim3(256), 0, s, T2.p, n, T1.p);
     gemm_dev(ctx, true, false, n, n, n, 1.0, Sinvh.p, n, T1.p, n, 0.0, T2.p, n);
     gemm_dev(ctx, false, false, n, n, n, 1.0, T2.p, n, Sinvh.p, n, 0.0, err, n);
+  }
+
+  // The same error for block-diagonal F, P, S (symmetry-enforced Fock matrix, block-confined orbitals) and a
+  // block-structured Sinvh: per symmetry block e_b = X_b^T (F_b P_b S_b - S_b P_b F_b) X_b with X_b = Sinvh(idx_b, cols_b).
+  // The full product is these blocks in the ordering of Sinvh's columns and zeros elsewhere; the mixer only takes inner
+  // products and the largest element of the error, so the blocks are stored one after the other at the head of the error
+  // buffer (the rest is zeroed).  Four task-list launches with nspin * nblk tasks each instead of four N^3 products:
+  // 9 times fewer flops for three equal blocks.
+  struct BlockedErr {
+    bool on = false;
+    int nblk = 0, nspin = 0, nmax = 0;
+    std::vector<int> ns;
+    std::vector<size_t> eoff;  // offset of block b in the error buffer
+    size_t etot = 0;
+    DevBuf<int64_t> rows, cols;
+    std::vector<int64_t> ptr;
+    DevBuf<double> Sb, Xb, Fb, Pb, T1b, T2b;  // [spin][block] slots of nmax^2 (Sb, Xb: [block])
+    DevBuf<GemmTask> tasks;                   // 4 stages x nspin x nblk
+  } be;
+  void blocked_error_setup(int nspin, const std::vector<int64_t> &ptr, const std::vector<int64_t> &idx) {
+    const int nblk = (int)ptr.size() - 1;
+    std::vector<int64_t> cols;
+    eig_block_supports(ctx, (int)N, Sinvh.p, nblk, ptr.data(), idx.data(), cols);
+    be.nblk = nblk;
+    be.nspin = nspin;
+    be.ptr = ptr;
+    be.ns.resize(nblk);
+    be.eoff.resize(nblk);
+    be.nmax = 0;
+    be.etot = 0;
+    for (int b = 0; b < nblk; b++) {
+      be.ns[b] = (int)(ptr[b + 1] - ptr[b]);
+      be.nmax = std::max(be.nmax, be.ns[b]);
+      be.eoff[b] = be.etot;
+      be.etot += (size_t)be.ns[b] * be.ns[b];
+    }
+    be.rows.upload(idx, s);
+    be.cols.upload(cols, s);
+    const size_t sl = (size_t)be.nmax * be.nmax;
+    be.Sb.resize(sl * nblk);
+    be.Xb.resize(sl * nblk);
+    for (DevBuf<double> *q : {&be.Fb, &be.Pb, &be.T1b, &be.T2b}) q->resize(sl * nblk * nspin);
+    HFG_HIP_CHECK(hipStreamSynchronize(s));  // idx / cols are the caller's vectors
+    for (int b = 0; b < nblk; b++) {
+      const int nb = be.ns[b];
+      dim3 g((nb + 255) / 256, nb);
+      hipLaunchKernelGGL(k_gather_rc, g, dim3(256), 0, s, S.p, (int)N, be.rows.p + ptr[b], be.rows.p + ptr[b], nb, be.Sb.p + sl * b);
+      hipLaunchKernelGGL(k_gather_rc, g, dim3(256), 0, s, Sinvh.p, (int)N, be.rows.p + ptr[b], be.cols.p + ptr[b], nb, be.Xb.p + sl * b);
+    }
+    be.on = true;
+  }
+  // errs[sp]: where the error of spin sp goes (N*N doubles each); F, P: the spins' matrices
+  void blocked_error(const double *const *F, const double *const *P, double *const *errs) {
+    const size_t sl = (size_t)be.nmax * be.nmax;
+    const int nt = be.nspin * be.nblk;
+    std::vector<GemmTask> t((size_t)4 * nt);
+    for (int sp = 0; sp < be.nspin; sp++) {
+      HFG_HIP_CHECK(hipMemsetAsync(errs[sp], 0, sizeof(double) * NN, s));
+      for (int b = 0; b < be.nblk; b++) {
+        const int nb = be.ns[b], k = sp * be.nblk + b;
+        dim3 g((nb + 255) / 256, nb);
+        hipLaunchKernelGGL(k_gather_rc, g, dim3(256), 0, s, F[sp], (int)N, be.rows.p + be.ptr[b], be.rows.p + be.ptr[b], nb, be.Fb.p + sl * k);
+        hipLaunchKernelGGL(k_gather_rc, g, dim3(256), 0, s, P[sp], (int)N, be.rows.p + be.ptr[b], be.rows.p + be.ptr[b], nb, be.Pb.p + sl * k);
+        GemmTask q;
+        q.M = q.N = q.K = nb;
+        q.lda = q.ldb = q.ldc = nb;
+        q.A = be.Fb.p + sl * k;  // T1 = F P
+        q.B = be.Pb.p + sl * k;
+        q.C = be.T1b.p + sl * k;
+        t[0 * nt + k] = q;
+        q.A = be.T1b.p + sl * k;  // T2 = T1 S
+        q.B = be.Sb.p + sl * b;
+        q.C = be.T2b.p + sl * k;
+        t[1 * nt + k] = q;
+        q.A = be.Xb.p + sl * b;  // T2 = X^T A   (A = T2 - T2^T lives in T1 by then)
+        q.tA = 1;
+        q.B = be.T1b.p + sl * k;
+        q.C = be.T2b.p + sl * k;
+        t[2 * nt + k] = q;
+        q.tA = 0;
+        q.A = be.T2b.p + sl * k;  // e = T2 X, straight into the error buffer
+        q.B = be.Xb.p + sl * b;
+        q.C = errs[sp] + be.eoff[b];
+        t[3 * nt + k] = q;
+      }
+    }
+    be.tasks.upload(t, s);
+    HFG_HIP_CHECK(hipStreamSynchronize(s));  // t lives on this stack frame
+    gemm_tasklist_dev(ctx, be.tasks.p, nt, be.nmax, be.nmax);
+    gemm_tasklist_dev(ctx, be.tasks.p + nt, nt, be.nmax, be.nmax);
+    for (int sp = 0; sp < be.nspin; sp++)
+      for (int b = 0; b < be.nblk; b++) {
+        const int nb = be.ns[b], k = sp * be.nblk + b;
+        hipLaunchKernelGGL(k_antisym_block, dim3((nb + 255) / 256, nb), dim3(256), 0, s, be.T2b.p + sl * k, nb, be.T1b.p + sl * k);
+      }
+    gemm_tasklist_dev(ctx, be.tasks.p + 2 * nt, nt, be.nmax, be.nmax);
+    gemm_tasklist_dev(ctx, be.tasks.p + 3 * nt, nt, be.nmax, be.nmax);
   }
 };
 
@@ -428,6 +540,11 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
 
   // ADIIS + CDIIS weights of the reference (diis.cpp:214-290) on the host from inner products of the stored matrices;
   // the restricted driver counts its one spin twice, as the reference does by passing Fa = Fb, Pa = Pb to uDIIS
+  // DIIS error by symmetry blocks when every matrix in it is block diagonal (not with the CUHF constraint, whose lambda
+  // comes from natural orbitals of the whole density); HELFEM_DIIS_BLOCKS=0 keeps the four dense N^3 products (checker)
+  static const bool blocks_off = getenv("HELFEM_DIIS_BLOCKS") && atoi(getenv("HELFEM_DIIS_BLOCKS")) == 0;
+  const bool blocked_err = symm != 0 && dsym.size() > 1 && !rohf && !blocks_off;
+  if (blocked_err) d.blocked_error_setup(nspin, ptr, idx);
   helfem::DiisMixer mixer(true, opt.diiseps, opt.diisthr, true, verbose, (size_t)order);
   const double spinfac = restr ? 2.0 : 1.0;
   std::deque<int> slots;  // ring slots in age order
@@ -536,9 +653,14 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       }
     }
     slots.push_back(slot);
+    if (blocked_err) {
+      const double *Fs[2] = {d.Fa.p, nspin == 2 ? d.Fb.p : nullptr}, *Ps[2] = {d.Pa.p, nspin == 2 ? d.Pb.p : nullptr};
+      double *Es[2] = {d.histE[slot].p, d.histE[slot].p + NN};
+      d.blocked_error(Fs, Ps, Es);
+    }
     for (int sp = 0; sp < nspin; sp++) {
       double *F = sp ? d.Fb.p : d.Fa.p;
-      d.diis_error(F, sp ? d.Pb.p : d.Pa.p, d.histE[slot].p + sp * NN);
+      if (!blocked_err) d.diis_error(F, sp ? d.Pb.p : d.Pa.p, d.histE[slot].p + sp * NN);
       HFG_HIP_CHECK(hipMemcpyAsync(d.histF[slot].p + sp * NN, F, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
       HFG_HIP_CHECK(hipMemcpyAsync(d.histP[slot].p + sp * NN, sp ? d.Pb.p : d.Pa.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
     }
