@@ -207,8 +207,8 @@ struct DevSCF {
   // The same error for block-diagonal F, P, S (symmetry-enforced Fock matrix, block-confined orbitals) and a
   // block-structured Sinvh: per symmetry block e_b = X_b^T (F_b P_b S_b - S_b P_b F_b) X_b with X_b = Sinvh(idx_b, cols_b).
   // The full product is these blocks in the ordering of Sinvh's columns and zeros elsewhere; the mixer only takes inner
-  // products and the largest element of the error, so the blocks are stored one after the other at the head of the error
-  // buffer (the rest is zeroed).  Four task-list launches with nspin * nblk tasks each instead of four N^3 products:
+  // products and the largest element of the error, so the blocks of both spins are stored one after the other at the head
+  // of the error buffer and the inner products run over that part only.  Four task-list launches with nspin * nblk tasks each instead of four N^3 products:
   // 9 times fewer flops for three equal blocks.
   struct BlockedErr {
     bool on = false;
@@ -259,7 +259,6 @@ struct DevSCF {
     const int nt = be.nspin * be.nblk;
     std::vector<GemmTask> t((size_t)4 * nt);
     for (int sp = 0; sp < be.nspin; sp++) {
-      HFG_HIP_CHECK(hipMemsetAsync(errs[sp], 0, sizeof(double) * NN, s));
       for (int b = 0; b < be.nblk; b++) {
         const int nb = be.ns[b], k = sp * be.nblk + b;
         dim3 g((nb + 255) / 256, nb);
@@ -655,7 +654,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     slots.push_back(slot);
     if (blocked_err) {
       const double *Fs[2] = {d.Fa.p, nspin == 2 ? d.Fb.p : nullptr}, *Ps[2] = {d.Pa.p, nspin == 2 ? d.Pb.p : nullptr};
-      double *Es[2] = {d.histE[slot].p, d.histE[slot].p + NN};
+      double *Es[2] = {d.histE[slot].p, d.histE[slot].p + d.be.etot};  // the spins' blocks one after the other
       d.blocked_error(Fs, Ps, Es);
     }
     for (int sp = 0; sp < nspin; sp++) {
@@ -664,10 +663,11 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       HFG_HIP_CHECK(hipMemcpyAsync(d.histF[slot].p + sp * NN, F, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
       HFG_HIP_CHECK(hipMemcpyAsync(d.histP[slot].p + sp * NN, sp ? d.Pb.p : d.Pa.p, sizeof(double) * NN, hipMemcpyDeviceToDevice, s));
     }
-    d.maxabs(d.histE[slot].p, nspin * NN, 5);
+    const size_t elen = blocked_err ? nspin * d.be.etot : nspin * NN;  // the stored part of an error
+    d.maxabs(d.histE[slot].p, elen, 5);
     const int nh0 = (int)slots.size();
     for (int k = 0; k < nh0; k++) {
-      d.dot(d.histE[slot].p, d.histE[slots[k]].p, nspin * NN, 8 + k);
+      d.dot(d.histE[slot].p, d.histE[slots[k]].p, elen, 8 + k);
       d.dot(d.histP[slots[k]].p, d.histF[slot].p, nspin * NN, 8 + nh0 + k);      // T(k, n)
       d.dot(d.histP[slot].p, d.histF[slots[k]].p, nspin * NN, 8 + 2 * nh0 + k);  // T(n, k)
     }
