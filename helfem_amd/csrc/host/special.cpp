@@ -109,10 +109,22 @@ long double gaunt_quad(int L, int M, int l, int m, int lp, int mp) {
   auto it = rules.find(n);
   if (it == rules.end()) it = rules.emplace(n, gauss_legendre(n)).first;
   const GLRule &r = it->second;
+  // Theta_l^m at the nodes of the n-point rule, tabulated once per (n, l, m): a basis with l up to 20 asks for ~70 000
+  // coefficients, and evaluating the three recurrences at every node of every coefficient took 0.6 s of its set-up
+  static thread_local std::map<long long, std::vector<long double> > tables;
+  auto table = [&](int ll, int mm) -> const std::vector<long double> & {
+    const long long key = ((long long)n << 40) | ((long long)ll << 20) | (long long)(mm + 4096);
+    auto jt = tables.find(key);
+    if (jt == tables.end()) {
+      std::vector<long double> v(n);
+      for (int i = 0; i < n; i++) v[i] = theta_lm_t<long double>(ll, mm, r.x[i]);
+      jt = tables.emplace(key, std::move(v)).first;
+    }
+    return jt->second;
+  };
+  const std::vector<long double> &tL = table(L, M), &tl = table(l, m), &tp = table(lp, mp);
   long double s = 0.0L;
-  for (int i = 0; i < n; i++)
-    s += r.w[i] * theta_lm_t<long double>(L, M, r.x[i]) * theta_lm_t<long double>(l, m, r.x[i]) *
-         theta_lm_t<long double>(lp, mp, r.x[i]);
+  for (int i = 0; i < n; i++) s += r.w[i] * tL[i] * tl[i] * tp[i];
   // phi integral gives 2 pi (M = m + mp); conj(Y_L^M) has the same Theta
   return 2.0L * 3.141592653589793238462643383279502884L * s;
 }
