@@ -165,21 +165,62 @@ static void set_sub(Mat &M, size_t Nrad, size_t iang, size_t jang, const Mat &Mr
     }
 }
 
+// One-electron matrices are sums of (angular coupling) x (radial matrix) blocks.  The terms are collected first (the
+// Gaunt cache is not thread safe) and the boundary-cleaned matrix is then filled shell column by shell column on all
+// host threads: value = scale * (fac_1 R_1(i,j) + fac_2 R_2(i,j) + ...) in the order the terms were added, which is
+// what "set_sub ...; M *= scale; remove_boundaries(M)" computes -- without the Ndummy^2 intermediate and its passes.
+namespace {
+struct BlockTerm {
+  size_t iang, jang;
+  const Mat *rad;
+  double fac;
+};
+}  // namespace
+static Mat assemble_pure(const TwoDBasis &b, const std::vector<BlockTerm> &terms, double scale) {
+  const size_t nang = b.lval.size(), Nr = b.Nrad();
+  std::vector<size_t> off(nang + 1, 0), skip(nang, 0);
+  for (size_t a = 0; a < nang; a++) {
+    skip[a] = (b.mval[a] != 0) ? 1 : 0;
+    off[a + 1] = off[a] + Nr - skip[a];
+  }
+  std::vector<std::vector<BlockTerm> > bycol(nang);
+  for (const BlockTerm &t : terms) bycol[t.jang].push_back(t);
+  Mat F(off[nang], off[nang]);
+  parallel_for(nang, [&](size_t jang) {
+    const std::vector<BlockTerm> &ts = bycol[jang];
+    // the terms of one (iang, jang) block are consecutive in ts (they were added pair by pair)
+    for (size_t k = 0; k < ts.size();) {
+      size_t k1 = k;
+      while (k1 < ts.size() && ts[k1].iang == ts[k].iang) k1++;
+      const size_t iang = ts[k].iang;
+      for (size_t j = skip[jang]; j < Nr; j++) {
+        double *col = &F(off[iang], off[jang] + j - skip[jang]);
+        for (size_t i = skip[iang]; i < Nr; i++) {
+          double v = ts[k].fac * (*ts[k].rad)(i, j);
+          for (size_t q = k + 1; q < k1; q++) v += ts[q].fac * (*ts[q].rad)(i, j);
+          col[i - skip[iang]] = v * scale;
+        }
+      }
+      k = k1;
+    }
+  });
+  return F;
+}
+
 Mat TwoDBasis::overlap() const {
   // basis.cpp:677-711:  S = Rh^3 [ delta_ll' I_{1,2} - c_2 I_{1,0} ]
   Mat I10(radial_integral(1, 0)), I12(radial_integral(1, 2));
-  Mat S(Ndummy(), Ndummy());
+  std::vector<BlockTerm> terms;
   for (size_t iang = 0; iang < lval.size(); iang++)
     for (size_t jang = 0; jang < lval.size(); jang++) {
       int li = lval[iang], mi = mval[iang], lj = lval[jang], mj = mval[jang];
       if (mi == mj) {
-        if (li == lj) set_sub(S, Nrad(), iang, jang, I12, 1.0, false);
+        if (li == lj) terms.push_back({iang, jang, &I12, 1.0});
         double cpl = gaunt.cosine2_coupling(lj, mj, li, mi);
-        if (cpl != 0.0) set_sub(S, Nrad(), iang, jang, I10, -cpl, true);
+        if (cpl != 0.0) terms.push_back({iang, jang, &I10, -cpl});
       }
     }
-  S *= std::pow(Rhalf, 3);
-  return remove_boundaries(S);
+  return assemble_pure(*this, terms, std::pow(Rhalf, 3));
 }
 
 Mat TwoDBasis::kinetic() const {
@@ -187,33 +228,31 @@ Mat TwoDBasis::kinetic() const {
   std::function<double(double)> sinhmu = [](double mu) { return std::sinh(mu); };
   Mat Trad(fem.matrix_element(1, 1, xq, wq, sinhmu));
   Mat Ip1(radial_integral(1, 0)), Im1(radial_integral(-1, 0));
-  Mat T(Ndummy(), Ndummy());
+  std::vector<BlockTerm> terms;
   for (size_t iang = 0; iang < lval.size(); iang++) {
-    set_sub(T, Nrad(), iang, iang, Trad, 1.0, false);
-    if (lval[iang] != 0) set_sub(T, Nrad(), iang, iang, Ip1, lval[iang] * (lval[iang] + 1), true);
-    if (mval[iang] != 0) set_sub(T, Nrad(), iang, iang, Im1, mval[iang] * mval[iang], true);
+    terms.push_back({iang, iang, &Trad, 1.0});
+    if (lval[iang] != 0) terms.push_back({iang, iang, &Ip1, (double)(lval[iang] * (lval[iang] + 1))});
+    if (mval[iang] != 0) terms.push_back({iang, iang, &Im1, (double)(mval[iang] * mval[iang])});
   }
-  T *= Rhalf / 2.0;
-  return remove_boundaries(T);
+  return assemble_pure(*this, terms, Rhalf / 2.0);
 }
 
 Mat TwoDBasis::nuclear() const {
   // basis.cpp:780-817
   Mat I10(radial_integral(1, 0)), I11(radial_integral(1, 1));
-  Mat V(Ndummy(), Ndummy());
+  std::vector<BlockTerm> terms;
   for (size_t iang = 0; iang < lval.size(); iang++)
     for (size_t jang = 0; jang < lval.size(); jang++) {
       int li = lval[iang], mi = mval[iang], lj = lval[jang], mj = mval[jang];
       if (mi == mj) {
-        if (li == lj) set_sub(V, Nrad(), iang, jang, I11, Z1 + Z2, false);
+        if (li == lj) terms.push_back({iang, jang, &I11, (double)(Z1 + Z2)});
         if (Z1 != Z2) {
           double cpl = gaunt.cosine_coupling(lj, mj, li, mi);
-          if (cpl != 0.0) set_sub(V, Nrad(), iang, jang, I10, (Z2 - Z1) * cpl, true);
+          if (cpl != 0.0) terms.push_back({iang, jang, &I10, (Z2 - Z1) * cpl});
         }
       }
     }
-  V *= -std::pow(Rhalf, 2);
-  return remove_boundaries(V);
+  return assemble_pure(*this, terms, -std::pow(Rhalf, 2));
 }
 
 Mat TwoDBasis::dipole_z() const {
