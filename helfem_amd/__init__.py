@@ -280,6 +280,14 @@ class TwoDBasis(object):
             _check(lib().hfg_compute_tei(self.h, 1 if exchange else 0))
         self._uploaded = None
 
+    def overlap_with(self, other):
+        """TwoDBasis::overlap(const TwoDBasis &rh), basis.cpp:713: <self | other>"""
+        out = np.zeros((self.Nbf(), other.Nbf()), order="F")
+        f = lib().hfg_basis_interbasis_overlap
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, c_double_p]
+        _check(f(self.h, other.h, _p(out)))
+        return out
+
     def lm_map(self):
         """the sorted (L, |M|) channels of the constructor (basis.cpp:333-375)"""
         n = ctypes.c_int(4096)

@@ -508,9 +508,15 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   if (opt.have_guess) {
     if (verbose) printf("Guess orbitals from checkpoint\nGuess orbitals from previous calculation\n");
     Mat Sh0 = hb->kind ? hb->ab.overlap() : hb->b.overlap();
-    Mat gCa, gCb;
+    Mat gCa, gCb, S12, Sinvh_h;
     helfem::Vec gEa, gEb;
-    helfem::scf::guess_from_checkpoint(opt, Sh0, (size_t)nela, (size_t)nelb, gCa, gCb, gEa, gEb);
+    if (!hb->kind && opt.guess_basis) {  // another basis: interbasis overlap and this run's half-inverse on the host
+      S12 = hb->b.overlap(*opt.guess_basis);
+      Sinvh_h.zeros(N, N);
+      HFG_HIP_CHECK(hipMemcpyAsync(Sinvh_h.memptr(), d.Sinvh.p, sizeof(double) * NN, hipMemcpyDeviceToHost, s));
+      HFG_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    helfem::scf::guess_from_checkpoint(opt, Sh0, Sinvh_h, S12, (size_t)nela, (size_t)nelb, gCa, gCb, gEa, gEb);
     auto put = [&](DevBuf<double> &dC, DevBuf<double> &dE, const Mat &C, const helfem::Vec &E) {
       // the checkpoint may hold fewer columns than basis functions (Cholesky-reduced runs): the rest stays zero
       Mat Cfull(N, N);

@@ -626,6 +626,7 @@ int hfg_scf_run(hfg_ctx *ctx, const hfg_scf_options *in, hfg_scf_result *res, do
       chk.read("Ea", o.guessEa);
       if (chk.exist("Cb")) chk.read("Cb", o.guessCb);
       if (chk.exist("Eb")) chk.read("Eb", o.guessEb);
+      if (p.program == 0) o.guess_basis = std::make_shared<helfem::diatomic::TwoDBasis>(chk.read_diatomic_basis(p.lpad));
       o.have_guess = true;
     }
     helfem::scf::Result r;

@@ -154,6 +154,66 @@ Mat TwoDBasis::radial_integral(int m, int n) const {
   return fem.matrix_element(0, 0, xq, wq, chsh);
 }
 
+Mat TwoDBasis::radial_overlap(const TwoDBasis &rh, int n) const {
+  // the products of two finite element bases are polynomial only on the intersections of their elements: one rule per
+  // intersection, with the larger of the two numbers of quadrature points (basis.cpp:104-200)
+  Vec xp, wp;
+  chebyshev_rule((int)std::max(xq.size(), rh.xq.size()), xp, wp);
+  Mat S(fem.nbf(), rh.fem.nbf());
+  for (size_t iel = 0; iel < fem.nelem(); iel++)
+    for (size_t jel = 0; jel < rh.fem.nelem(); jel++) {
+      const double imin = fem.element_begin(iel), imax = fem.element_end(iel);
+      const double jmin = rh.fem.element_begin(jel), jmax = rh.fem.element_end(jel);
+      if (!((jmin >= imin && jmin < imax) || (imin >= jmin && imin < jmax))) continue;
+      const double a = std::max(imin, jmin), b = std::min(imax, jmax);
+      const double mid = 0.5 * (b + a), len = 0.5 * (b - a);
+      Vec xi(xp.size()), xj(xp.size()), w(xp.size());
+      for (size_t q = 0; q < xp.size(); q++) {
+        const double mu = mid + len * xp[q];
+        xi[q] = (mu - fem.element_midpoint(iel)) / fem.scaling_factor(iel);
+        xj[q] = (mu - rh.fem.element_midpoint(jel)) / rh.fem.scaling_factor(jel);
+        w[q] = wp[q] * len * std::sinh(mu) * (n != 0 ? std::pow(std::cosh(mu), n) : 1.0);
+      }
+      const Mat ibf = fem.eval_dnf(xi, 0, iel), jbf = rh.fem.eval_dnf(xj, 0, jel);
+      size_t i0, i1, j0, j1;
+      fem.get_idx(iel, i0, i1);
+      rh.fem.get_idx(jel, j0, j1);
+      for (size_t fj = 0; fj < jbf.n_cols; fj++)
+        for (size_t fi = 0; fi < ibf.n_cols; fi++) {
+          double acc = 0.0;
+          for (size_t q = 0; q < xp.size(); q++) acc += w[q] * ibf(q, fi) * jbf(q, fj);
+          S(i0 + fi, j0 + fj) += acc;
+        }
+    }
+  return S;
+}
+
+Mat TwoDBasis::overlap(const TwoDBasis &rh) const {
+  // basis.cpp:713-750
+  const Mat I10(radial_overlap(rh, 0)), I12(radial_overlap(rh, 2));
+  const size_t Nr = Nrad(), Nr2 = rh.Nrad();
+  Mat S(Ndummy(), rh.Ndummy());
+  for (size_t iang = 0; iang < lval.size(); iang++)
+    for (size_t jang = 0; jang < rh.lval.size(); jang++) {
+      const int li = lval[iang], mi = mval[iang], lj = rh.lval[jang], mj = rh.mval[jang];
+      if (mi != mj) continue;
+      const double cpl = gaunt.cosine2_coupling(lj, mj, li, mi);
+      if (li != lj && cpl == 0.0) continue;
+      for (size_t j = 0; j < Nr2; j++)
+        for (size_t i = 0; i < Nr; i++) {
+          double v = (li == lj) ? I12(i, j) : 0.0;
+          if (cpl != 0.0) v -= I10(i, j) * cpl;
+          S(iang * Nr + i, jang * Nr2 + j) = v;
+        }
+    }
+  S *= std::pow(Rhalf, 3);
+  const std::vector<size_t> pi(pure_indices()), pj(rh.pure_indices());
+  Mat out(pi.size(), pj.size());
+  for (size_t j = 0; j < pj.size(); j++)
+    for (size_t i = 0; i < pi.size(); i++) out(i, j) = S(pi[i], pj[j]);
+  return out;
+}
+
 static void set_sub(Mat &M, size_t Nrad, size_t iang, size_t jang, const Mat &Mrad, double fac, bool add) {
   for (size_t j = 0; j < Nrad; j++)
     for (size_t i = 0; i < Nrad; i++) {

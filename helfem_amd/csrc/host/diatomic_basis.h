@@ -62,6 +62,11 @@ struct TwoDBasis {
 
   Mat radial_integral(int m, int n) const;  // \int B_i B_j sinh^m cosh^n
   Mat overlap() const;
+  /// radial overlap with ANOTHER basis, \int B_i B'_j sinh(mu) cosh^n(mu) dmu (RadialBasis::overlap(rh, n), basis.cpp:104-200)
+  Mat radial_overlap(const TwoDBasis &rh, int n) const;
+  /// interbasis overlap <this | rh> in the boundary-cleaned index spaces, Nbf() x rh.Nbf() (basis.cpp:713-750): what
+  /// projects the orbitals of a checkpoint made in another basis (--load)
+  Mat overlap(const TwoDBasis &rh) const;
   Mat kinetic() const;
   Mat nuclear() const;
   Mat dipole_z() const;

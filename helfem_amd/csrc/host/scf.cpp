@@ -143,7 +143,8 @@ OccupationPlan occupation_plan(const Options &opt, const atomic::TwoDBasis &basi
   return pl;
 }
 
-void guess_from_checkpoint(const Options &opt, const Mat &S, size_t nela, size_t nelb, Mat &Ca, Mat &Cb, Vec &Ea, Vec &Eb) {
+void guess_from_checkpoint(const Options &opt, const Mat &S, const Mat &Sinvh, const Mat &S12, size_t nela, size_t nelb, Mat &Ca, Mat &Cb,
+                           Vec &Ea, Vec &Eb) {
   const size_t N = S.n_rows;
   bool same = opt.guessS.n_rows == N && opt.guessS.n_cols == N && opt.guessCa.n_rows == N;
   if (same) {
@@ -154,13 +155,24 @@ void guess_from_checkpoint(const Options &opt, const Mat &S, size_t nela, size_t
     }
     same = dmax <= 1e-10 * smax;
   }
-  if (!same)
-    throw std::logic_error("The checkpoint to load was made in a different basis set; projection between basis sets "
-                           "(interbasis overlap) is not supported by this build.\n");
-  Ca = opt.guessCa;
-  Cb = opt.guessCb.n_rows == N ? opt.guessCb : opt.guessCa;
   Ea = opt.guessEa;
   Eb = opt.guessEb.size() ? opt.guessEb : opt.guessEa;
+  if (same) {
+    Ca = opt.guessCa;
+    Cb = opt.guessCb.n_rows == N ? opt.guessCb : opt.guessCa;
+  } else {
+    if (S12.n_rows != N || S12.n_cols != opt.guessCa.n_rows)
+      throw std::logic_error("The checkpoint to load was made in a different basis set; projection between basis sets "
+                             "(interbasis overlap) is not supported for this program by this build.\n");
+    // C = Sinvh Sinvh^T S12 C_old (main.cpp:616-626)
+    auto project = [&](const Mat &Cold) {
+      Mat t = matmul(S12, false, Cold, false);
+      t = matmul(Sinvh, true, t, false);
+      return matmul(Sinvh, false, t, false);
+    };
+    Ca = project(opt.guessCa);
+    Cb = opt.guessCb.n_rows == opt.guessCa.n_rows && opt.guessCb.n_cols ? project(opt.guessCb) : Ca;
+  }
   if (Ca.n_cols < nela || Cb.n_cols < nelb) throw std::logic_error("The checkpoint holds fewer orbitals than are to be occupied.\n");
   auto gram_schmidt = [&](Mat &C, size_t nocc) {
     std::vector<double> Sc(N);
@@ -265,6 +277,8 @@ struct Problem {
   std::vector<std::vector<std::vector<size_t> > > avg_idx;
   // --readocc: the plan once the spin state is known
   std::function<OccupationPlan(int, int)> occupations;
+  // --load from another basis: interbasis overlap (this x checkpoint), when the program can form it
+  std::function<Mat()> guess_overlap;
 };
 
 // scf::fock_symmetry_average (src/general/scf_helpers.cpp:263-284)
@@ -355,7 +369,7 @@ Result scf_loop(const Options &opt, Backend &be, Problem &pb, Result res) {
     printf("Guess orbitals from core Hamiltonian\n");
   if (opt.have_guess) {
     if (verbose) printf("Guess orbitals from checkpoint\nGuess orbitals from previous calculation\n");
-    guess_from_checkpoint(opt, S, nela, nelb, Ca, Cb, Ea, Eb);
+    guess_from_checkpoint(opt, S, Sinvh, pb.guess_overlap ? pb.guess_overlap() : Mat(), nela, nelb, Ca, Cb, Ea, Eb);
   } else {
     be.eig_gsym_sub(Ea, Ca, Hguess, Sinvh, dsym);
     if (!restr) {
@@ -686,6 +700,7 @@ Result run_diatomic(const Options &opt, Backend &be) {
   Options oo = opt;
   oo.symmetry = symm;
   pb.occupations = [oo, &basis](int na, int nb) { return occupation_plan(oo, basis, na, nb); };
+  if (opt.guess_basis) pb.guess_overlap = [&opt, &basis]() { return basis.overlap(*opt.guess_basis); };
   return scf_loop(opt, be, pb, res);
 }
 

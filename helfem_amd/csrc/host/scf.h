@@ -11,6 +11,7 @@
 #include "atomic_basis.h"
 #include "diatomic_basis.h"
 #include <map>
+#include <memory>
 #include <string>
 
 namespace helfem {
@@ -86,13 +87,15 @@ struct Options {
   // i < readocc (negative: always)
   int readocc = 0;
   std::vector<std::vector<int> > occs;
-  // --load (main.cpp:552-648, the "project lowest orbitals" branch): orbitals and the overlap matrix of a previous run.
-  // The reference projects between different bases through the interbasis overlap; here the checkpoint must be of the SAME
-  // basis (its S must equal this run's S), for which the projection is the identity; the occupied orbitals are
-  // re-orthonormalised by Gram-Schmidt as in main.cpp:630-640.
+  // --load (main.cpp:552-648, the "project lowest orbitals" branch): orbitals, overlap matrix and basis of a previous run.
+  // Same basis (the stored S equals this run's): the projection is the identity.  Another diatomic basis (guess_basis,
+  // read from the checkpoint): C = S^-1 S12 C_old with the interbasis overlap S12 (basis.cpp:713-750), S^-1 = Sinvh Sinvh^T.
+  // The occupied orbitals are re-orthonormalised by Gram-Schmidt as in main.cpp:630-640.  (The atomic program restarts
+  // from checkpoints of the same basis only.)
   bool have_guess = false;
   Mat guessS, guessCa, guessCb;
   Vec guessEa, guessEb;
+  std::shared_ptr<diatomic::TwoDBasis> guess_basis;
   bool keep_matrices = false;  // fill Result::mats with what the reference's drivers write to their checkpoint
   bool verbose = true;
 };
@@ -145,7 +148,9 @@ std::vector<size_t> occupation_order(const Vec &E, const std::vector<std::vector
 void enforce_occupations(Mat &C, Vec &E, const Mat &S, const std::vector<int> &nocc, const std::vector<std::vector<size_t> > &sym);
 /// --load: checks that the stored overlap is this basis' and returns the stored orbitals with the first nela / nelb columns
 /// S-orthonormalised (main.cpp:618-646); throws std::logic_error for a checkpoint of another basis
-void guess_from_checkpoint(const Options &opt, const Mat &S, size_t nela, size_t nelb, Mat &Ca, Mat &Cb, Vec &Ea, Vec &Eb);
+/// S12: interbasis overlap (this basis x checkpoint basis) or an empty matrix when none can be formed; Sinvh: this run's
+void guess_from_checkpoint(const Options &opt, const Mat &S, const Mat &Sinvh, const Mat &S12, size_t nela, size_t nelb, Mat &Ca, Mat &Cb,
+                           Vec &Ea, Vec &Eb);
 
 std::vector<std::vector<std::vector<size_t> > > atomic_average_groups(const atomic::TwoDBasis &basis);
 Result run_diatomic(const Options &opt, Backend &be);

@@ -251,3 +251,29 @@ def test_checkpoint_round_trip_and_layout(hf, chk, tmp_path):
     assert L.hfg_chk_open(path, 0, ctypes.byref(h)) == 0
     assert L.hfg_chk_write_int(h, b"x", 1) != 0 and b"reading only" in L.hfg_last_error()
     L.hfg_chk_close(h)
+
+
+def test_interbasis_overlap_projects_between_bases(hf):
+    """TwoDBasis::overlap(const TwoDBasis &) (basis.cpp:713-750, RadialBasis::overlap basis.cpp:104-200): with the basis
+    itself it is the overlap matrix; onto a refinement (every element split in two, same polynomial order) the functions of
+    the coarse basis are represented exactly, so S11^-1 S12 maps S22-orthonormal vectors to S11-orthonormal ones"""
+    lval, mval = hf.lm_to_l_m([3, 2])
+    Rh = 1.0
+    bcoarse = np.array([0.0, 0.6, 1.5, 3.0])
+    bfine = np.array([0.0, 0.3, 0.6, 1.05, 1.5, 2.25, 3.0])
+    b2 = hf.TwoDBasis(3, 9, Rh, 6, 30, bcoarse, lval, mval, 10)
+    b1 = hf.TwoDBasis(3, 9, Rh, 6, 30, bfine, lval, mval, 10)
+    S22, S11 = b2.overlap(), b1.overlap()
+    assert np.max(np.abs(b2.overlap_with(b2) - S22)) < 1e-12 * np.max(np.abs(S22))
+    S12 = b1.overlap_with(b2)
+    assert S12.shape == (b1.Nbf(), b2.Nbf())
+    # S22-orthonormal vectors of the coarse basis
+    w, U = np.linalg.eigh(S22)
+    C2 = U / np.sqrt(w)
+    C1 = np.linalg.solve(S11, S12 @ C2)
+    assert np.max(np.abs(C1.T @ S11 @ C1 - np.eye(b2.Nbf()))) < 1e-9
+    # and an unrelated grid loses norm (a projection)
+    b3 = hf.TwoDBasis(3, 9, Rh, 6, 30, np.array([0.0, 1.0, 3.0]), lval, mval, 10)
+    C3 = np.linalg.solve(b3.overlap(), b3.overlap_with(b2) @ C2)
+    nrm = np.diag(C3.T @ b3.overlap() @ C3)
+    assert np.all(nrm < 1.0 + 1e-9) and np.min(nrm) < 0.999
