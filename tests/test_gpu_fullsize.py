@@ -81,6 +81,19 @@ def test_fullsize_density_coulomb_exchange(full):
     assert abs(np.sum(p0 * basis.coulomb(p0)) + np.sum(p0 * basis.exchange(p0))) < 1e-10 * np.sum(p0 * basis.coulomb(p0))
 
 
+def test_fullsize_exchange_with_more_than_64_factors(full):
+    """a density of 7 + 60 = 67 factors: the fast path factorises the residual matrix a second time; the result must be the
+    sum of the two parts' exchange matrices (linearity), symmetric, and agree with the general kernels on a probe vector"""
+    hf, basis, C, N = full["hf"], full["basis"], full["C"], full["N"]
+    Pa = hf.scf.form_density(C, 7)
+    Pb = hf.scf.form_density(np.asfortranarray(C[:, 40:100]), 60)
+    K = basis.exchange(np.asfortranarray(Pa + 0.01 * Pb))
+    Ka, Kb = basis.exchange(Pa), basis.exchange(np.asfortranarray(0.01 * Pb))
+    sk = np.max(np.abs(K))
+    assert np.max(np.abs(K - Ka - Kb)) < 1e-11 * sk
+    assert np.max(np.abs(K - K.T)) < 1e-11 * sk
+
+
 def test_fullsize_xc_quadrature(full):
     hf, basis, S, C, N = full["hf"], full["basis"], full["S"], full["C"], full["N"]
     grid = hf.DFTGrid(basis, full["ldft"], full["mdft"])
