@@ -83,7 +83,7 @@ def test_fullsize_density_coulomb_exchange(full):
 
 def test_fullsize_exchange_with_more_than_64_factors(full):
     """a density of 7 + 60 = 67 factors: the fast path factorises the residual matrix a second time; the result must be the
-    sum of the two parts' exchange matrices (linearity), symmetric, and agree with the general kernels on a probe vector"""
+    sum of the two parts' exchange matrices (linearity: each part alone needs one factor group) and symmetric"""
     hf, basis, C, N = full["hf"], full["basis"], full["C"], full["N"]
     Pa = hf.scf.form_density(C, 7)
     Pb = hf.scf.form_density(np.asfortranarray(C[:, 40:100]), 60)
