@@ -24,6 +24,7 @@ namespace hfg {
 
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
 void gemm_mirror_lower_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxN);
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restri
 }
 
 struct EigWork {
+  bool split_full = false;  // this batch's full products run as two half-K workgroups per tile
   DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
@@ -997,6 +999,14 @@ size_t eig_block_buf_size(int nblk, const int64_t *blk_ptr) {
 // spins cost about what one costs
 void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs, const double *dS, int nblk, const int64_t *blk_ptr,
                           const int64_t *blk_idx, double *const *dBlockBufs);
+static int eig_num_cus(hfg_ctx *ctx) {
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t prop;
+    ncu = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return ncu;
+}
 void eig_blocks_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
                     const int64_t *blk_idx, double *dBlockBuf) {
   eig_blocks_multi_dev(ctx, N, 1, &dF, dS, nblk, blk_ptr, blk_idx, &dBlockBuf);
@@ -1116,16 +1126,37 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
                            dcols + blk_ptr[ib], n, Fb.p + (size_t)k * nmax * nmax, Xall.p + (size_t)k * nmax * nmax);
       }
       static const bool rect = getenv("HELFEM_GEMM_RECT") && atoi(getenv("HELFEM_GEMM_RECT"));
-      if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p, nb, nm, nm);
+      // two workgroups per tile (split K) when the batch's tiles would not fill the chip evenly: more than half, fewer
+      // than all of the 2 x CU slots; HELFEM_GEMM_SPLITK = 0 / 1 forces it off / on
+      static const int force_split = getenv("HELFEM_GEMM_SPLITK") ? atoi(getenv("HELFEM_GEMM_SPLITK")) : -1;
+      long full_tiles = 0, low_tiles = 0;
+      for (int k = 0; k < nb; k++) {
+        const long t1 = (ns[k] + 127) / 128;
+        full_tiles += t1 * t1;
+        low_tiles += t1 * (t1 + 1) / 2;
+      }
+      const int slots = 2 * eig_num_cus(ctx);
+      const bool split_full = force_split >= 0 ? force_split != 0 : (full_tiles < slots && nm >= 256);
+      const bool split_low = force_split >= 0 ? force_split != 0 : (low_tiles < slots && nm >= 256);
+      w.split_full = split_full;
+      if (split_full) {
+        for (int k = 0; k < nb; k++) HFG_HIP_CHECK(hipMemsetAsync(T1.p + (size_t)k * nmax * nmax, 0, sizeof(double) * (size_t)ns[k] * ns[k], s));
+        gemm_tasklist_split2_dev(ctx, w.gtasks.p, nb, nm, nm);
+      } else if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p, nb, nm, nm);
       else gemm_tasklist_dev(ctx, w.gtasks.p, nb, nm, nm);
-      gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);      // lower tiles of X^T (F X) only (GemmTask::sym)
+      if (split_low) {
+        for (int k = 0; k < nb; k++) HFG_HIP_CHECK(hipMemsetAsync(w.A[k].p, 0, sizeof(double) * (size_t)ns[k] * ns[k], s));
+        gemm_tasklist_split2_dev(ctx, w.gtasks.p + nb, nb, nm, nm);
+      } else
+        gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);      // lower tiles of X^T (F X) only (GemmTask::sym)
       gemm_mirror_lower_dev(ctx, w.gtasks.p + nb, nb, nm);        // the tridiagonalisation sweeps the full square
     }
     eig_sym_batch(ctx, w, nb, ns.data());
     {
       ProfScope ps(ctx, "eig_backtransform");
       static const bool rect = getenv("HELFEM_GEMM_RECT") && atoi(getenv("HELFEM_GEMM_RECT"));
-      if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+      if (w.split_full) gemm_tasklist_split2_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);  // the block slots were zeroed above
+      else if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
       else gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
       for (int k = 0; k < nb; k++) {
         const int ib = mine[c0 + k] % nblk;

@@ -50,7 +50,7 @@ template <int BM, int BN, bool ACC = false, int MF = 1>
 __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
                                            const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
                                            double beta, double *__restrict__ C, int ldc, double (*As)[16][BM + 16],
-                                           double (*Bs)[16][BN + 16], int sym = 0) {
+                                           double (*Bs)[16][BN + 16], int sym = 0, int kbeg = 0, int kend = -1) {
   constexpr int BK = 16;
   constexpr int PAD = 16;
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
@@ -231,12 +231,16 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
     }
   };
 
-  load_tiles(0);
+  // split K (kend >= 0): this workgroup forms the k range [kbeg, kend) of its tile and ADDS it to C (zeroed by the
+  // caller) with FP64 atomics; with two halves per tile the sum has two addends, so its value does not depend on their order
+  const bool splitk = kend >= 0;
+  const int kstop = splitk ? min(kend, K) : K;
+  load_tiles(kbeg);
   store_tiles(0);
   __syncthreads();
   int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool more = (k0 + BK < K);
+  for (int k0 = kbeg; k0 < kstop; k0 += BK) {
+    const bool more = (k0 + BK < kstop);
     if (more) load_tiles(k0 + BK);  // the next step's operands travel while this step's MFMAs run
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
@@ -319,6 +323,10 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
         if (gm < M && gn < N) {
           size_t o = (size_t)gn * ldc + gm;
           double v = alpha * acc(i, j, r);
+          if (splitk) {
+            unsafeAtomicAdd(&C[o], v);
+            continue;
+          }
           if (beta != 0.0) v += beta * C[o];
           C[o] = v;
         }
@@ -347,6 +355,27 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__res
   if ((int)blockIdx.x >= nt) return;
   dgemm_tile<BM, BN, ACC, MF>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc,
                               As, Bs, sym);
+}
+
+// Two workgroups per tile, each half of K (rounded to the k step): for batches whose tiles do not fill the chip evenly --
+// 386 tiles of the eigensolve's products on 512 workgroup slots last two tile-times for 1.5 tile-times of average work,
+// 772 half tiles fill them with three each; the 210 lower tiles of the symmetric product become 420 units that all
+// run at once.  C must be zero on entry (beta == 0 tasks only).
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void k_dgemm_tasklist_split2(const GemmTask *__restrict__ tasks) {
+  __shared__ __attribute__((aligned(16))) double As[2][16][BM + 16];
+  __shared__ __attribute__((aligned(16))) double Bs[2][16][BN + 16];
+  const GemmTask t = tasks[blockIdx.y];
+  if (t.M <= 0 || t.N <= 0) return;
+  const int sym = (BM == BN && t.M == t.N) ? (t.sym == 1) : 0;
+  const int nbm = (t.M + BM - 1) / BM;
+  const int nt = (sym == 1) ? nbm * (nbm + 1) / 2 : nbm * ((t.N + BN - 1) / BN);
+  const int tile = blockIdx.x >> 1, half = blockIdx.x & 1;
+  if (tile >= nt) return;
+  const int Kh = ((t.K / 2 + 15) / 16) * 16;
+  const int kbeg = half ? Kh : 0, kend = half ? t.K : Kh;
+  if (kbeg >= kend) return;
+  dgemm_tile<BM, BN, false, 1>(tile, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, 0.0, t.C, t.ldc, As, Bs, sym, kbeg, kend);
 }
 
 /// HELFEM_MFMA=4x4x4 selects the v_mfma_f64_4x4x4_4b_f64 form of the tile engine (A/B runs; same speed, more LDS reads)
@@ -423,6 +452,15 @@ void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, in
   ProfScope ps(ctx, "gemm");
   const int tiles = ((maxM + 127) / 128) * ((maxN + 63) / 64);
   hipLaunchKernelGGL((k_dgemm_tasklist<128, 64>), dim3(tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+/// C = A B for task lists with beta == 0 whose outputs the caller has ZEROED: two workgroups per 128 x 128 tile
+void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
+  if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
+  hipLaunchKernelGGL((k_dgemm_tasklist_split2<128, 128>), dim3(2 * tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
   HFG_HIP_CHECK(hipGetLastError());
 }
 
