@@ -1,5 +1,12 @@
 // Two-stage tridiagonalisation of symmetric matrices on gfx950, batched over problems
-// (the LAPACK dsyevd call behind scf::eig_gsym / eig_gsym_sub, /root/reference/src/general/scf_helpers.cpp:131-186):
+// (the LAPACK dsyevd call behind scf::eig_gsym / eig_gsym_sub, /root/reference/src/general/scf_helpers.cpp:131-186).
+//
+// STATUS: both stages are correct (tests/test_gpu_twostage.py) and were MEASURED SLOWER than the one-stage chain of
+// trd.hip at the sizes of this path (3 x 1470: stage 1 11.2 ms, stage 2 23.7 ms against 12.1 ms; DESIGN.md section 7 has the
+// numbers and the reason -- a dependent step through device memory costs 3.5 us inside a kernel, 1.8 us as a kernel
+// boundary).  The product path does not call this file; it is reachable through hfg_debug_band_reduce /
+// hfg_debug_two_stage only and kept as the record of that measurement.  The back-transformation described below was
+// therefore not written.
 //
 //   stage 1  dense -> band of half-width SB = 32: per panel of SB columns a Householder QR of the block below the band
 //            (one workgroup per problem, the panel in registers), then the two-sided compact-WY update of the trailing
