@@ -131,7 +131,20 @@ __global__ void k_coulomb_ket(const double *__restrict__ Pc, int A, int E, int p
   int beg = lm_off[iLM], end = lm_off[iLM + 1];
   for (int t = threadIdx.x; t < pp; t += blockDim.x) {
     double a0 = 0.0, a2 = 0.0;
-    for (int k = beg; k < end; k++) {
+    // eight entries in flight: the rolled "load P, two FMAs" loop paid one memory round trip per entry (~330 entries per
+    // channel: 146 us for the kernel); the order of the additions is unchanged
+    int k = beg;
+    for (; k + 8 <= end; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = Pc[((size_t)(lm_x[k + u] * A + lm_y[k + u]) * E + e) * pp + t];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        a0 += lm_c0[k + u] * v[u];
+        a2 += lm_c2[k + u] * v[u];
+      }
+    }
+    for (; k < end; k++) {
       double v = Pc[((size_t)(lm_x[k] * A + lm_y[k]) * E + e) * pp + t];
       a0 += lm_c0[k] * v;
       a2 += lm_c2[k] * v;
@@ -261,7 +274,24 @@ __global__ void k_coulomb_bra(const double *__restrict__ Jaux, int A, int E, int
   int beg = pair_off[pr], end = pair_off[pr + 1];
   for (int t = threadIdx.x; t < pp; t += blockDim.x) {
     double acc = 0.0;
-    for (int k = beg; k < end; k++) {
+    // four entries (eight loads) in flight; entries of other ranks' channels contribute an exact zero in the same place
+    int k = beg;
+    for (; k + 4 <= end; k += 4) {
+      double j0[4], j2[4], c0[4], c2[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int iLM = ent_iLM[k + u];
+        const bool mine = (LM_ilm[iLM] % nranks == rank);
+        j0[u] = Jaux[((size_t)(0 * NLM + iLM) * E + e) * pp + t];
+        j2[u] = Jaux[((size_t)(1 * NLM + iLM) * E + e) * pp + t];
+        c0[u] = mine ? ent_c0[k + u] : 0.0;
+        c2[u] = mine ? ent_c2[k + u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (c0[u] != 0.0 || c2[u] != 0.0) acc += c0[u] * j0[u] + c2[u] * j2[u];
+    }
+    for (; k < end; k++) {
       int iLM = ent_iLM[k];
       if (LM_ilm[iLM] % nranks != rank) continue;
       acc += ent_c0[k] * Jaux[((size_t)(0 * NLM + iLM) * E + e) * pp + t] +
