@@ -45,6 +45,60 @@ def build_basis(hf, w):
     return b, bval, lval, mval, ldft, mdft
 
 
+class MT19937_64(object):
+    """std::mt19937_64 (Matsumoto / Nishimura 2000), for the seeded density BASELINE.md section 2 names"""
+
+    def __init__(self, seed):
+        self.mt = [0] * 312
+        self.mt[0] = seed & 0xFFFFFFFFFFFFFFFF
+        for i in range(1, 312):
+            self.mt[i] = (6364136223846793005 * (self.mt[i - 1] ^ (self.mt[i - 1] >> 62)) + i) & 0xFFFFFFFFFFFFFFFF
+        self.idx = 312
+
+    def next(self):
+        if self.idx >= 312:
+            mt, UM, LM = self.mt, 0xFFFFFFFF80000000, 0x7FFFFFFF
+            for i in range(312):
+                x = (mt[i] & UM) | (mt[(i + 1) % 312] & LM)
+                mt[i] = mt[(i + 156) % 312] ^ (x >> 1) ^ (0xB5026F5AA96619E9 if x & 1 else 0)
+            self.idx = 0
+        x = self.mt[self.idx]
+        self.idx += 1
+        x ^= (x >> 29) & 0x5555555555555555
+        x ^= (x << 17) & 0x71D67FFFEDA60000
+        x ^= (x << 37) & 0xFFF7EEE000000000
+        x ^= x >> 43
+        return x
+
+    def uniform(self, lo, hi):
+        """std::uniform_real_distribution<double>(lo, hi): one 64-bit draw per value (generate_canonical<double, 53>)"""
+        u = min(self.next() / 18446744073709551616.0, 1.0 - 2.0 ** -53)
+        return lo + (hi - lo) * u
+
+
+def seeded_density(N, nocc, blocks, Sinvh, seed=20260130):
+    """BASELINE.md section 2, kernel-only runs: P = 2 C C^T with C = Sinvh Q, Q orthonormalised columns of i.i.d.
+    U(-1,1) numbers from std::mt19937_64(seed), built per symmetry block so that P is block diagonal in m; the nocc
+    columns are dealt out as in a diatomic ground state (every further block one orbital, the rest in the first block)"""
+    rng = MT19937_64(seed)
+    per = [1] * len(blocks)
+    per[0] = nocc - (len(blocks) - 1)
+    if per[0] < 1:
+        per = [nocc] + [0] * (len(blocks) - 1)
+    C = np.zeros((N, nocc), order="F")
+    col = 0
+    for idx, k in zip(blocks, per):
+        if k == 0:
+            continue
+        n = len(idx)
+        Q = np.array([[rng.uniform(-1.0, 1.0) for _ in range(k)] for _ in range(n)])
+        Q, _ = np.linalg.qr(Q)
+        cols = np.where(np.max(np.abs(Sinvh[np.ix_(idx, range(N))]), axis=0) > 0)[0]
+        C[:, col:col + k] = Sinvh[:, cols] @ Q
+        col += k
+    return 2.0 * (C @ C.T)
+
+
 def usable_cores():
     """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a GPU box
     hands a 256-core host's affinity to a job that owns 16 CPUs' worth of time: 256 spinning BLAS threads on that are
@@ -166,6 +220,8 @@ def main():
     ap.add_argument("--workload", default="n2_pbe_nbf4230")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--symmetry", type=int, default=1, help="0: one unsymmetrised eigenproblem; 1 (reference default): m blocks")
+    ap.add_argument("--density", default="core", choices=["core", "seeded"],
+                    help="start density: occupied orbitals of the core Hamiltonian, or BASELINE.md's seeded mt19937_64 orbitals")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +251,8 @@ def main():
     # core guess -> density (done through the same device path: F = sym(H0) by using a zero compact matrix)
     E0, C0 = hf.scf.eig_gsym_sub(H0, Sinvh, blocks, ctx=ctx)
     P0 = 2.0 * hf.scf.form_density(C0, w["nocc"], ctx=ctx)
+    if args.density == "seeded":
+        P0 = np.asfortranarray(seeded_density(N, w["nocc"], blocks, Sinvh))
     allred = parallel.allreduce_sum_ if (world > 1 or parallel.forced()) else None
     xblocks = parallel.broadcast_block_slots_ if (world > 1 or parallel.forced()) else None
 
@@ -285,6 +343,8 @@ def main():
                                        w["Z1"], w["Z2"], w["Rbond"], w["nelem"], w["nnodes"], 5 * w["nnodes"],
                                        str(w["lmmax"]).replace(" ", ""), N, basis.Nang(), basis.Nrad(), ldft, mdft, sizes),
                        "name": args.workload, "parallelism": "shard%d" % world,
+                       "density": "occupied orbitals of the core Hamiltonian" if args.density == "core"
+                       else "seeded std::mt19937_64(20260130) block-diagonal orbitals (BASELINE.md section 2)",
                        "timed_path": "device-resident step (hfg_*_dev entry points on HBM buffers: the loop body of hfg_scf_run, "
                                      "which the diatomic/atomic executables and helfem::gpu::run_scf call); the host-pointer "
                                      "entry points (hfg_coulomb, hfg_eig_gsym_sub, ...) add ~12 ms of PCIe per call"},
