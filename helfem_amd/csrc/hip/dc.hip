@@ -145,8 +145,12 @@ constexpr int DC_SQZ = 20;  // candidate-list entries per thread in the parallel
 __global__ __launch_bounds__(256) void k_dc_prepare(DCBatch b, const DCNode *__restrict__ nodes,
                                                     const double *__restrict__ rho_all, int node0,
                                                     int *__restrict__ kcount, int *__restrict__ nrot,
-                                                    double *__restrict__ rho_eff, GemmTask *__restrict__ tasks) {
-  extern __shared__ double sh[];
+                                                    double *__restrict__ rho_eff, GemmTask *__restrict__ tasks,
+                                                    double *__restrict__ gscratch, size_t gstride) {
+  // work arrays of the node: LDS, or -- for merges whose arrays exceed it (n > ~5000) -- a slice of a global buffer
+  // (same code: a workgroup's global stores are visible to its own threads behind __syncthreads)
+  extern __shared__ double lds_[];
+  double *sh = gscratch ? gscratch + (size_t)blockIdx.x * gstride : lds_;
   const int ni = node0 + blockIdx.x;
   const DCNode nd = nodes[ni];
   const int blk = nd.blk, lo = nd.lo, mid = nd.mid, hi = nd.hi;
@@ -775,6 +779,7 @@ void gemm_tasks_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int max_ti
 // host driver
 // -------------------------------------------------------------------------------------------------
 struct DCWork {
+  DevBuf<double> prep_scratch;  // work arrays of k_dc_prepare for merges too large for LDS
   DevBuf<double> d2[DC_MAXB], Qb[DC_MAXB], U[DC_MAXB], Qg[DC_MAXB], Qn[DC_MAXB];
   DevBuf<double> vec[DC_MAXB];  // 9 double vectors of length n
   DevBuf<int> ivec[DC_MAXB];    // 7 int vectors of length n
@@ -911,10 +916,17 @@ void tridiag_dc_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, d
     const int node0 = w.level_off[h], nn = w.level_off[h + 1] - node0;
     const int mx = w.level_maxn[h];
     size_t shb = (size_t)mx * (2 * sizeof(double) + 4 * sizeof(int)) + ((size_t)mx / 64 + 2) * sizeof(unsigned long long);
-    if (shb > 64 * 1024)
+    double *gscr = nullptr;
+    size_t gstride = 0;
+    if (shb > 150 * 1024) {  // beyond the LDS of a CU (merges of more than ~4800 values): global work arrays
+      gstride = (shb + 7) / 8 + 8;
+      w.prep_scratch.resize(gstride * nn);
+      gscr = w.prep_scratch.p;
+      shb = 0;
+    } else if (shb > 64 * 1024)
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_dc_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
     hipLaunchKernelGGL(k_dc_prepare, dim3(nn), dim3(256), shb, s, b, w.nodes.p, w.rho.p, node0, w.kcount.p, w.nrot.p,
-                       w.rho_eff.p, w.tasks.p);
+                       w.rho_eff.p, w.tasks.p, gscr, gstride);
     hipLaunchKernelGGL(k_dc_rotate, dim3((mx + 255) / 256, nn), dim3(256), 0, s, b, w.nodes.p, node0, w.nrot.p);
     hipLaunchKernelGGL(k_dc_secular, dim3((mx + 3) / 4, nn), dim3(256), 0, s, b, w.nodes.p, node0, w.kcount.p,
                        w.rho_eff.p);

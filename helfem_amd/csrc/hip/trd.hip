@@ -34,7 +34,7 @@ constexpr int TB_MAXB = 8;
 constexpr int TB_NB = 16;   // panel width (measured: 16 beats 8 and 32 at n ~ 1400 x 3 blocks; 32 again after the DPP work: 11.7 vs 7.6 us per column)
 constexpr int TB_NCS = 8;   // column slabs of the trailing-matrix sweep
 constexpr int TF_T = 128;    // tile edge of the fused kernel
-constexpr int TF_MAXS = 40;  // max slabs per dimension: n <= TF_T * (TF_MAXS - 1)
+constexpr int TF_MAXS = 64;  // max slabs per dimension: n <= TF_T * (TF_MAXS - 1) = 8064 (larger problems take the two-kernel path)
 
 struct TrdBatch {
   int n[TB_MAXB];

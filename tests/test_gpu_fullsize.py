@@ -247,3 +247,19 @@ def test_pair_eigensolve_at_full_size(full):
         assert np.max(np.abs(C.T @ SC - np.eye(N))) < 1e-9
         assert np.max(np.abs(F @ C - SC * E)) < 1e-9 * np.max(np.abs(E))
     assert np.max(np.abs(Eb - Ea)) > 1e-6  # the second matrix really is another problem
+
+
+def test_eigensolver_beyond_one_cu_lds():
+    """n = 5200: the top merge of the divide & conquer stage no longer fits its work arrays into one CU's LDS (they move to
+    a global buffer) and the fused tridiagonalisation runs with 41 slabs per dimension; residual and orthonormality"""
+    import helfem_amd as hf
+    n = 5200
+    rng = np.random.RandomState(n)
+    A = rng.standard_normal((n, n))
+    A = np.asfortranarray(A + A.T)
+    E, C = hf.scf.eig_sym(A)
+    assert np.all(np.diff(E) >= 0.0)
+    scale = np.max(np.abs(E))
+    assert np.max(np.abs(A @ C - C * E)) < 1e-11 * scale
+    assert np.max(np.abs(C.T @ C - np.eye(n))) < 1e-11
+    assert abs(np.sum(E) - np.trace(A)) < 1e-9 * scale * np.sqrt(n)
