@@ -606,10 +606,11 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
                               const double *__restrict__ cosd, const double *__restrict__ sind, int Dmax, int G, int nth,
                               int nphi, double Rh, int geom, int x_func, int c_func, int do_grad, int do_tau, double thr,
                               size_t NQ, int rank, int nranks, double *__restrict__ Fo,
-                              double *__restrict__ partial /* [3][NQ] */) {
+                              double *__restrict__ partial /* [3][NQ] */, int rowc) {
   // meta-GGA (do_tau): V and Fo carry five planes per spin (the tau planes 3, 4 as in k_xc_grid), LDS one more potential
-  // plane per spin
-  extern __shared__ double sh[];  // pot[npot][nth*nphi] (npot = 8, or 10 with tau), red[3*nwave]
+  // plane per spin.  The theta rows go through LDS rowc at a time (the phi transform is row by row): rowc = nth unless the
+  // planes of the whole grid exceed a CU's LDS (lmax beyond ~26 with mmax = 2).
+  extern __shared__ double sh[];  // pot[npot][rowc*nphi] (npot = 8, or 10 with tau), red[3*nwave]
   size_t Q = blockIdx.x;
   if ((int)(Q % nranks) != rank) {
     if (threadIdx.x == 0) {
@@ -619,7 +620,7 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
     }
     return;
   }
-  int ng = nth * nphi;
+  const int ng = rowc * nphi;        // plane stride in LDS
   const int npl = do_tau ? 5 : 3;    // planes per spin in V and Fo
   const int npot = do_tau ? 5 : 4;   // potential planes per spin in LDS
   double *red = sh + 2 * npot * ng;
@@ -627,8 +628,11 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
   double dphi = 2.0 * HFG_PI / nphi;
   size_t stride = NQ * G * G * nth;
   double nel = 0.0, exc_sum = 0.0, kin_sum = 0.0;
-  for (int pt = threadIdx.x; pt < ng; pt += blockDim.x) {
-    int i = pt / nphi, j = pt % nphi;
+  for (int i0 = 0; i0 < nth; i0 += rowc) {
+  const int rows = min(rowc, nth - i0);
+  if (i0) __syncthreads();  // the previous chunk's planes have been transformed
+  for (int pt = threadIdx.x; pt < rows * nphi; pt += blockDim.x) {
+    int i = i0 + pt / nphi, j = pt % nphi;
     double sth = th_s[i];
     double hmu, hnu, hphi, w;
     if (geom == 0) {
@@ -704,34 +708,13 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
       sh[(npot + 3) * ng + pt] = w * (2.0 * vsbb * gphi[1] + vsab * gphi[0]) / hphi;
     }
   }
-  int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
-  for (int o = 32; o > 0; o >>= 1) {
-    nel += __shfl_down(nel, o, 64);
-    exc_sum += __shfl_down(exc_sum, o, 64);
-    kin_sum += __shfl_down(kin_sum, o, 64);
-  }
-  if (lane == 0) {
-    red[wave] = nel;
-    red[nwave + wave] = exc_sum;
-    red[2 * nwave + wave] = kin_sum;
-  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0, c2 = 0.0;
-    for (int w = 0; w < nwave; w++) {
-      a += red[w];
-      b += red[nwave + w];
-      c2 += red[2 * nwave + w];
-    }
-    partial[Q] = a;
-    partial[NQ + Q] = b;
-    partial[2 * NQ + Q] = c2;
-  }
-  int nout = G * G * nth;
+  int nout = G * G * rows;
   for (int t = threadIdx.x; t < 2 * nout; t += blockDim.x) {
     int sp = t / nout, tt = t % nout;
-    int i = tt % nth;
-    int gab = tt / nth;
+    const int il = tt % rows;
+    int i = i0 + il;
+    int gab = tt / rows;
     int ga = gab / G, gb = gab % G;
     int D = grp_m[ga] - grp_m[gb];
     const double *cd = cosd + (size_t)(D + Dmax) * nphi;
@@ -740,7 +723,7 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
     double fa = 0.0, fs = 0.0, fb = 0.0, ft = 0.0;
     double mga = grp_m[ga];
     for (int j = 0; j < nphi; j++) {
-      int pt = i * nphi + j;
+      int pt = il * nphi + j;
       fa += 0.5 * p0[pt] * cd[j];
       if (do_grad) {
         fa -= mga * p3[pt] * sd[j];
@@ -770,6 +753,30 @@ __global__ void k_xc_grid_pol(const double *__restrict__ V, const double *__rest
       Fs[stride + o] = fs;
       Fs[2 * stride + o] = fb;
     }
+  }
+  }  // theta chunks
+  int nwave = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x & 63;
+  for (int o = 32; o > 0; o >>= 1) {
+    nel += __shfl_down(nel, o, 64);
+    exc_sum += __shfl_down(exc_sum, o, 64);
+    kin_sum += __shfl_down(kin_sum, o, 64);
+  }
+  if (lane == 0) {
+    red[wave] = nel;
+    red[nwave + wave] = exc_sum;
+    red[2 * nwave + wave] = kin_sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0, c2 = 0.0;
+    for (int w = 0; w < nwave; w++) {
+      a += red[w];
+      b += red[nwave + w];
+      c2 += red[2 * nwave + w];
+    }
+    partial[Q] = a;
+    partial[NQ + Q] = b;
+    partial[2 * NQ + Q] = c2;
   }
 }
 
@@ -829,6 +836,87 @@ __global__ void k_xc_fock_theta(const double *__restrict__ Fo, const double *__r
     GA[Q * AA + (size_t)a * A + b] = s0;
     if (do_grad) GB[Q * AA + (size_t)a * A + b] = s1;
     if (do_tau) GC[Q * AA + (size_t)a * A + b] = s2;
+  }
+}
+
+// X4 for shell groups whose Theta tables do not fit a CU's LDS (lmax beyond ~33 with mmax = 2): the theta points go
+// through LDS nthc at a time and every thread keeps the sums of its (a, b) pairs in registers across the chunks
+// (at most XC_FT_MAXPP pairs per thread: groups of up to 64 shells)
+constexpr int XC_FT_MAXPP = 16;
+__global__ __launch_bounds__(256) void k_xc_fock_theta_chunked(const double *__restrict__ Fo, const double *__restrict__ Th,
+                                                               const double *__restrict__ dTh, int A, int nth, int G,
+                                                               const int *__restrict__ grp_off, const int *__restrict__ grp_shell,
+                                                               int do_grad, int do_tau, size_t NQ, int rank, int nranks,
+                                                               double *__restrict__ GA, double *__restrict__ GB,
+                                                               double *__restrict__ GC, int nthc) {
+  extern __shared__ double sh[];
+  size_t Q = blockIdx.x;
+  if ((int)(Q % nranks) != rank) return;
+  int ga = blockIdx.y / G, gb = blockIdx.y % G;
+  int a0 = grp_off[ga], na = grp_off[ga + 1] - a0;
+  int b0 = grp_off[gb], nb = grp_off[gb + 1] - b0;
+  size_t stride = NQ * G * G * nth;
+  size_t o = ((Q * G + ga) * G + gb) * nth;
+  double *f0 = sh, *f1 = sh + nthc, *f2 = sh + 2 * nthc, *f3 = sh + 3 * nthc, *f4 = sh + 4 * nthc;
+  double *sTa = sh + 5 * nthc, *sDa = sTa + (size_t)nthc * na, *sTb = sDa + (size_t)nthc * na, *sDb = sTb + (size_t)nthc * nb;
+  double s0[XC_FT_MAXPP], s1[XC_FT_MAXPP], s2[XC_FT_MAXPP];
+#pragma unroll
+  for (int q = 0; q < XC_FT_MAXPP; q++) s0[q] = s1[q] = s2[q] = 0.0;
+  for (int c0 = 0; c0 < nth; c0 += nthc) {
+    const int len = min(nthc, nth - c0);
+    if (c0) __syncthreads();
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+      f0[i] = Fo[o + c0 + i];
+      f1[i] = do_grad ? Fo[stride + o + c0 + i] : 0.0;
+      f2[i] = do_grad ? Fo[2 * stride + o + c0 + i] : 0.0;
+      f3[i] = do_tau ? Fo[3 * stride + o + c0 + i] : 0.0;
+      f4[i] = do_tau ? Fo[4 * stride + o + c0 + i] : 0.0;
+    }
+    for (int t = threadIdx.x; t < len * na; t += blockDim.x) {
+      int ia = t / len, i = t % len;
+      int a = grp_shell[a0 + ia];
+      sTa[i * na + ia] = Th[(size_t)a * nth + c0 + i];
+      sDa[i * na + ia] = dTh[(size_t)a * nth + c0 + i];
+    }
+    for (int t = threadIdx.x; t < len * nb; t += blockDim.x) {
+      int ib = t / len, i = t % len;
+      int b = grp_shell[b0 + ib];
+      sTb[i * nb + ib] = Th[(size_t)b * nth + c0 + i];
+      sDb[i * nb + ib] = dTh[(size_t)b * nth + c0 + i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < XC_FT_MAXPP; q++) {
+      const int t = threadIdx.x + q * 256;
+      if (t < na * nb) {
+        const int ia = t / nb, ib = t % nb;
+        double t0 = s0[q], t1 = s1[q], t2 = s2[q];
+        for (int i = 0; i < len; i++) {
+          const double tai = sTa[i * na + ia], dai = sDa[i * na + ia], tbi = sTb[i * nb + ib];
+          t0 += (tai * f0[i] + dai * f1[i]) * tbi;
+          t1 += tai * f2[i] * tbi;
+          if (do_tau) {
+            t0 += dai * sDb[i * nb + ib] * f4[i];
+            t2 += tai * tbi * f3[i];
+          }
+        }
+        s0[q] = t0;
+        s1[q] = t1;
+        s2[q] = t2;
+      }
+    }
+  }
+  size_t AA = (size_t)A * A;
+#pragma unroll
+  for (int q = 0; q < XC_FT_MAXPP; q++) {
+    const int t = threadIdx.x + q * 256;
+    if (t < na * nb) {
+      const int ia = t / nb, ib = t % nb;
+      int a = grp_shell[a0 + ia], b = grp_shell[b0 + ib];
+      GA[Q * AA + (size_t)a * A + b] = s0[q];
+      if (do_grad) GB[Q * AA + (size_t)a * A + b] = s1[q];
+      if (do_tau) GC[Q * AA + (size_t)a * A + b] = s2[q];
+    }
   }
 }
 
@@ -955,11 +1043,38 @@ static int round_up64(int n) { return ((n + 63) / 64) * 64; }
 // LDS of k_xc_fock_theta: five potential rows and the Theta, dTheta rows of two shell groups
 static size_t xc_fock_theta_lds(int nth, int maxgrp) {
   size_t shb = (size_t)(5 * nth + 4 * nth * maxgrp) * sizeof(double);
-  if (shb > 160 * 1024) throw std::runtime_error("angular grid too large for the XC Fock kernel's LDS tables");
+  if (shb > 160 * 1024) throw std::runtime_error("angular grid too large for the XC Fock kernel's LDS tables");  // callers use launch_xc_fock_theta
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_fock_theta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   return shb;
 }
+// LDS the angular kernels may plan with; HELFEM_XC_LDS_LIMIT (bytes) lowers it so that the chunked paths can be exercised on
+// small bases (tests)
+static size_t xc_lds_limit() {
+  static const size_t v = getenv("HELFEM_XC_LDS_LIMIT") ? (size_t)atol(getenv("HELFEM_XC_LDS_LIMIT")) : (size_t)150 * 1024;
+  return v;
+}
+// X4 launch: the one-pass kernel when its tables fit a CU's LDS, the chunked one otherwise
+static void launch_xc_fock_theta(hfg_ctx *ctx, size_t NQ, int G, int nth, int maxgrp, const double *Fo, const double *Th, const double *dTh,
+                                 int A, const int *grp_off, const int *grp_shell, int do_grad, int do_tau, int rank, int nranks,
+                                 double *GA, double *GB, double *GC) {
+  const size_t need = (size_t)(5 * nth + 4 * nth * maxgrp) * sizeof(double);
+  if (need <= xc_lds_limit()) {
+    hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), xc_fock_theta_lds(nth, maxgrp), ctx->stream, Fo, Th, dTh, A, nth,
+                       G, grp_off, grp_shell, do_grad, do_tau, NQ, rank, nranks, GA, GB, GC);
+    return;
+  }
+  if (maxgrp * maxgrp > XC_FT_MAXPP * 256) throw std::runtime_error("angular basis too large for the XC Fock kernels (more than 64 shells of one m)");
+  int nthc = (int)(xc_lds_limit() / sizeof(double) / (5 + 4 * maxgrp));
+  if (nthc < 4) throw std::runtime_error("angular basis too large for the XC Fock kernels' LDS tables");
+  nthc = std::min(nthc, nth);
+  const size_t shb = (size_t)(5 * nthc + 4 * nthc * maxgrp) * sizeof(double);
+  if (shb > 64 * 1024)
+    HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_fock_theta_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+  hipLaunchKernelGGL(k_xc_fock_theta_chunked, dim3((unsigned)NQ, G * G), dim3(256), shb, ctx->stream, Fo, Th, dTh, A, nth, G, grp_off, grp_shell,
+                     do_grad, do_tau, NQ, rank, nranks, GA, GB, GC, nthc);
+}
+
 // LDS of k_xc_density_radial (256 threads): P block, the two transposed tables, the partial sums of the j classes
 static size_t xc_density_radial_lds(int p, int nq) {
   const int NJ = (256 / nq > 0) ? std::min(256 / nq, p) : 1;
@@ -1108,9 +1223,8 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   hipLaunchKernelGGL(k_xc_grid, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
                      x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
-  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), xc_fock_theta_lds(nth, maxgrp), ctx->stream,
-                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, NQ,
-                     ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
+  launch_xc_fock_theta(ctx, NQ, G, nth, maxgrp, a.Fo.p, t->Th.p, t->dTh.p, A, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, ctx->shard_rank,
+                       ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
   hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 4 * nq * p) * sizeof(double),
                      ctx->stream, a.GA.p, a.GB.p, a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                      ctx->shard_rank, ctx->shard_n, dHc);
@@ -1201,17 +1315,18 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
                        A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, NQ, ctx->shard_rank, ctx->shard_n,
                        a.V.p + (size_t)sp * npl * nv);
   }
-  size_t shb = (size_t)((do_tau ? 10 : 8) * nth * nphi + 3 * 4) * sizeof(double);
-  if (shb > 160 * 1024) throw std::runtime_error("XC angular grid too large for the polarised grid kernel's LDS tile");
+  int rowc = nth;  // theta rows per pass through LDS
+  while ((size_t)((do_tau ? 10 : 8) * rowc * nphi + 3 * 4) * sizeof(double) > xc_lds_limit() && rowc > 1) rowc = (rowc + 1) / 2;
+  size_t shb = (size_t)((do_tau ? 10 : 8) * rowc * nphi + 3 * 4) * sizeof(double);
+  if (shb > 150 * 1024) throw std::runtime_error("XC angular grid too large for the polarised grid kernel's LDS tile");
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_grid_pol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   hipLaunchKernelGGL(k_xc_grid_pol, dim3((unsigned)NQ), dim3(256), shb, ctx->stream, a.V.p, t->rad_w.p, t->rad_sh.p,
                      t->th_s.p, t->th_w.p, t->grp_m.p, t->cosd.p, t->sind.p, t->Dmax, G, nth, nphi, t->Rhalf, t->geom,
-                     x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
+                     x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p, rowc);
   for (int sp = 0; sp < 2; sp++) {
-    hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), xc_fock_theta_lds(nth, maxgrp), ctx->stream,
-                       a.Fo.p + (size_t)sp * npl * nv, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, do_grad,
-                       do_tau, NQ, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
+    launch_xc_fock_theta(ctx, NQ, G, nth, maxgrp, a.Fo.p + (size_t)sp * npl * nv, t->Th.p, t->dTh.p, A, t->grp_off.p, t->grp_shell.p, do_grad,
+                         do_tau, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
     hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 4 * nq * p) * sizeof(double),
                        ctx->stream, a.GA.p, a.GB.p, (const double *)a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                        ctx->shard_rank, ctx->shard_n, sp ? dHcb : dHca);
@@ -1259,9 +1374,8 @@ void model_potential_dev(hfg_ctx *ctx, hfg_basis *basis, int kind1, int Z1, doub
   DevModelPot p1{kind1, Z1, d1, H1}, p2{kind2, Z2, d2, H2};
   hipLaunchKernelGGL(k_mp_fill, dim3((unsigned)NQ), dim3(256), 0, ctx->stream, t->rad_w.p, t->rad_sh.p, t->th_c.p, t->th_s.p,
                      t->th_w.p, G, nth, nphi, t->Rhalf, t->geom, p1, p2, a.Fo.p);
-  hipLaunchKernelGGL(k_xc_fock_theta, dim3((unsigned)NQ, G * G), dim3(256), xc_fock_theta_lds(nth, maxgrp), ctx->stream,
-                     a.Fo.p, t->Th.p, t->dTh.p, A, nth, G, t->grp_off.p, t->grp_shell.p, 0, 0, NQ, 0, 1, a.GA.p, a.GB.p,
-                     (double *)nullptr);
+  launch_xc_fock_theta(ctx, NQ, G, nth, maxgrp, a.Fo.p, t->Th.p, t->dTh.p, A, t->grp_off.p, t->grp_shell.p, 0, 0, 0, 1, a.GA.p, a.GB.p,
+                       (double *)nullptr);
   hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))),
                      (4 * nq + 4 * nq * p) * sizeof(double), ctx->stream, a.GA.p, a.GB.p, (const double *)nullptr, t->rad_B.p,
                      t->rad_dB.p, A, E, p, nq, 0, 0, 0, 1, a.Jc.p);
