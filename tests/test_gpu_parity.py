@@ -129,6 +129,21 @@ def test_exchange_indefinite_and_full_rank_inputs(case):
     assert np.all(K0 == 0.0)
 
 
+def test_xc_kernels_with_chunked_angular_tables(hf):
+    """angular bases beyond lmax ~ 33 (restricted) / 26 (unrestricted) do not fit the XC kernels' Theta tables and potential
+    planes into one CU's LDS: the theta points then go through LDS in chunks.  HELFEM_XC_LDS_LIMIT (read once per process)
+    forces those paths on a small basis in ONE child process (tests/xc_chunk_worker.py), against the oracle"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HELFEM_XC_LDS_LIMIT="2500")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "xc_chunk_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    assert "worst relative deviation" in p.stdout.decode()
+
+
 def test_exchange_of_a_density_with_more_than_64_factors(case, monkeypatch):
     """rank 70 ... 150: the fast path factorises the residual matrix again (groups of 64 factors, K is linear in P) instead
     of handing the density to the general kernels; HELFEM_EXL_GROUPS=1 restores the single-group behaviour (fallback)"""
