@@ -1040,6 +1040,13 @@ __global__ void k_mp_fill(const double *__restrict__ rad_w, const double *__rest
 // launchers
 // -------------------------------------------------------------------------------------------------
 static int round_up64(int n) { return ((n + 63) / 64) * 64; }
+static size_t xc_fock_radial_lds(int p, int nq) {
+  const size_t shb = (size_t)(4 * nq + 4 * nq * p) * sizeof(double);
+  if (shb > 150 * 1024) throw std::runtime_error("radial quadrature too large for the XC Fock kernel's LDS tables");
+  if (shb > 64 * 1024)
+    HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_fock_radial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+  return shb;
+}
 // LDS of k_xc_fock_theta: five potential rows and the Theta, dTheta rows of two shell groups
 static size_t xc_fock_theta_lds(int nth, int maxgrp) {
   size_t shb = (size_t)(5 * nth + 4 * nth * maxgrp) * sizeof(double);
@@ -1076,10 +1083,13 @@ static void launch_xc_fock_theta(hfg_ctx *ctx, size_t NQ, int G, int nth, int ma
 }
 
 // LDS of k_xc_density_radial (256 threads): P block, the two transposed tables, the partial sums of the j classes
+static size_t xc_fock_radial_lds(int p, int nq);
 static size_t xc_density_radial_lds(int p, int nq) {
   const int NJ = (256 / nq > 0) ? std::min(256 / nq, p) : 1;
   size_t shb = (size_t)(p * p + 2 * p * nq + 3 * NJ * nq) * sizeof(double);
-  if (shb > 64 * 1024) throw std::runtime_error("radial quadrature too large for the XC density kernel's LDS tables");
+  if (shb > 150 * 1024) throw std::runtime_error("radial quadrature too large for the XC density kernel's LDS tables");
+  if (shb > 64 * 1024)  // elements of more than ~24 nodes with the default 5 quadrature points per node
+    HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_xc_density_radial, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   return shb;
 }
 
@@ -1225,7 +1235,7 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
                      x_func, c_func, do_grad, do_tau, thr, NQ, ctx->shard_rank, ctx->shard_n, a.Fo.p, a.partial.p);
   launch_xc_fock_theta(ctx, NQ, G, nth, maxgrp, a.Fo.p, t->Th.p, t->dTh.p, A, t->grp_off.p, t->grp_shell.p, do_grad, do_tau, ctx->shard_rank,
                        ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
-  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 4 * nq * p) * sizeof(double),
+  hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), xc_fock_radial_lds(p, nq),
                      ctx->stream, a.GA.p, a.GB.p, a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                      ctx->shard_rank, ctx->shard_n, dHc);
   hipLaunchKernelGGL(k_xc_sum_partials, dim3(1), dim3(64), 0, ctx->stream, a.partial.p, NQ, dScal);
@@ -1327,7 +1337,7 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
   for (int sp = 0; sp < 2; sp++) {
     launch_xc_fock_theta(ctx, NQ, G, nth, maxgrp, a.Fo.p + (size_t)sp * npl * nv, t->Th.p, t->dTh.p, A, t->grp_off.p, t->grp_shell.p, do_grad,
                          do_tau, ctx->shard_rank, ctx->shard_n, a.GA.p, a.GB.p, a.GC.p);
-    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), (4 * nq + 4 * nq * p) * sizeof(double),
+    hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))), xc_fock_radial_lds(p, nq),
                        ctx->stream, a.GA.p, a.GB.p, (const double *)a.GC.p, t->rad_B.p, t->rad_dB.p, A, E, p, nq, do_grad, do_tau,
                        ctx->shard_rank, ctx->shard_n, sp ? dHcb : dHca);
   }
@@ -1377,7 +1387,7 @@ void model_potential_dev(hfg_ctx *ctx, hfg_basis *basis, int kind1, int Z1, doub
   launch_xc_fock_theta(ctx, NQ, G, nth, maxgrp, a.Fo.p, t->Th.p, t->dTh.p, A, t->grp_off.p, t->grp_shell.p, 0, 0, 0, 1, a.GA.p, a.GB.p,
                        (double *)nullptr);
   hipLaunchKernelGGL(k_xc_fock_radial, dim3(A * A, E), dim3(std::min(256, round_up64(p * p))),
-                     (4 * nq + 4 * nq * p) * sizeof(double), ctx->stream, a.GA.p, a.GB.p, (const double *)nullptr, t->rad_B.p,
+                     xc_fock_radial_lds(p, nq), ctx->stream, a.GA.p, a.GB.p, (const double *)nullptr, t->rad_B.p,
                      t->rad_dB.p, A, E, p, nq, 0, 0, 0, 1, a.Jc.p);
   scatter_dense(ctx, basis, a.Jc.p, dH);
   HFG_HIP_CHECK(hipGetLastError());
