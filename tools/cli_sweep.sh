@@ -23,3 +23,11 @@ run Na_ROHF     $B/atomic --Z Na --lmax 1 --mmax 1 --nelem 8 --nnodes 15 --metho
 run Ne_CAMLDA0  $B/atomic --Z Ne --lmax 1 --mmax 1 --nelem 5 --nnodes 15 --method hyb_lda_xc_cam_lda0
 run Zn_LDA      $B/atomic --Z Zn --lmax 2 --mmax 2 --nelem 10 --nnodes 15 --method lda_x-lda_c_pw
 run Kr_PBE_s2   $B/atomic --Z Kr --lmax 2 --mmax 2 --nelem 10 --nnodes 15 --method gga_x_pbe-gga_c_pbe --symmetry 2
+run Rn_LDA_s2   $B/atomic --Z Rn --lmax 3 --mmax 3 --nelem 10 --nnodes 15 --method lda_x-lda_c_vwn --symmetry 2
+run Xe_HF_s2    $B/atomic --Z Xe --lmax 2 --mmax 2 --nelem 10 --nnodes 15 --method HF --symmetry 2
+run Ne_PBE_l6   $B/atomic --Z Ne --lmax 6 --mmax 6 --nelem 4 --nnodes 12 --method gga_x_pbe-gga_c_pbe
+run Cu_UPBE     $B/atomic --Z Cu --lmax 2 --mmax 2 --nelem 10 --nnodes 15 --method gga_x_pbe-gga_c_pbe --M 2
+run Ne_PBE_n25  $B/atomic --Z Ne --lmax 1 --mmax 1 --nelem 3 --nnodes 25 --method gga_x_pbe-gga_c_pbe
+run CO_PBE_l36  $B/diatomic --Z1 C --Z2 O --Rbond 2.132 --lmax 36 --mmax 2 --nelem 3 --nnodes 10 --method gga_x_pbe-gga_c_pbe
+run O2_UPBE_l30 $B/diatomic --Z1 O --Z2 O --Rbond 2.282 --lmax 30 --mmax 2 --nelem 3 --nnodes 10 --method gga_x_pbe-gga_c_pbe --M 3
+run N2_PBE_e30  $B/diatomic --Z1 N --Z2 N --Rbond 2.068 --lmax 6 --mmax 1 --nelem 30 --nnodes 15 --method gga_x_pbe-gga_c_pbe
