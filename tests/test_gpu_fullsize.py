@@ -263,3 +263,15 @@ def test_eigensolver_beyond_one_cu_lds():
     assert np.max(np.abs(A @ C - C * E)) < 1e-11 * scale
     assert np.max(np.abs(C.T @ C - np.eye(n))) < 1e-11
     assert abs(np.sum(E) - np.trace(A)) < 1e-9 * scale * np.sqrt(n)
+
+
+@pytest.mark.parametrize("kw,ref,tol", [
+    (dict(Z=86, lmax=3, mmax=3, nelem=10, nnodes=15, method="lda_x-lda_c_vwn", symmetry=2), -21861.346869, 5e-6),  # NIST LDA reference data
+    (dict(Z=54, lmax=2, mmax=2, nelem=10, nnodes=15, method="HF", symmetry=2), -7232.138364, 5e-6),                 # numerical HF limit
+])
+def test_heavy_atoms_against_reference_data(kw, ref, tol):
+    """radon / LDA against the NIST atomic reference data and xenon / HF against the numerical Hartree-Fock limit: the device
+    path alone (the CPU oracle would need minutes here); f shells, 16 (l, m) symmetry blocks, 139 radial functions"""
+    import helfem_amd as hf
+    r = hf.scf_atomic(convthr=1e-8, maxit=60, **kw)
+    assert r["converged"] and abs(r["Etot"] - ref) < tol, (r["Etot"], ref)
