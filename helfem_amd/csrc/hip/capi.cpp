@@ -371,8 +371,8 @@ int hfg_compute_tei_dev(hfg_ctx *ctx, hfg_basis *b, int exchange) {
 // arma::mat TwoDBasis::overlap(const TwoDBasis &rh) (basis.cpp:713-750): <a | b>, Nbf(a) x Nbf(b), column-major
 int hfg_basis_interbasis_overlap(const hfg_basis *a, const hfg_basis *b, double *S12) {
   HFG_TRY
-  if (a->kind || b->kind) throw std::logic_error("hfg_basis_interbasis_overlap: diatomic bases only\n");
-  const helfem::Mat m = a->b.overlap(b->b);
+  if (a->kind != b->kind) throw std::logic_error("hfg_basis_interbasis_overlap: the two bases must be of the same program\n");
+  const helfem::Mat m = a->kind ? a->ab.overlap(b->ab) : a->b.overlap(b->b);
   std::copy(m.d.begin(), m.d.end(), S12);
   HFG_CATCH
 }

@@ -510,8 +510,9 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     Mat Sh0 = hb->kind ? hb->ab.overlap() : hb->b.overlap();
     Mat gCa, gCb, S12, Sinvh_h;
     helfem::Vec gEa, gEb;
-    if (!hb->kind && opt.guess_basis) {  // another basis: interbasis overlap and this run's half-inverse on the host
-      S12 = hb->b.overlap(*opt.guess_basis);
+    if ((!hb->kind && opt.guess_basis) || (hb->kind && opt.guess_basis_atomic)) {
+      // (possibly) another basis: interbasis overlap and this run's half-inverse on the host
+      S12 = hb->kind ? hb->ab.overlap(*opt.guess_basis_atomic) : hb->b.overlap(*opt.guess_basis);
       Sinvh_h.zeros(N, N);
       HFG_HIP_CHECK(hipMemcpyAsync(Sinvh_h.memptr(), d.Sinvh.p, sizeof(double) * NN, hipMemcpyDeviceToHost, s));
       HFG_HIP_CHECK(hipStreamSynchronize(s));

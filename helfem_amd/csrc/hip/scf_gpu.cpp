@@ -627,6 +627,7 @@ int hfg_scf_run(hfg_ctx *ctx, const hfg_scf_options *in, hfg_scf_result *res, do
       if (chk.exist("Cb")) chk.read("Cb", o.guessCb);
       if (chk.exist("Eb")) chk.read("Eb", o.guessEb);
       if (p.program == 0) o.guess_basis = std::make_shared<helfem::diatomic::TwoDBasis>(chk.read_diatomic_basis(p.lpad));
+      else o.guess_basis_atomic = std::make_shared<helfem::atomic::TwoDBasis>(chk.read_atomic_basis());
       o.have_guess = true;
     }
     helfem::scf::Result r;

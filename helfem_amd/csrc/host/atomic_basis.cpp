@@ -174,6 +174,44 @@ Mat TwoDBasis::overlap() const {
   return place_diag(*this, std::vector<Mat>(Nang(), Orad));
 }
 
+Mat TwoDBasis::overlap(const TwoDBasis &rh) const {
+  // radial part: int (B_i / r)(B'_j / r) r^2 dr = int B_i B'_j dr over the intersections of the two element grids
+  Vec xp, wp;
+  chebyshev_rule((int)std::max(xq.size(), rh.xq.size()), xp, wp);
+  Mat Srad(fem.nbf(), rh.fem.nbf());
+  for (size_t iel = 0; iel < fem.nelem(); iel++)
+    for (size_t jel = 0; jel < rh.fem.nelem(); jel++) {
+      const double imin = fem.element_begin(iel), imax = fem.element_end(iel);
+      const double jmin = rh.fem.element_begin(jel), jmax = rh.fem.element_end(jel);
+      if (!((jmin >= imin && jmin < imax) || (imin >= jmin && imin < jmax))) continue;
+      const double a = std::max(imin, jmin), b = std::min(imax, jmax);
+      const double mid = 0.5 * (b + a), len = 0.5 * (b - a);
+      Vec xi(xp.size()), xj(xp.size());
+      for (size_t q = 0; q < xp.size(); q++) {
+        const double r = mid + len * xp[q];
+        xi[q] = (r - fem.element_midpoint(iel)) / fem.scaling_factor(iel);
+        xj[q] = (r - rh.fem.element_midpoint(jel)) / rh.fem.scaling_factor(jel);
+      }
+      const Mat ibf = fem.eval_dnf(xi, 0, iel), jbf = rh.fem.eval_dnf(xj, 0, jel);
+      const size_t i0 = fem.first[iel], j0 = rh.fem.first[jel];
+      for (size_t fj = 0; fj < jbf.n_cols; fj++)
+        for (size_t fi = 0; fi < ibf.n_cols; fi++) {
+          double acc = 0.0;
+          for (size_t q = 0; q < xp.size(); q++) acc += wp[q] * len * ibf(q, fi) * jbf(q, fj);
+          Srad(i0 + fi, j0 + fj) += acc;
+        }
+    }
+  // angular part: the same (l, m) only (atomic/TwoDBasis.cpp:338-341)
+  const size_t R = Nrad(), R2 = rh.Nrad();
+  Mat S(Nbf(), rh.Nbf());
+  for (size_t ia = 0; ia < Nang(); ia++)
+    for (size_t ja = 0; ja < rh.Nang(); ja++)
+      if (lval[ia] == rh.lval[ja] && mval[ia] == rh.mval[ja])
+        for (size_t j = 0; j < R2; j++)
+          for (size_t i = 0; i < R; i++) S(ia * R + i, ja * R2 + j) = Srad(i, j);
+  return S;
+}
+
 Mat TwoDBasis::kinetic() const {
   // TwoDBasis.cpp:349-380: 1/2 int B'B' + l(l+1) 1/2 int (B/r)(B/r)
   std::function<double(double)> none;

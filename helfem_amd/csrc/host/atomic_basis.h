@@ -82,6 +82,10 @@ struct TwoDBasis {
   /// quadrature::twoe_inner_integral (libhelfem/src/quadrature.cpp:22-75), which carries the inner integral from point
   /// to point with the ratio (r_{q-1}/r_q)^{L+1} instead; all terms are positive, the two forms agree to rounding
   void tei_element_tables(size_t iel, diatomic::TwoDBasis::TeiElementTables &t) const;
+  /// interbasis overlap <this | rh>, Nbf() x rh.Nbf() (atomic/TwoDBasis.cpp:330-344 with RadialBasis::overlap =
+  /// radial_integral(rh, 0), RadialBasis.cpp:211-300: one quadrature rule per intersection of elements): what projects the
+  /// orbitals of a checkpoint made in another basis (--load)
+  Mat overlap(const TwoDBasis &rh) const;
   /// the disjoint (cross-element) integrals only (the cheap part of compute_tei)
   void compute_disjoint();
   bool have_disjoint = false;

@@ -316,4 +316,24 @@ diatomic::TwoDBasis Checkpoint::read_diatomic_basis(int lpad) const {
   return diatomic::TwoDBasis(Z1, Z2, Rh, nn, nq, bval, lval, mval, lpad);
 }
 
+atomic::TwoDBasis Checkpoint::read_atomic_basis() const {
+  int id = 0;
+  read("HelFEM_ID", id);
+  if (id != 1) throw std::logic_error("Checkpoint does not correspond to an atomic calculation!\n");
+  int Z, nq, pid, nn, finitenuc = 0;
+  Vec bval;
+  IVec lval, mval;
+  read("Z", Z);
+  read("bval", bval);
+  read("n_quad", nq);
+  read("poly_id", pid);
+  read("poly_nnodes", nn);
+  read("lval", lval);
+  read("mval", mval);
+  if (exist("finitenuc")) read("finitenuc", finitenuc);
+  if (pid != 4) throw std::logic_error("Only the LIP primitive basis (poly_id 4) is supported by this build.\n");
+  if (finitenuc != 0) throw std::logic_error("Finite nuclear models are not supported by this build.\n");
+  return atomic::TwoDBasis(Z, nn, nq, bval, lval, mval);
+}
+
 }  // namespace helfem

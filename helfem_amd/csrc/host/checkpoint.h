@@ -43,6 +43,9 @@ class Checkpoint {
   void read(const std::string &name, int &v) const;
   /// the constructor arguments of a diatomic basis (Checkpoint::read(diatomic::basis::TwoDBasis &), checkpoint.cpp:587-625)
   diatomic::TwoDBasis read_diatomic_basis(int lpad) const;
+  /// the constructor arguments of an atomic basis (Checkpoint::read(atomic::basis::TwoDBasis &), checkpoint.cpp:510-558);
+  /// point nucleus, LIP primitives
+  atomic::TwoDBasis read_atomic_basis() const;
 
   /// dataset shape as stored (HDF5 order); empty for scalars
   std::vector<long long> dims(const std::string &name) const;

@@ -163,7 +163,7 @@ void guess_from_checkpoint(const Options &opt, const Mat &S, const Mat &Sinvh, c
   } else {
     if (S12.n_rows != N || S12.n_cols != opt.guessCa.n_rows)
       throw std::logic_error("The checkpoint to load was made in a different basis set; projection between basis sets "
-                             "(interbasis overlap) is not supported for this program by this build.\n");
+                             "(interbasis overlap) needs the checkpoint's basis, which could not be read.\n");
     // C = Sinvh Sinvh^T S12 C_old (main.cpp:616-626)
     auto project = [&](const Mat &Cold) {
       Mat t = matmul(S12, false, Cold, false);
@@ -769,6 +769,7 @@ Result run_atomic(const AtomicOptions &aopt, Backend &be) {
     be.prepare_atomic(basis, opt.kfrac != 0.0, ldft, mdft);
   };
   pb.occupations = [&opt, &basis](int na, int nb) { return occupation_plan(opt, basis, na, nb); };
+  if (opt.guess_basis_atomic) pb.guess_overlap = [&opt, &basis]() { return basis.overlap(*opt.guess_basis_atomic); };
   return scf_loop(opt, be, pb, res);
 }
 

@@ -89,13 +89,13 @@ struct Options {
   std::vector<std::vector<int> > occs;
   // --load (main.cpp:552-648, the "project lowest orbitals" branch): orbitals, overlap matrix and basis of a previous run.
   // Same basis (the stored S equals this run's): the projection is the identity.  Another diatomic basis (guess_basis,
-  // read from the checkpoint): C = S^-1 S12 C_old with the interbasis overlap S12 (basis.cpp:713-750), S^-1 = Sinvh Sinvh^T.
-  // The occupied orbitals are re-orthonormalised by Gram-Schmidt as in main.cpp:630-640.  (The atomic program restarts
-  // from checkpoints of the same basis only.)
+  // read from the checkpoint): C = S^-1 S12 C_old with the interbasis overlap S12 (basis.cpp:713-750; atomic/TwoDBasis.cpp:330-344 for the atomic program), S^-1 = Sinvh Sinvh^T.
+  // The occupied orbitals are re-orthonormalised by Gram-Schmidt as in main.cpp:630-640.
   bool have_guess = false;
   Mat guessS, guessCa, guessCb;
   Vec guessEa, guessEb;
   std::shared_ptr<diatomic::TwoDBasis> guess_basis;
+  std::shared_ptr<atomic::TwoDBasis> guess_basis_atomic;
   bool keep_matrices = false;  // fill Result::mats with what the reference's drivers write to their checkpoint
   bool verbose = true;
 };

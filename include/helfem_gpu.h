@@ -133,8 +133,9 @@ int hfg_diis_weights(int n, const double *B, const double *T, const double *E, d
  *   hfg_basis_get_prim: which 0-3 prim_tei00/02/20/22, 4-7 prim_ktei00/02/20/22, 8-11 disjoint_P0/P2/Q0/Q2 of channel ilm and
  *   element iel, column-major in the reference's shape (rows/cols returned; out may be NULL to query the shape).  Tables built
  *   by hfg_compute_tei_dev are copied back from the device (ctx required). */
-/* arma::mat TwoDBasis::overlap(const TwoDBasis &rh)   basis.cpp:713: interbasis overlap <a|b>, Nbf(a) x Nbf(b) (the
- * projection of a checkpoint's orbitals onto another basis, --load) */
+/* arma::mat TwoDBasis::overlap(const TwoDBasis &rh)   basis.cpp:713 and atomic/TwoDBasis.cpp:330: interbasis overlap
+ * <a|b>, Nbf(a) x Nbf(b), of two bases of the same program (the projection of a checkpoint's orbitals onto another
+ * basis, --load) */
 int hfg_basis_interbasis_overlap(const hfg_basis *a, const hfg_basis *b, double *S12);
 int hfg_basis_lm_map(const hfg_basis *basis, int *L, int *M, int *n);
 int hfg_basis_get_prim(hfg_ctx *ctx, const hfg_basis *basis, int which, int ilm, int iel, double *out, int64_t *rows,

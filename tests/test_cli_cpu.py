@@ -277,3 +277,27 @@ def test_interbasis_overlap_projects_between_bases(hf):
     C3 = np.linalg.solve(b3.overlap(), b3.overlap_with(b2) @ C2)
     nrm = np.diag(C3.T @ b3.overlap() @ C3)
     assert np.all(nrm < 1.0 + 1e-9) and np.min(nrm) < 0.999
+
+
+def test_atomic_interbasis_overlap(hf):
+    """atomic TwoDBasis::overlap(const TwoDBasis &) (src/atomic/TwoDBasis.cpp:330-344): radial int B_i B'_j dr on matching
+    (l, m) shells; same properties as the diatomic one, plus: an angular shell missing from the other basis gives zero rows"""
+    lval, mval = [0, 1, 1, 1], [0, -1, 0, 1]
+    bcoarse = np.array([0.0, 0.5, 2.0, 8.0])
+    bfine = np.array([0.0, 0.25, 0.5, 1.25, 2.0, 5.0, 8.0])
+    b2 = hf.AtomicTwoDBasis(4, 8, 40, bcoarse, lval, mval)
+    b1 = hf.AtomicTwoDBasis(4, 8, 40, bfine, lval, mval)
+    S22, S11 = b2.overlap(), b1.overlap()
+    assert np.max(np.abs(b2.overlap_with(b2) - S22)) < 1e-12 * np.max(np.abs(S22))
+    S12 = b1.overlap_with(b2)
+    assert S12.shape == (b1.Nbf(), b2.Nbf())
+    w, U = np.linalg.eigh(S22)
+    C2 = U / np.sqrt(w)
+    C1 = np.linalg.solve(S11, S12 @ C2)
+    assert np.max(np.abs(C1.T @ S11 @ C1 - np.eye(b2.Nbf()))) < 1e-9
+    # s-only basis against the s+p one: the p shells of the larger basis have no partner
+    bs = hf.AtomicTwoDBasis(4, 8, 40, bcoarse, [0], [0])
+    Ssp = b2.overlap_with(bs)
+    R = b2.Nbf() // 4
+    assert np.max(np.abs(Ssp[:R] - bs.overlap())) < 1e-12 and np.max(np.abs(Ssp[R:])) == 0.0
+

@@ -201,6 +201,25 @@ def test_restart_from_a_checkpoint_of_the_same_and_of_another_basis(hf, tmp_path
     assert abs(e1 - _etot(out4)) < 5e-3, (e1, _etot(out4))  # the smaller basis is itself 1.4e-3 Eh above
 
 
+def test_atomic_restart_from_another_basis(hf, tmp_path):
+    """the atomic program's --load (src/atomic/main.cpp:575-640): orbitals of a run with fewer elements and a smaller
+    angular basis, projected through the atomic interbasis overlap (src/atomic/TwoDBasis.cpp:330-344)"""
+    if not hf.lib().hfg_chk_available():
+        pytest.skip("no libhdf5 on this box")
+    base = ["--Z", "Be", "--nnodes", "8", "--method", "gga_x_pbe-gga_c_pbe"]
+    rc, out1, err = _run_cli("atomic", base + ["--nelem", "3", "--lmax", "0", "--mmax", "0", "--save", "a.chk"], str(tmp_path))
+    assert rc == 0, out1[-2000:] + err[-2000:]
+    rc, out2, err = _run_cli("atomic", base + ["--nelem", "5", "--lmax", "1", "--mmax", "1", "--load", "a.chk", "--save", ""], str(tmp_path))
+    assert rc == 0, out2[-2000:] + err[-2000:]
+    assert "Guess orbitals from checkpoint" in out2
+    rc, out3, err = _run_cli("atomic", base + ["--nelem", "5", "--lmax", "1", "--mmax", "1", "--save", ""], str(tmp_path))
+    assert rc == 0, err
+    it2, it3 = len(re.findall(r"\*\*\*\* Iteration", out2)), len(re.findall(r"\*\*\*\* Iteration", out3))
+    assert abs(_etot(out2) - _etot(out3)) < 2e-7 and it2 < it3, (it2, it3, _etot(out2), _etot(out3))
+    e1 = float(re.search(r"Total energy is\s+(-[0-9.]+)", out2).group(1))
+    assert abs(e1 - _etot(out3)) < 5e-3, (e1, _etot(out3))
+
+
 def test_functional_parameters_and_forced_occupations_through_the_command_line(hf, tmp_path):
     """--x_pars / --c_pars files (scf::parse_xc_params) reach the device-resident loop: PBE's own parameters reproduce the
     plain run, revPBE's kappa changes the energy to the oracle's value with the same parameter; --readocc puts lithium's
