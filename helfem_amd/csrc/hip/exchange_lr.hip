@@ -27,6 +27,7 @@ namespace hfg {
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 
 constexpr int EXL_RMAX = 64;
 constexpr int EXL_GMAX = 16;  // factor groups (residual factorisations) at most
@@ -217,8 +218,8 @@ __global__ void k_exl_V(const double *__restrict__ Ld, int Nd, int R, int A, int
   }
 }
 
-// aP[(c,o)][(j,e,a)] = sum_c' P0_e(a,c') V0[j, e(p-1)+c'] - P2_e(a,c') V2[...];  aQw = w_(c,o) * (same with Q0, Q2)
-__global__ void k_exl_alpha(const double *__restrict__ V0, const double *__restrict__ V2, const double *__restrict__ disj,
+// general form (any p, any number of elements): one workgroup per (column, shell)
+__global__ void k_exl_alpha_gen(const double *__restrict__ V0, const double *__restrict__ V2, const double *__restrict__ disj,
                             const int *__restrict__ LM_tab, const int *__restrict__ LM_ilm,
                             const double *__restrict__ LM_fac, const double *__restrict__ sgn, int Nd, int R, int A, int E,
                             int p, int r, int Ntab, int two, int rank, int nranks, double *__restrict__ aP,
@@ -253,6 +254,77 @@ __global__ void k_exl_alpha(const double *__restrict__ V0, const double *__restr
       }
     }
     size_t off = (size_t)col * Na + ((size_t)e * A + j) * p + a;  // rows ordered (element, shell, primitive)
+    aP[off] = sp;
+    aQw[off] = w * sq;
+  }
+}
+
+// aP[(c,o)][(j,e,a)] = sum_c' P0_e(a,c') V0[j, e(p-1)+c'] - P2_e(a,c') V2[...];  aQw = w_(c,o) * (same with Q0, Q2)
+// One workgroup per (channel, factor) column: thread (group g, element e, row a) keeps row a of the four p x p tables of
+// its element in registers and walks over the shells j = g, g + EXL_AG, ...; the p values of V it needs per shell are the
+// same for the p lanes of an (e, j) and come through the L1.  (One workgroup per (column, shell) with the tables read
+// from L2 per output took 1.5 ms at Nbf = 4230: 268 000 workgroups of 75 active threads.)
+constexpr int EXL_AG = 4;
+constexpr int EXL_AP = 16;  // p at most
+__global__ __launch_bounds__(512) void k_exl_alpha(const double *__restrict__ V0, const double *__restrict__ V2,
+                                                   const double *__restrict__ disj, const int *__restrict__ LM_tab,
+                                                   const int *__restrict__ LM_ilm, const double *__restrict__ LM_fac,
+                                                   const double *__restrict__ sgn, int Nd, int R, int A, int E, int p, int r,
+                                                   int Ntab, int two, int rank, int nranks, double *__restrict__ aP,
+                                                   double *__restrict__ aQw) {
+  extern __shared__ double xs[];  // this column of V0 (and of V2)
+  const int col = blockIdx.x;
+  const int c = col / r, o = col % r;
+  const int tab = LM_tab[c];
+  const int pp = p * p;
+  // multi-GPU: the (L,M) channels of the cross-element part are dealt out over the ranks
+  const double w = (LM_ilm[c] % nranks == rank) ? LM_fac[c] * sgn[o] : 0.0;
+  const int tQ0 = two ? 2 : 1;
+  const size_t Na = (size_t)A * E * p;
+  const int ng = min(EXL_AG, (int)blockDim.x / (E * p));
+  // thread (e, g, a): the lanes of one pass write ng * p consecutive doubles per element
+  const int e = threadIdx.x / (ng * p), g = (threadIdx.x / p) % ng, a = threadIdx.x % p;
+  const bool act = e < E;
+  double tp0[EXL_AP], tq0[EXL_AP], tp2[EXL_AP], tq2[EXL_AP];
+  {
+    const int ee = act ? e : 0;
+    const double *P0 = disj + (((size_t)0 * Ntab + tab) * E + ee) * pp;
+    const double *Q0 = disj + (((size_t)tQ0 * Ntab + tab) * E + ee) * pp;
+    const double *P2 = disj + (((size_t)1 * Ntab + tab) * E + ee) * pp;
+    const double *Q2 = disj + (((size_t)3 * Ntab + tab) * E + ee) * pp;
+#pragma unroll
+    for (int cc = 0; cc < EXL_AP; cc++) {
+      const bool in = act && cc < p && ee * (p - 1) + cc < R;
+      tp0[cc] = in ? P0[cc * p + a] : 0.0;
+      tq0[cc] = in ? Q0[cc * p + a] : 0.0;
+      tp2[cc] = (in && two) ? P2[cc * p + a] : 0.0;
+      tq2[cc] = (in && two) ? Q2[cc * p + a] : 0.0;
+    }
+  }
+  double *x0s = xs, *x2s = xs + Nd;
+  for (int t = threadIdx.x; t < Nd; t += blockDim.x) {
+    x0s[t] = V0[(size_t)col * Nd + t];
+    if (two) x2s[t] = V2[(size_t)col * Nd + t];
+  }
+  __syncthreads();
+  if (!act) return;
+  const int n0 = e * (p - 1);
+  for (int j = g; j < A; j += ng) {
+    const double *x0 = x0s + j * R + n0, *x2 = x2s + j * R + n0;
+    double sp = 0.0, sq = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < EXL_AP; cc++) {
+      const int n = max(0, min(cc, R - 1 - n0));  // clamped: the table entries beyond the basis are zero
+      const double y0 = x0[n];
+      sp += tp0[cc] * y0;
+      sq += tq0[cc] * y0;
+      if (two) {
+        const double y2 = x2[n];
+        sp -= tp2[cc] * y2;
+        sq -= tq2[cc] * y2;
+      }
+    }
+    const size_t off = (size_t)col * Na + ((size_t)e * A + j) * p + a;  // rows ordered (element, shell, primitive)
     aP[off] = sp;
     aQw[off] = w * sq;
   }
@@ -466,6 +538,108 @@ __global__ __launch_bounds__(512) void k_exl_RB4(const double *__restrict__ V0, 
         out[pp + il] = -acc[a][b][1];
         out[2 * pp + il] = -acc[a][b][2];
         out[3 * pp + il] = acc[a][b][3];
+      }
+    }
+}
+
+// The same blocks on the matrix cores.  For one block of 4 x 4 shells the sums are one small product
+//   D[(t2, b, l'), (t1, a, i')] = sum_cl  V_t2[k_b][l'; cl] * (w_cl V_t1[j_a][i'; cl]),     cl = (channel, factor),
+// i.e. 8 x 8 tiles of 16 x 16 (p <= 16 rows of a shell per tile) with K = nco: v_mfma_f64_16x16x4_f64 with the a-operand
+// taken from the k shells and the b-operand from the weighted j shells (operand maps: hip/gemm.hip), so that a result
+// register of lane l holds (l' = (l >> 4) + 4 reg, i' = l & 15) and one store instruction writes four consecutive rows
+// l' of a p x p block: 4 p contiguous doubles.  No LDS: the operands of a 16 x 4 fragment are p contiguous doubles per
+// (channel, factor) column of V0 / V2 and go from L2 straight into the operand registers, two k-steps ahead of the
+// instructions that use them.  512 threads = 8 waves of 4 x 2 tiles (types: wave & 1 for k, (wave >> 1) & 1 for j; j
+// shells 2 (wave >> 2) + {0, 1}); without the second table type (atomic basis) 8 waves of 1 x 2 tiles.
+typedef double exl_d4 __attribute__((ext_vector_type(4)));
+template <bool TWO>
+__global__ __launch_bounds__(512) void k_exl_RBm(const double *__restrict__ V0, const double *__restrict__ V2,
+                                                 const int *__restrict__ tab_ch_off, const int *__restrict__ tab_ch,
+                                                 const double *__restrict__ LM_fac, const double *__restrict__ sgn,
+                                                 const int *__restrict__ S_off, const int *__restrict__ S_list,
+                                                 const long long *__restrict__ rb_off, int tau0, int Nd, int R, int E, int p, int r,
+                                                 double *__restrict__ RB) {
+  const int e = blockIdx.y;
+  const int tau = tau0 + blockIdx.z;
+  if (rb_off[tau] < 0) return;
+  const int ns = S_off[tau + 1] - S_off[tau];
+  const int nb = (ns + EXL_SB - 1) / EXL_SB;
+  if ((int)blockIdx.x >= nb * (nb + 1) / 2) return;
+  int bk = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((bk + 1) * (bk + 2) / 2 <= (int)blockIdx.x) bk++;
+  while (bk * (bk + 1) / 2 > (int)blockIdx.x) bk--;
+  const int bj = blockIdx.x - bk * (bk + 1) / 2;  // bj <= bk
+  const int c0 = tab_ch_off[tau], nco = (tab_ch_off[tau + 1] - c0) * r;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  constexpr int NR = TWO ? 4 : 1, NC = 2;
+  const int t2 = TWO ? (wave & 1) : 0, t1 = TWO ? ((wave >> 1) & 1) : 0;
+  const int b0 = TWO ? 0 : (wave >> 1), a0 = TWO ? 2 * (wave >> 2) : 2 * (wave & 1);
+  const double *Vk = t2 ? V2 : V0, *Vj = t1 ? V2 : V0;
+  const int nn = e * (p - 1) + l15;
+  const bool okrow = l15 < p && nn < R;
+  // element offsets of this lane's row in the k shells (a-operand) and the j shells (b-operand); -1: beyond the list
+  long long offk[NR], offj[NC];
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    const int pk = EXL_SB * bk + b0 + i;
+    offk[i] = (okrow && pk < ns) ? (long long)S_list[S_off[tau] + pk] * R + nn : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    const int pj = EXL_SB * bj + a0 + i;
+    offj[i] = (okrow && pj < ns) ? (long long)S_list[S_off[tau] + pj] * R + nn : -1;
+  }
+  exl_d4 acc[NR][NC];
+#pragma unroll
+  for (int i = 0; i < NR; i++)
+#pragma unroll
+    for (int j = 0; j < NC; j++) acc[i][j] = exl_d4{0.0, 0.0, 0.0, 0.0};
+  const int nsteps = (nco + 3) / 4;
+  auto fetch = [&](int s, double (&fa)[NR], double (&fb)[NC]) {
+    const int cl = 4 * s + l4;
+    const bool in = cl < nco;
+    const int cc = in ? cl : 0;
+    const int c = tab_ch[c0 + cc / r], o = cc % r;
+    const size_t col = ((size_t)c * r + o) * Nd;
+    const double wt = in ? LM_fac[c] * sgn[o] : 0.0;
+#pragma unroll
+    for (int i = 0; i < NR; i++) fa[i] = (in && offk[i] >= 0) ? Vk[col + offk[i]] : 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; i++) fb[i] = (in && offj[i] >= 0) ? wt * Vj[col + offj[i]] : 0.0;
+  };
+  auto mma = [&](const double (&fa)[NR], const double (&fb)[NC]) {
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+#pragma unroll
+      for (int j = 0; j < NC; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+  double fa0[NR], fb0[NC], fa1[NR], fb1[NC];
+  if (nsteps > 0) fetch(0, fa0, fb0);
+  if (nsteps > 1) fetch(1, fa1, fb1);
+  for (int s = 0; s < nsteps; s += 2) {
+    mma(fa0, fb0);
+    if (s + 2 < nsteps) fetch(s + 2, fa0, fb0);
+    if (s + 1 < nsteps) {
+      mma(fa1, fb1);
+      if (s + 3 < nsteps) fetch(s + 3, fa1, fb1);
+    }
+  }
+  const int pp = p * p, Kt = (TWO ? 4 : 1) * pp;
+  const int npair = ns * (ns + 1) / 2;
+  const double sg = (t1 != t2) ? -1.0 : 1.0;
+  const int q = 2 * t1 + t2;
+  if (l15 >= p) return;
+#pragma unroll
+  for (int i = 0; i < NR; i++)
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+      const int pk = EXL_SB * bk + b0 + i, pj = EXL_SB * bj + a0 + j;
+      if (pj > pk || pk >= ns) continue;  // only pj <= pk is stored (K is symmetric)
+      double *out = RB + rb_off[tau] + ((size_t)e * npair + (size_t)pk * (pk + 1) / 2 + pj) * Kt + q * pp + l15;
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int lp = l4 + 4 * reg;
+        if (lp < p) out[lp * p] = sg * acc[i][j][reg];
       }
     }
 }
@@ -800,10 +974,22 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
                      t->shell_skip.p, a.Ld.p);
   hipLaunchKernelGGL(k_exl_V, dim3(NLM, A), dim3(256), 0, s, a.Ld.p, Nd, R, A, r, a.LM_L.p, a.LM_M.p, t->shell_m.p,
                      a.c0tab.p, a.c2tab.p, t->Lp1, two, a.V0.p, a.V2.p);
-  if (!pair)
-    hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol, A), dim3(128), 0, s, a.V0.p, a.V2.p, t->disj.p, t->LM_tab.p,
+  if (!pair) {
+  const size_t alds = (size_t)(two ? 2 : 1) * Nd * sizeof(double);
+  if (p > EXL_AP || E * p > 512 || alds > 150 * 1024)
+    hipLaunchKernelGGL(k_exl_alpha_gen, dim3((unsigned)ncol, A), dim3(128), 0, s, a.V0.p, a.V2.p, t->disj.p, t->LM_tab.p,
                        t->LM_ilm.p, t->LM_fac.p, sgrp, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
                        a.aQw.p);
+  else {
+    // threads: (element, group, row) -- as many groups of shells as fit into 512 threads, EXL_AG at most
+    const int per = E * p, ng = std::max(1, std::min(EXL_AG, 512 / per));
+    if (alds > 64 * 1024)
+      HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_alpha, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+    hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol), dim3(ng * per), alds, s, a.V0.p, two ? a.V2.p : a.V0.p, t->disj.p, t->LM_tab.p,
+                       t->LM_ilm.p, t->LM_fac.p, sgrp, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
+                       a.aQw.p);
+  }
+  }
   // ---- cross-element part: G_ef = aQw_e aP_f^T for e > f (the other half of K is its transpose) ----
   if (!pair) {
     std::vector<GemmTask> ct;
@@ -823,7 +1009,15 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     if (!ct.empty()) {
       a.ctasks.upload(ct, s);
       HFG_HIP_CHECK(hipStreamSynchronize(s));  // ct lives on this stack frame
-      gemm_tasklist_dev(ctx, a.ctasks.p, (int)ct.size(), (int)Ap, (int)Ap);
+      // few large tiles (ten products of 8 x 8 tiles at Nbf = 4230: 640 tiles on 512 slots run as two rounds): two
+      // half-K workgroups per tile into a zeroed G fill the slots evenly (two addends per element: deterministic)
+      const long tiles = (long)ct.size() * ((Ap + 127) / 128) * ((Ap + 127) / 128);
+      static const bool nosplit = getenv("HELFEM_EXL_SPLITK") && atoi(getenv("HELFEM_EXL_SPLITK")) == 0;
+      if (!nosplit && tiles < 2048 && ncol >= 512) {
+        HFG_HIP_CHECK(hipMemsetAsync(a.G.p, 0, sizeof(double) * ct.size() * Ap * Ap, s));
+        gemm_tasklist_split2_dev(ctx, a.ctasks.p, (int)ct.size(), (int)Ap, (int)Ap);
+      } else
+        gemm_tasklist_dev(ctx, a.ctasks.p, (int)ct.size(), (int)Ap, (int)Ap);
     }
   }
 
@@ -905,8 +1099,17 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
                            p, r, ntt, a.RB.p);
       else {
         static const bool rb_one = getenv("HELFEM_EXL_RB") && atoi(getenv("HELFEM_EXL_RB")) == 1;  // the one-pair kernel (checker)
+        static const bool rb_four = getenv("HELFEM_EXL_RB") && atoi(getenv("HELFEM_EXL_RB")) == 4;  // the 4 x 4 vector kernel (checker)
         const size_t shb4 = (size_t)(4 * EXL_SB * EXL_CK * p + EXL_CK) * sizeof(double);
-        if (rb_one || p > 16)
+        if (!rb_one && !rb_four && p <= 16) {
+          const int nb = (max_ns + EXL_SB - 1) / EXL_SB;
+          if (two)
+            hipLaunchKernelGGL(k_exl_RBm<true>, dim3(nb * (nb + 1) / 2, E, nz), dim3(512), 0, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
+                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, a.RB.p);
+          else
+            hipLaunchKernelGGL(k_exl_RBm<false>, dim3(nb * (nb + 1) / 2, E, nz), dim3(512), 0, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
+                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, a.RB.p);
+        } else if (rb_one || p > 16)
           hipLaunchKernelGGL(k_exl_RB, dim3(max_ns * (max_ns + 1) / 2, E, nz), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
                              a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,
                              a.RB.p);
