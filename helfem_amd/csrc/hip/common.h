@@ -144,7 +144,10 @@ struct GemmTask {
                 // are enumerated and computed (k_dgemm_tasklist with beta == 0), k_mirror_lower fills the rest.
                 // 2 (accumulating task lists): only the lower triangle of C and a band of three tile rows above the
                 // diagonal are read afterwards, the other tiles are skipped
-  int pad_ = 0;  // no padding bytes: task lists are compared bytewise (upload_cached)
+  int over = 0;  // over-read permissions (k_dgemm_tasklist): bit 0 -- the rows of op(A) from M up to the edge of the last
+                 // 128-row tile are readable memory (their products land in rows of C that are not stored), bit 1 -- likewise
+                 // the columns of op(B) from N up to the tile edge; lets partial edge tiles use the 16-byte loads.
+                 // (Also fills the struct: task lists are compared bytewise, upload_cached.)
 };
 static_assert(sizeof(GemmTask) == 80, "GemmTask is compared bytewise: keep it free of padding");
 

@@ -331,18 +331,20 @@ __global__ __launch_bounds__(512) void k_exl_alpha(const double *__restrict__ V0
 }
 
 // ktei[tab][e][tt][(i' + p l')][(a + p b)] = tei_tt[tab][e][(a p + i'), (l' p + b)]   (utils::exchange_tei)
-__global__ void k_exl_permute_tei(const double *__restrict__ tei, int Ntab, int E, int p, int ntt,
+// One column-major block of Mld rows x Kcols columns per (tab, e), column tt pp + i' + p l', row a + p b; Mld >= pp and
+// Kcols >= ntt pp pad the block for the GEMM's 16-byte loads (the padding is zeroed by the caller).
+__global__ void k_exl_permute_tei(const double *__restrict__ tei, int Ntab, int E, int p, int ntt, int Mld, int Kcols,
                                   double *__restrict__ ktei) {
   const int blk = blockIdx.x;  // (tt*Ntab + tab)*E + e
   const int e = blk % E, tab = (blk / E) % Ntab, tt = blk / (E * Ntab);
   const int pp = p * p;
   const double *T = tei + (size_t)blk * pp * pp;
-  double *K = ktei + (((size_t)tab * E + e) * ntt + tt) * (size_t)pp * pp;
+  double *K = ktei + (((size_t)tab * E + e) * Kcols + (size_t)tt * pp) * Mld;
   const int lp = blockIdx.y;
   for (int t = threadIdx.x; t < p * pp; t += blockDim.x) {
     int m = t % pp, ip = t / pp;
     int a = m % p, b = m / p;
-    K[(size_t)(ip + p * lp) * pp + m] = T[(size_t)(lp * p + b) * pp + a * p + ip];
+    K[(size_t)(ip + p * lp) * Mld + m] = T[(size_t)(lp * p + b) * pp + a * p + ip];
   }
 }
 
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(512) void k_exl_RBm(const double *__restrict__ V0, 
                                                  const double *__restrict__ LM_fac, const double *__restrict__ sgn,
                                                  const int *__restrict__ S_off, const int *__restrict__ S_list,
                                                  const long long *__restrict__ rb_off, int tau0, int Nd, int R, int E, int p, int r,
-                                                 double *__restrict__ RB) {
+                                                 int Kld, double *__restrict__ RB) {
   const int e = blockIdx.y;
   const int tau = tau0 + blockIdx.z;
   if (rb_off[tau] < 0) return;
@@ -628,14 +630,16 @@ __global__ __launch_bounds__(512) void k_exl_RBm(const double *__restrict__ V0, 
   const int npair = ns * (ns + 1) / 2;
   const double sg = (t1 != t2) ? -1.0 : 1.0;
   const int q = 2 * t1 + t2;
-  if (l15 >= p) return;
 #pragma unroll
   for (int i = 0; i < NR; i++)
 #pragma unroll
     for (int j = 0; j < NC; j++) {
       const int pk = EXL_SB * bk + b0 + i, pj = EXL_SB * bj + a0 + j;
       if (pj > pk || pk >= ns) continue;  // only pj <= pk is stored (K is symmetric)
-      double *out = RB + rb_off[tau] + ((size_t)e * npair + (size_t)pk * (pk + 1) / 2 + pj) * Kt + q * pp + l15;
+      double *col = RB + rb_off[tau] + ((size_t)e * npair + (size_t)pk * (pk + 1) / 2 + pj) * Kld;
+      if (q == 0 && lane < Kld - Kt) col[Kt + lane] = 0.0;  // rows Kt .. Kld of the column: padding of the GEMM's k steps
+      if (l15 >= p) continue;
+      double *out = col + q * pp + l15;
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) {
         const int lp = l4 + 4 * reg;
@@ -799,6 +803,7 @@ __global__ void k_exl_assemble(const double *__restrict__ Kin, const double *__r
 
 struct ExLRAux {
   DevBuf<double> c0tab, c2tab, ktei, L, sgn, dinfo, Ld, V0, V2, aP, aQw, G, RB, C, Kin, Pwork, LS;
+  int kM = 0, kK = 0;  // rows and columns of one exchange-ordered element table (padded, see exlr_for)
   DevBuf<int> info, LM_L, LM_M, tab_ch_off, tab_ch, S_off, S_list, pos, pure_shell, pure_n;
   DevBuf<long long> rb_off, c_off;
   DevBuf<GemmTask> tasks, ctasks;
@@ -880,9 +885,13 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
   // (pair tables, erfc: one block per ordered element pair, the permutation is the same with E^2 "elements")
   const size_t pp = (size_t)t->p * t->p;
   const int nper = t->pair_tei ? t->E * t->E : t->E;
-  a->ktei.resize((size_t)t->ntt * Ntab * nper * pp * pp);
+  // element tables: rows padded to whole 128-row tiles, columns to a multiple of the GEMM's k step (zeros)
+  a->kM = t->pair_tei ? (int)pp : (int)((pp + 127) / 128 * 128);
+  a->kK = t->pair_tei ? (int)(t->ntt * pp) : (int)((t->ntt * pp + 15) / 16 * 16);
+  a->ktei.resize((size_t)Ntab * nper * a->kM * a->kK);
+  HFG_HIP_CHECK(hipMemsetAsync(a->ktei.p, 0, sizeof(double) * (size_t)Ntab * nper * a->kM * a->kK, s));
   hipLaunchKernelGGL(k_exl_permute_tei, dim3(t->ntt * Ntab * nper, t->p), dim3(256), 0, s, t->tei.p, Ntab, nper, t->p,
-                     t->ntt, a->ktei.p);
+                     t->ntt, a->kM, a->kK, a->ktei.p);
   HFG_HIP_CHECK(hipStreamSynchronize(s));
   g_exlr[t] = a;
   return *a;
@@ -1025,6 +1034,11 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   std::vector<long long> rb_off(Ntab, -1), c_off(Ntab, -1);
   std::vector<GemmTask> tasks;
   const int Kt = ntt * pp;
+  // the matrix-core RB kernel writes columns of a.kK >= Kt rows (zero padded like the element tables): every k step of
+  // the GEMM is then a full one; the vector kernels (checkers, p > 16) and the pair tables keep the unpadded columns
+  static const int rb_env = getenv("HELFEM_EXL_RB") ? atoi(getenv("HELFEM_EXL_RB")) : 0;
+  const bool rb_mfma = !pair && p <= 16 && rb_env != 1 && rb_env != 4;
+  const int Kld = rb_mfma ? a.kK : Kt;
   size_t rb_tot = 0, c_tot = 0;
   int maxN = 0;
   for (int tau = 0; tau < Ntab; tau++) {
@@ -1034,11 +1048,11 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     c_off[tau] = (long long)c_tot;
     // blocks per slot: elements x unordered shell pairs, or (pair tables) element pairs e >= f x ordered shell pairs
     const size_t nblk = pair ? (size_t)E * (E + 1) / 2 : (size_t)E, ncols = pair ? (size_t)ns * ns : (size_t)ns * (ns + 1) / 2;
-    rb_tot += nblk * ncols * Kt;
+    rb_tot += nblk * ncols * Kld;
     c_tot += nblk * ncols * pp;
     maxN = std::max(maxN, (int)ncols);
   }
-  a.RB.resize(std::max<size_t>(rb_tot, 1));
+  a.RB.resize(rb_tot + 128 * (size_t)Kld);  // slack: the GEMM may read up to the edge of its last column tile
   a.C.resize(std::max<size_t>(c_tot, 1));
   for (int tau = 0; tau < Ntab; tau++) {
     if (rb_off[tau] < 0) continue;
@@ -1065,15 +1079,16 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     const size_t npair = (size_t)ns * (ns + 1) / 2;
     for (int e = 0; e < E; e++) {
       GemmTask g;
-      g.A = a.ktei.p + (((size_t)tau * E + e) * ntt) * (size_t)pp * pp;
-      g.B = a.RB.p + rb_off[tau] + (size_t)e * npair * Kt;
+      g.A = a.ktei.p + ((size_t)tau * E + e) * (size_t)a.kM * a.kK;
+      g.B = a.RB.p + rb_off[tau] + (size_t)e * npair * Kld;
       g.C = a.C.p + c_off[tau] + (size_t)e * npair * pp;
       g.M = pp;
       g.N = (int)npair;
-      g.K = Kt;
-      g.lda = pp;
-      g.ldb = Kt;
+      g.K = Kld;
+      g.lda = a.kM;
+      g.ldb = Kld;
       g.ldc = pp;
+      g.over = 3;  // the table's rows are padded to whole tiles; RB has slack behind its last column
       tasks.push_back(g);
     }
   }
@@ -1105,10 +1120,10 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
           const int nb = (max_ns + EXL_SB - 1) / EXL_SB;
           if (two)
             hipLaunchKernelGGL(k_exl_RBm<true>, dim3(nb * (nb + 1) / 2, E, nz), dim3(512), 0, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
-                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, a.RB.p);
+                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, Kld, a.RB.p);
           else
             hipLaunchKernelGGL(k_exl_RBm<false>, dim3(nb * (nb + 1) / 2, E, nz), dim3(512), 0, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
-                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, a.RB.p);
+                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, Kld, a.RB.p);
         } else if (rb_one || p > 16)
           hipLaunchKernelGGL(k_exl_RB, dim3(max_ns * (max_ns + 1) / 2, E, nz), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
                              a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,

@@ -50,7 +50,7 @@ template <int BM, int BN, bool ACC = false, int MF = 1>
 __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M, int N, int K, double alpha,
                                            const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
                                            double beta, double *__restrict__ C, int ldc, double (*As)[16][BM + 16],
-                                           double (*Bs)[16][BN + 16], int sym = 0, int kbeg = 0, int kend = -1) {
+                                           double (*Bs)[16][BN + 16], int sym = 0, int kbeg = 0, int kend = -1, int over = 0) {
   constexpr int BK = 16;
   constexpr int PAD = 16;
   constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
@@ -141,8 +141,8 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
   // Fast path (no bounds tests, 16-byte loads): the tile lies inside the operand for this k step, the leading dimension
   // is even and the base address 16-byte aligned; otherwise element-wise loads with bounds tests fill the same registers.
   constexpr int VA = BM * BK / 2 / 256, VB = BN * BK / 2 / 256;  // vectors per thread and tile
-  const bool fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) && (bm + BM <= M);
-  const bool fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0) && (bn + BN <= N);
+  const bool fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0) && (bm + BM <= M || (over & 1));
+  const bool fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((ldb & 1) == 0) && (bn + BN <= N || (over & 2));
   // per-thread origin inside a tile
   const int a_mv = tid % (BM / 2), a_kc = tid / (BM / 2);  // kind C: rows 2 a_mv, column a_kc + r * (512 / BM)
   const int a_m = tid % BM, a_kv = tid / BM;               // kind K: row a_m, k pair a_kv + r * (256 / BM)
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__res
   const int nt = (sym == 1) ? nbm * (nbm + 1) / 2 : nbm * ((t.N + BN - 1) / BN);
   if ((int)blockIdx.x >= nt) return;
   dgemm_tile<BM, BN, ACC, MF>(blockIdx.x, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc,
-                              As, Bs, sym);
+                              As, Bs, sym, 0, -1, t.over);
 }
 
 // Two workgroups per tile, each half of K (rounded to the k step): for batches whose tiles do not fill the chip evenly --
