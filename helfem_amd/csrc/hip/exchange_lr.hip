@@ -559,18 +559,18 @@ __global__ __launch_bounds__(512) void k_exl_RBm(const double *__restrict__ V0, 
                                                  const int *__restrict__ tab_ch_off, const int *__restrict__ tab_ch,
                                                  const double *__restrict__ LM_fac, const double *__restrict__ sgn,
                                                  const int *__restrict__ S_off, const int *__restrict__ S_list,
-                                                 const long long *__restrict__ rb_off, int tau0, int Nd, int R, int E, int p, int r,
-                                                 int Kld, double *__restrict__ RB) {
-  const int e = blockIdx.y;
-  const int tau = tau0 + blockIdx.z;
-  if (rb_off[tau] < 0) return;
+                                                 const long long *__restrict__ rb_off, const int4 *__restrict__ wlist, int nwg,
+                                                 int Nd, int R, int E, int p, int r, int Kld, double *__restrict__ RB) {
+  // workgroup list (slot, element, block pair), slot-major: consecutive workgroup ids go round the 8 XCDs, so every XCD
+  // takes one contiguous eighth of the list -- the blocks of a (slot, element) share their shells' columns of V in ONE L2
+  int id = blockIdx.x;
+  {
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
+    id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
+  }
+  const int4 wd = wlist[id];
+  const int tau = wd.x, e = wd.y, bj = wd.z, bk = wd.w;  // bj <= bk
   const int ns = S_off[tau + 1] - S_off[tau];
-  const int nb = (ns + EXL_SB - 1) / EXL_SB;
-  if ((int)blockIdx.x >= nb * (nb + 1) / 2) return;
-  int bk = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-  while ((bk + 1) * (bk + 2) / 2 <= (int)blockIdx.x) bk++;
-  while (bk * (bk + 1) / 2 > (int)blockIdx.x) bk--;
-  const int bj = blockIdx.x - bk * (bk + 1) / 2;  // bj <= bk
   const int c0 = tab_ch_off[tau], nco = (tab_ch_off[tau + 1] - c0) * r;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   constexpr int NR = TWO ? 4 : 1, NC = 2;
@@ -597,17 +597,32 @@ __global__ __launch_bounds__(512) void k_exl_RBm(const double *__restrict__ V0, 
 #pragma unroll
     for (int j = 0; j < NC; j++) acc[i][j] = exl_d4{0.0, 0.0, 0.0, 0.0};
   const int nsteps = (nco + 3) / 4;
+  // column offset and weight of every (channel, factor) column once per workgroup (the divisions and the three dependent
+  // index loads per fetch kept the vector ALU busier than the matrix pipe); columns nco .. 4 nsteps: weight 0, offset 0
+  extern __shared__ double2 colw[];  // {bit pattern of the offset, weight}
+  for (int cl = threadIdx.x; cl < 4 * nsteps; cl += blockDim.x) {
+    double2 v = {0.0, 0.0};
+    if (cl < nco) {
+      const int c = tab_ch[c0 + cl / r], o = cl % r;
+      v.x = __longlong_as_double((long long)(((size_t)c * r + o) * Nd));
+      v.y = LM_fac[c] * sgn[o];
+    }
+    colw[cl] = v;
+  }
+  __syncthreads();
   auto fetch = [&](int s, double (&fa)[NR], double (&fb)[NC]) {
-    const int cl = 4 * s + l4;
-    const bool in = cl < nco;
-    const int cc = in ? cl : 0;
-    const int c = tab_ch[c0 + cc / r], o = cc % r;
-    const size_t col = ((size_t)c * r + o) * Nd;
-    const double wt = in ? LM_fac[c] * sgn[o] : 0.0;
+    const double2 cw = colw[4 * s + l4];
+    const long long col = __double_as_longlong(cw.x);
 #pragma unroll
-    for (int i = 0; i < NR; i++) fa[i] = (in && offk[i] >= 0) ? Vk[col + offk[i]] : 0.0;
+    for (int i = 0; i < NR; i++) {
+      const double v = Vk[col + (offk[i] >= 0 ? offk[i] : 0)];
+      fa[i] = offk[i] >= 0 ? v : 0.0;
+    }
 #pragma unroll
-    for (int i = 0; i < NC; i++) fb[i] = (in && offj[i] >= 0) ? wt * Vj[col + offj[i]] : 0.0;
+    for (int i = 0; i < NC; i++) {
+      const double v = Vj[col + (offj[i] >= 0 ? offj[i] : 0)];
+      fb[i] = offj[i] >= 0 ? cw.y * v : 0.0;
+    }
   };
   auto mma = [&](const double (&fa)[NR], const double (&fb)[NC]) {
 #pragma unroll
@@ -747,25 +762,57 @@ __global__ void k_exl_reduce_pair(const double *__restrict__ C, const long long 
 
 // Kin[(j,k)][e][(a + p b)] = sum over the table slots that contain both shells of C_tau,e[(a b),(pj,pk)]; the GEMMs
 // only cover pj <= pk, the other half is the transpose
-__global__ void k_exl_reduce(const double *__restrict__ C, const long long *__restrict__ c_off,
-                             const int *__restrict__ S_off, const int *__restrict__ pos, int A, int E, int p, int Ntab,
-                             double *__restrict__ Kin) {
+__global__ __launch_bounds__(256) void k_exl_reduce(const double *__restrict__ C, const long long *__restrict__ c_off,
+                                                    const int *__restrict__ S_off, const int *__restrict__ pos, int A, int E, int p,
+                                                    int Ntab, double *__restrict__ Kin) {
+  // the slots' block offsets for this (j, k, e) first (one thread per slot), then the sums with four loads in flight: the
+  // rolled loop over the slots paid the index loads and the load of C one after the other, 126 times
+  __shared__ long long soff[1024];  // offset of the block, -1: no contribution; bit 62: transposed
   const int jk = blockIdx.x, e = blockIdx.y;
   const int j = jk / A, k = jk % A;
   const int pp = p * p;
-  for (int t = threadIdx.x; t < pp; t += blockDim.x) {
-    const int a = t % p, b = t / p;
-    double s = 0.0;
-    for (int tau = 0; tau < Ntab; tau++) {
-      if (c_off[tau] < 0) continue;
-      int pj = pos[tau * A + j], pk = pos[tau * A + k];
-      if (pj < 0 || pk < 0) continue;
-      int ns = S_off[tau + 1] - S_off[tau];
-      size_t npair = (size_t)ns * (ns + 1) / 2;
-      if (pj <= pk) s += C[c_off[tau] + ((size_t)e * npair + (size_t)pk * (pk + 1) / 2 + pj) * pp + a + p * b];
-      else s += C[c_off[tau] + ((size_t)e * npair + (size_t)pj * (pj + 1) / 2 + pk) * pp + b + p * a];
+  constexpr long long TR = 1ll << 62;
+  for (int t0 = 0; t0 < Ntab; t0 += 1024) {
+    const int nt = min(1024, Ntab - t0);
+    if (t0) __syncthreads();
+    for (int u = threadIdx.x; u < nt; u += blockDim.x) {
+      const int tau = t0 + u;
+      long long o = -1;
+      if (c_off[tau] >= 0) {
+        const int pj = pos[tau * A + j], pk = pos[tau * A + k];
+        if (pj >= 0 && pk >= 0) {
+          const int ns = S_off[tau + 1] - S_off[tau];
+          const size_t npair = (size_t)ns * (ns + 1) / 2;
+          if (pj <= pk) o = c_off[tau] + (long long)(((size_t)e * npair + (size_t)pk * (pk + 1) / 2 + pj) * pp);
+          else o = (c_off[tau] + (long long)(((size_t)e * npair + (size_t)pj * (pj + 1) / 2 + pk) * pp)) | TR;
+        }
+      }
+      soff[u] = o;
     }
-    Kin[((size_t)jk * E + e) * pp + t] = s;
+    __syncthreads();
+    for (int t = threadIdx.x; t < pp; t += blockDim.x) {
+      const int a = t % p, b = t / p;
+      const int in_n = a + p * b, in_t = b + p * a;
+      double s = t0 ? Kin[((size_t)jk * E + e) * pp + t] : 0.0;
+      int u = 0;
+      for (; u + 4 <= nt; u += 4) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const long long o = soff[u + q];
+          v[q] = (o < 0) ? 0.0 : C[(o & ~TR) + ((o & TR) ? in_t : in_n)];
+        }
+        s += v[0];
+        s += v[1];
+        s += v[2];
+        s += v[3];
+      }
+      for (; u < nt; u++) {
+        const long long o = soff[u];
+        if (o >= 0) s += C[(o & ~TR) + ((o & TR) ? in_t : in_n)];
+      }
+      Kin[((size_t)jk * E + e) * pp + t] = s;
+    }
   }
 }
 
@@ -804,6 +851,8 @@ __global__ void k_exl_assemble(const double *__restrict__ Kin, const double *__r
 struct ExLRAux {
   DevBuf<double> c0tab, c2tab, ktei, L, sgn, dinfo, Ld, V0, V2, aP, aQw, G, RB, C, Kin, Pwork, LS;
   int kM = 0, kK = 0;  // rows and columns of one exchange-ordered element table (padded, see exlr_for)
+  DevBuf<int4> rbm_list;  // workgroups of k_exl_RBm: (slot, element, block pair)
+  int rbm_n = 0, rbm_shard = -1;
   DevBuf<int> info, LM_L, LM_M, tab_ch_off, tab_ch, S_off, S_list, pos, pure_shell, pure_n;
   DevBuf<long long> rb_off, c_off;
   DevBuf<GemmTask> tasks, ctasks;
@@ -1117,13 +1166,32 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
         static const bool rb_four = getenv("HELFEM_EXL_RB") && atoi(getenv("HELFEM_EXL_RB")) == 4;  // the 4 x 4 vector kernel (checker)
         const size_t shb4 = (size_t)(4 * EXL_SB * EXL_CK * p + EXL_CK) * sizeof(double);
         if (!rb_one && !rb_four && p <= 16) {
-          const int nb = (max_ns + EXL_SB - 1) / EXL_SB;
-          if (two)
-            hipLaunchKernelGGL(k_exl_RBm<true>, dim3(nb * (nb + 1) / 2, E, nz), dim3(512), 0, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
-                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, Kld, a.RB.p);
-          else
-            hipLaunchKernelGGL(k_exl_RBm<false>, dim3(nb * (nb + 1) / 2, E, nz), dim3(512), 0, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
-                               a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, Kld, a.RB.p);
+          // the list of workgroups depends on the tables and on the shard only
+          if (a.rbm_shard != ctx->shard_rank * 65536 + ctx->shard_n) {
+            std::vector<int4> wl;
+            for (int tau = 0; tau < Ntab; tau++) {
+              if (rb_off[tau] < 0) continue;
+              const int nbk = (a.hS_off[tau + 1] - a.hS_off[tau] + EXL_SB - 1) / EXL_SB;
+              for (int e = 0; e < E; e++)
+                for (int bk = 0; bk < nbk; bk++)
+                  for (int bj = 0; bj <= bk; bj++) wl.push_back(make_int4(tau, e, bj, bk));
+            }
+            a.rbm_n = (int)wl.size();
+            a.rbm_list.upload(wl, s);
+            HFG_HIP_CHECK(hipStreamSynchronize(s));  // wl lives on this stack frame
+            a.rbm_shard = ctx->shard_rank * 65536 + ctx->shard_n;
+          }
+          const size_t shm = (size_t)((a.max_nch * r + 3) / 4 * 4) * sizeof(double2);
+          if (a.rbm_n > 0) {
+            if (two)
+              hipLaunchKernelGGL(k_exl_RBm<true>, dim3(a.rbm_n), dim3(512), shm, s, a.V0.p, a.V2.p, a.tab_ch_off.p, a.tab_ch.p,
+                                 t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, a.rbm_list.p, a.rbm_n, Nd, R, E, p, r, Kld,
+                                 a.RB.p);
+            else
+              hipLaunchKernelGGL(k_exl_RBm<false>, dim3(a.rbm_n), dim3(512), shm, s, a.V0.p, a.V2.p, a.tab_ch_off.p, a.tab_ch.p,
+                                 t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, a.rbm_list.p, a.rbm_n, Nd, R, E, p, r, Kld,
+                                 a.RB.p);
+          }
         } else if (rb_one || p > 16)
           hipLaunchKernelGGL(k_exl_RB, dim3(max_ns * (max_ns + 1) / 2, E, nz), dim3(256), shb, s, a.V0.p, a.V2.p, a.tab_ch_off.p,
                              a.tab_ch.p, t->LM_fac.p, sgrp, a.S_off.p, a.S_list.p, a.rb_off.p, tau0, Nd, R, E, p, r, ntt,
