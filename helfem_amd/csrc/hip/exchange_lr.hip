@@ -261,8 +261,8 @@ __global__ void k_exl_alpha_gen(const double *__restrict__ V0, const double *__r
 
 // aP[(c,o)][(j,e,a)] = sum_c' P0_e(a,c') V0[j, e(p-1)+c'] - P2_e(a,c') V2[...];  aQw = w_(c,o) * (same with Q0, Q2)
 // One workgroup per (channel, factor) column: thread (group g, element e, row a) keeps row a of the four p x p tables of
-// its element in registers and walks over the shells j = g, g + EXL_AG, ...; the p values of V it needs per shell are the
-// same for the p lanes of an (e, j) and come through the L1.  (One workgroup per (column, shell) with the tables read
+// its element in registers and walks over the shells j = g, g + EXL_AG, ...; the column of V is staged in LDS (the p
+// values a thread needs per shell are the same for the p lanes of an (e, j): broadcast reads).  (One workgroup per (column, shell) with the tables read
 // from L2 per output took 1.5 ms at Nbf = 4230: 268 000 workgroups of 75 active threads.)
 constexpr int EXL_AG = 4;
 constexpr int EXL_AP = 16;  // p at most
