@@ -99,6 +99,38 @@ def seeded_density(N, nocc, blocks, Sinvh, seed=20260130):
     return 2.0 * (C @ C.T)
 
 
+def stage_rooflines(basis, w, sizes, fams):
+    """Coulomb against HBM, the eigensolve's N^3 products against the FP64 matrix peak.
+    Coulomb: read P, write J, the (L,M) intermediates once, the in-element tables once:
+    2 (Nd^2 + 2 N_LM R^2) 8 B + 4 N_lm E p^4 8 B.  Products per block: F X (2 n^3), the lower 128 x 128 tiles of
+    X^T (F X), C = X Z (2 n^3)."""
+    out = []
+    try:
+        lm = basis.lm_map()
+        n_lm, n_LM = len(lm), sum(1 if m == 0 else 2 for (_, m) in lm)
+        R, E, p = basis.Nrad(), w["nelem"], w["nnodes"]
+        Nd = basis.Nang() * R
+        cbytes = 2.0 * (Nd * Nd + 2.0 * n_LM * R * R) * 8 + 4.0 * n_lm * E * p ** 4 * 8
+        ms = fams["coulomb"]["ms_per_step"]
+        if ms > 0:
+            gbs = cbytes / (ms * 1e-3) / 1e9
+            out.append({"stage": "coulomb (4 kernels)", "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                        "frac": gbs / 8000.0, "algorithmic_bytes": cbytes, "ms": ms})
+    except Exception:
+        pass
+    ms = fams.get("eig_products", {}).get("ms_per_step", 0.0)
+    if ms > 0:
+        fl = 0.0
+        for n in sizes:
+            t = (n + 127) // 128
+            low = sum(min(128, n - 128 * i) * min(128, n - 128 * j) for i in range(t) for j in range(i + 1))
+            fl += 2.0 * n ** 3 + 2.0 * n * low + 2.0 * n ** 3
+        tf = fl / (ms * 1e-3) / 1e12
+        out.append({"stage": "eigensolve N^3 products (F X, lower tiles of X^T(F X), X Z)", "bound": "mfma", "achieved": tf,
+                    "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "flops": fl, "ms": ms})
+    return out
+
+
 def usable_cores():
     """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a GPU box
     hands a 256-core host's affinity to a job that owns 16 CPUs' worth of time: 256 spinning BLAS threads on that are
@@ -281,7 +313,7 @@ def main():
 
     fams = {}
     for name in ("coulomb", "xc", "scatter", "eig_reduce", "eig_tridiag", "eig_tridiag_solve", "eig_backtransform",
-                 "gemm", "density"):
+                 "gemm", "eig_products", "density"):
         ms, n = ctx.profile_get(name)
         fams[name] = dict(ms_per_step=ms / args.steps, calls=n)
     ctx.profile(False)
@@ -356,6 +388,8 @@ def main():
                          "avg_launch_us": avg_ms * 1e3, "launches_per_step": launches_per_step,
                          "note": "latency-bound: one dependent launch per Householder column (see DESIGN.md 3.4)"},
             "stages_ms": {k: round(v["ms_per_step"], 4) for k, v in fams.items()},
+            # the other stages against their own bounds (stage time of this run, algorithmic work)
+            "stage_rooflines": stage_rooflines(basis, w, my_sizes, fams),
             # size-independent self-check of the timed path: must not depend on the number of ranks
             "check": check,
         }

@@ -1139,6 +1139,7 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
       const bool split_full = force_split >= 0 ? force_split != 0 : (full_tiles < slots && nm >= 256);
       const bool split_low = force_split >= 0 ? force_split != 0 : (low_tiles < slots && nm >= 256);
       w.split_full = split_full;
+      ProfScope pp3(ctx, "eig_products");  // the N^3 products alone (bench.py: MFMA fraction of the tile engine)
       if (split_full) {
         for (int k = 0; k < nb; k++) HFG_HIP_CHECK(hipMemsetAsync(T1.p + (size_t)k * nmax * nmax, 0, sizeof(double) * (size_t)ns[k] * ns[k], s));
         gemm_tasklist_split2_dev(ctx, w.gtasks.p, nb, nm, nm);
@@ -1155,9 +1156,12 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
     {
       ProfScope ps(ctx, "eig_backtransform");
       static const bool rect = getenv("HELFEM_GEMM_RECT") && atoi(getenv("HELFEM_GEMM_RECT"));
-      if (w.split_full) gemm_tasklist_split2_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);  // the block slots were zeroed above
-      else if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
-      else gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+      {
+        ProfScope pp3(ctx, "eig_products");
+        if (w.split_full) gemm_tasklist_split2_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);  // the block slots were zeroed above
+        else if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+        else gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+      }
       for (int k = 0; k < nb; k++) {
         const int ib = mine[c0 + k] % nblk;
         int n = ns[k];
