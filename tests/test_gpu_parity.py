@@ -144,6 +144,26 @@ def test_xc_kernels_with_chunked_angular_tables(hf):
     assert "worst relative deviation" in p.stdout.decode()
 
 
+@pytest.mark.parametrize("rb", ["", "1", "4"])
+def test_exchange_rb_kernels_at_large_element_order(hf, rb):
+    """exact exchange against the oracle at 15, 16 and 17 nodes per element (tests/exl_worker.py, one child process per
+    setting because HELFEM_EXL_RB is read once): the matrix-core RB kernel with and without a padding row in its 16 x 16
+    tiles and the one-pair kernel beyond 16 nodes; HELFEM_EXL_RB = 1 / 4 run the two vector kernels (the checkers of the
+    matrix-core one) on the padded element tables"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("HELFEM_EXL_RB", None)
+    if rb:
+        env["HELFEM_EXL_RB"] = rb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "exl_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    assert "worst relative deviation" in p.stdout.decode()
+
+
 def test_exchange_of_a_density_with_more_than_64_factors(case, monkeypatch):
     """rank 70 ... 150: the fast path factorises the residual matrix again (groups of 64 factors, K is linear in P) instead
     of handing the density to the general kernels; HELFEM_EXL_GROUPS=1 restores the single-group behaviour (fallback)"""
