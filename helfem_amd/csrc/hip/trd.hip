@@ -102,7 +102,10 @@ __global__ __launch_bounds__(64) void k_trdb_loadcol(const TrdBatch *__restrict_
 // the slabs are kept small (32 columns) so that the whole matrix is in flight at once.
 __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ bp, int i, int c, int ncs) {
   const TrdBatch &b = *bp;
-  extern __shared__ double sh[];  // v[m], red[4*128]
+  // LDS: v on this workgroup's column chunk and on its rows only (the whole vector, 8 n bytes, left room for ONE
+  // workgroup per CU beyond n ~ 8000 and was read from L2 by every workgroup: more bytes than the matrix itself),
+  // vcol[cchunk], vrow[129], red[4*128]
+  extern __shared__ double sh[];
   const int blk = blockIdx.y;
   const int n = b.n[blk];
   if (i > n - 3) return;
@@ -110,39 +113,45 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
   const int nrs = (m + 1 + 127) / 128;  // one spare row for the alignment shift
   const int rs = blockIdx.x / ncs, cs = blockIdx.x % ncs;
   if (rs >= nrs) return;
-  double *vsh = sh;
-  double *red = sh + n;
   __shared__ double nsum[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double *A = b.A[blk];
   const int cchunk = (m + ncs - 1) / ncs;
   const int c0 = cs * cchunk, c1 = min(m, c0 + cchunk);
+  double *vcol = sh;
+  double *vrow = sh + cchunk;
+  double *red = vrow + 136;
   // A lane owns the row pair (row, row+1).  For even n the pairs are shifted by delta so that every pair is a
   // 16-byte aligned double2 in every column (1 KiB per wave instruction at the full 16-B/lane rate).
   const bool vec2 = ((n & 1) == 0);
   const int delta = vec2 ? (int)((((size_t)(i + 1) * n + (i + 1))) & 1) : 0;
   const int row = rs * 128 + 2 * lane - delta;
   const double *a = A + (size_t)(i + 1) * n + (i + 1) + row;
-  // ---- issue the first batch of matrix loads (16 columns x 2 rows per lane) ----
+  // ---- matrix loads in batches of 16 columns x 2 rows per lane, all of a batch in flight at once ----
   constexpr int NU = 16;
   double r0[NU], r1[NU];
+  const bool pair_ok = vec2 && row >= 0 && row + 1 < m;
+  const bool ok0 = row >= 0 && row < m, ok1 = row + 1 >= 0 && row + 1 < m;
+  auto load_batch = [&](int base) {
 #pragma unroll
-  for (int u = 0; u < NU; u++) {
-    int cc = c0 + wave + 4 * u;
-    bool ok = (cc < c1);
-    r0[u] = 0.0;
-    r1[u] = 0.0;
-    if (ok) {
-      if (vec2 && row >= 0 && row + 1 < m) {
-        double2 t = *reinterpret_cast<const double2 *>(a + (size_t)cc * n);
-        r0[u] = t.x;
-        r1[u] = t.y;
-      } else {
-        if (row >= 0 && row < m) r0[u] = a[(size_t)cc * n];
-        if (row + 1 >= 0 && row + 1 < m) r1[u] = a[(size_t)cc * n + 1];
+    for (int u = 0; u < NU; u++) {
+      int cc = base + wave + 4 * u;
+      bool ok = (cc < c1);
+      r0[u] = 0.0;
+      r1[u] = 0.0;
+      if (ok) {
+        if (pair_ok) {
+          double2 t = *reinterpret_cast<const double2 *>(a + (size_t)cc * n);
+          r0[u] = t.x;
+          r1[u] = t.y;
+        } else {
+          if (ok0) r0[u] = a[(size_t)cc * n];
+          if (ok1) r1[u] = a[(size_t)cc * n + 1];
+        }
       }
     }
-  }
+  };
+  load_batch(c0);  // the first batch travels during the Householder prologue
   // ---- Householder vector of the (already updated) column i ----
   const double *x = b.col[blk] + i + 1;
   {
@@ -152,11 +161,17 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
     t = wave_sum(t);
     if (lane == 0) nsum[wave] = t;
   }
-  double xv[4];  // up to 1024 rows per pass; longer columns loop below
-  const int npass = (m + 255) / 256;
-  for (int q = 0; q < 4; q++) {
-    int k = tid + 256 * q;
-    xv[q] = (q < npass && k < m) ? x[k] : 0.0;
+  // x on the column chunk (two values per thread up to 512 columns, the rest in the loop below) and on the rows
+  double xc[2];
+  for (int q = 0; q < 2; q++) {
+    int k = c0 + tid + 256 * q;
+    xc[q] = (k < c1) ? x[k] : 0.0;
+  }
+  const int rrow = rs * 128 - delta + tid;  // vrow[t] = v[rs 128 - delta + t], t < 129
+  double xr = (tid < 129 && rrow >= 0 && rrow < m) ? x[rrow] : 0.0, xr2 = 0.0;
+  if (tid == 0) {
+    const int r2 = rs * 128 - delta + 128;
+    xr2 = (r2 >= 0 && r2 < m) ? x[r2] : 0.0;
   }
   const double alpha0 = x[0];
   __syncthreads();
@@ -174,17 +189,19 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
       scale = 1.0 / (alpha0 - beta);
     }
   }
-  for (int q = 0; q < 4 && q < npass; q++) {
-    int k = tid + 256 * q;
-    if (k < m) vsh[k] = (k == 0) ? 1.0 : xv[q] * scale;
+  for (int q = 0; q < 2; q++) {
+    int k = c0 + tid + 256 * q;
+    if (k < c1) vcol[k - c0] = (k == 0) ? 1.0 : xc[q] * scale;
   }
-  for (int k = tid + 1024; k < m; k += 256) vsh[k] = x[k] * scale;
+  for (int k = c0 + tid + 512; k < c1; k += 256) vcol[k - c0] = x[k] * scale;
+  if (tid < 128) vrow[tid] = (rrow == 0) ? 1.0 : xr * scale;  // rows outside the block: 0 (xr = 0)
+  if (tid == 0) vrow[128] = (rs * 128 - delta + 128 == 0) ? 1.0 : xr2 * scale;
   __syncthreads();
   if (blockIdx.x == 0) {
     // panel bookkeeping by the first workgroup: V(:,c) = v, Householder vector stored in A for the back-transformation
     double *Vc = b.V[blk] + (size_t)c * n;
-    for (int k = tid; k < n; k += 256) Vc[k] = (k >= i + 1) ? vsh[k - i - 1] : 0.0;
-    for (int k = 1 + tid; k < m; k += 256) A[(size_t)i * n + i + 1 + k] = vsh[k];
+    for (int k = tid; k < n; k += 256) Vc[k] = (k >= i + 1) ? ((k == i + 1) ? 1.0 : x[k - i - 1] * scale) : 0.0;
+    for (int k = 1 + tid; k < m; k += 256) A[(size_t)i * n + i + 1 + k] = x[k] * scale;
     if (tid == 0) {
       b.tau[blk][i] = tau;
       b.e[blk][i] = beta;
@@ -192,17 +209,15 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
     }
   }
   double acc0 = 0.0, acc1 = 0.0;
+  for (int base = c0; base < c1; base += 4 * NU) {  // slabs wider than 64 columns: very large matrices only
+    if (base > c0) load_batch(base);
 #pragma unroll
-  for (int u = 0; u < NU; u++) {
-    int cc = c0 + wave + 4 * u;
-    double vc = (cc < c1) ? vsh[cc] : 0.0;
-    acc0 += r0[u] * vc;
-    acc1 += r1[u] * vc;
-  }
-  for (int cc = c0 + wave + 4 * NU; cc < c1; cc += 4) {  // slabs wider than 64 columns (very large matrices only)
-    double vc = vsh[cc];
-    if (row >= 0 && row < m) acc0 += a[(size_t)cc * n] * vc;
-    if (row + 1 >= 0 && row + 1 < m) acc1 += a[(size_t)cc * n + 1] * vc;
+    for (int u = 0; u < NU; u++) {
+      int cc = base + wave + 4 * u;
+      double vc = (cc < c1) ? vcol[cc - c0] : 0.0;
+      acc0 += r0[u] * vc;
+      acc1 += r1[u] * vc;
+    }
   }
   red[wave * 128 + 2 * lane] = acc0;
   red[wave * 128 + 2 * lane + 1] = acc1;
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
     const bool okr = (r >= 0 && r < m);
     double p = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     if (okr) b.pp[blk][(size_t)cs * n + r] = p;
-    double dv = okr ? p * vsh[r] : 0.0;
+    double dv = okr ? p * vrow[tid] : 0.0;
     dv = wave_sum(dv);
     if ((tid & 63) == 0) b.dots[blk][blockIdx.x * 2 + (tid >> 6)] = dv;
   }
@@ -223,7 +238,7 @@ __global__ __launch_bounds__(256) void k_trdb_gemv(const TrdBatch *__restrict__ 
       double t = 0.0;
       for (int h = 0; h < 2; h++) {
         int r = rs * 128 + h * 64 + lane;
-        if (r < m) t += M[i + 1 + r] * vsh[r];
+        if (r < m) t += M[i + 1 + r] * vrow[h * 64 + lane + delta];
       }
       t = wave_sum(t);
       if (lane == 0) b.cpart[blk][(size_t)rs * 2 * TB_NB + cc] = t;
@@ -1217,7 +1232,8 @@ void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *
   hipStream_t s = ctx->stream;
   upload_cached(w.desc, w.h_desc, std::vector<TrdBatch>(1, b), s);
   const TrdBatch *db = w.desc.p;
-  size_t shb = (size_t)(nmax + 4 * 128 + 8) * sizeof(double);
+  // k_trdb_gemv: v on a column chunk (at most 64 chunks per column) and on 129 rows, 4 x 128 partial sums
+  size_t shb = (size_t)(std::max(64, (nmax + 63) / 64 + 1) + 136 + 4 * 128 + 8) * sizeof(double);
   if (shb > 64 * 1024)
     HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_trdb_gemv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
   // HELFEM_TRD=twokernel keeps the earlier two-launches-per-column variant (k_trdb_gemv + k_trdb_w)
@@ -1374,7 +1390,8 @@ void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches) {
     s = cap;
   }
   const TrdBatch *db = w.desc.p;
-  size_t shb = (size_t)(nmax + 4 * 128 + 8) * sizeof(double);
+  // k_trdb_gemv: v on a column chunk (at most 64 chunks per column) and on 129 rows, 4 x 128 partial sums
+  size_t shb = (size_t)(std::max(64, (nmax + 63) / 64 + 1) + 136 + 4 * 128 + 8) * sizeof(double);
   hipEvent_t e0, e1;
   HFG_HIP_CHECK(hipEventCreate(&e0));
   HFG_HIP_CHECK(hipEventCreate(&e1));
