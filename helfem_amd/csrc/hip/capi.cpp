@@ -15,7 +15,8 @@ void set_error(const std::string &msg) { g_err = msg; }
 void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr);
-void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false);
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false, const double *Lknown = nullptr,
+                  int rknown = 0);
 void sb_reduce_to_band(hfg_ctx *ctx, int nblk, const int *ns, double *const *A);
 void sb_fetch_band(hfg_ctx *ctx, int blk, int n, double *hostAB);
 void sb_fetch_debug(hfg_ctx *ctx, int which, int n, double *host, size_t count);

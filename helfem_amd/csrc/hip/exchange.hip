@@ -271,10 +271,10 @@ static ExAux &exaux_for(hfg_ctx *ctx, hfg_dev_tables *t) {
   return *a;
 }
 
-bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, double *dK);
+bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, double *dK, const double *Lknown, int rknown);
 
 // rs: the range-separated kernel of TwoDBasis::rs_exchange (src/atomic/TwoDBasis.cpp:1142) through basis->dev_rs
-void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs) {
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs, const double *Lknown, int rknown) {
   hfg_dev_tables *t = rs ? basis->dev_rs : basis->dev;
   if (!t || !t->have_tei) throw std::logic_error("Primitive teis have not been computed!\n");
   if (basis->dev_device != ctx->device) throw std::logic_error("basis tables live on a different device\n");
@@ -283,7 +283,7 @@ void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, 
   // general kernels below, which take any symmetric P
   {
     const char *mode = getenv("HELFEM_EXCHANGE");
-    if (!(mode && std::string(mode) == "general") && exchange_lowrank_dev(ctx, t, dP, dK)) return;
+    if (!(mode && std::string(mode) == "general") && exchange_lowrank_dev(ctx, t, dP, dK, Lknown, rknown)) return;
   }
   ExAux &a = exaux_for(ctx, t);
   hipStream_t s = ctx->stream;

@@ -162,14 +162,20 @@ __global__ __launch_bounds__(256) void k_exl_resid(const double *__restrict__ P,
   __syncthreads();
   double res = 0.0, pa = 0.0;
   if (i < N)
-    for (int jj = 0; jj < 32 && j0 + jj < N; jj++) {
-      double pv = P[(size_t)(j0 + jj) * N + i];
-      double acc = pv;
+    for (int jb = 0; jb < 32; jb += 8) {
+      // eight columns at a time: their loads of P travel together (one load per column in a rolled loop paid 32 round trips)
+      double pv[8];
 #pragma unroll
-      for (int k = 0; k < EXL_RMAX; k++)
-        if (k < r) acc -= li[k] * lj[jj][k];
-      res = fmax(res, fabs(acc));
-      pa = fmax(pa, fabs(pv));
+      for (int u = 0; u < 8; u++) pv[u] = (j0 + jb + u < N) ? P[(size_t)(j0 + jb + u) * N + i] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        double acc = pv[u];
+#pragma unroll
+        for (int k = 0; k < EXL_RMAX; k++)
+          if (k < r) acc -= li[k] * lj[jb + u][k];
+        if (j0 + jb + u < N) res = fmax(res, fabs(acc));
+        pa = fmax(pa, fabs(pv[u]));
+      }
     }
   for (int o = 32; o > 0; o >>= 1) {
     res = fmax(res, __shfl_down(res, o, 64));
@@ -852,6 +858,7 @@ struct ExLRAux {
   DevBuf<double> c0tab, c2tab, ktei, L, sgn, dinfo, Ld, V0, V2, aP, aQw, G, RB, C, Kin, Pwork, LS;
   int kM = 0, kK = 0;  // rows and columns of one exchange-ordered element table (padded, see exlr_for)
   DevBuf<int4> rbm_list;  // workgroups of k_exl_RBm: (slot, element, block pair)
+  DevBuf<double> ones;     // EXL_RMAX ones: the signs of factors handed in by the caller
   int rbm_n = 0, rbm_shard = -1;
   DevBuf<int> info, LM_L, LM_M, tab_ch_off, tab_ch, S_off, S_list, pos, pure_shell, pure_n;
   DevBuf<long long> rb_off, c_off;
@@ -934,6 +941,8 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
   // (pair tables, erfc: one block per ordered element pair, the permutation is the same with E^2 "elements")
   const size_t pp = (size_t)t->p * t->p;
   const int nper = t->pair_tei ? t->E * t->E : t->E;
+  const std::vector<double> ones_h((size_t)EXL_RMAX, 1.0);  // alive until the synchronisation below
+  a->ones.upload(ones_h, s);
   // element tables: rows padded to whole 128-row tiles, columns to a multiple of the GEMM's k step (zeros)
   a->kM = t->pair_tei ? (int)pp : (int)((pp + 127) / 128 * 128);
   a->kK = t->pair_tei ? (int)(t->ntt * pp) : (int)((t->ntt * pp + 15) / 16 * 16);
@@ -948,7 +957,9 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
 
 /// K from P through the low-rank factors.  Returns false (nothing written) when P is not reproduced by at most
 /// EXL_RMAX factors; the caller then runs the general kernels.
-bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, double *dK) {
+/// Lknown / rknown: the caller KNOWS P = sum_o l_o l_o^T (the device-resident SCF loop: P = C_occ C_occ^T, formed from the
+/// same columns one line earlier): the factorisation, its verification and their host synchronisation are skipped.
+bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, double *dK, const double *Lknown, int rknown) {
   const int A = t->A, R = t->R, E = t->E, p = t->p, Nd = t->Nd, N = t->N, NLM = t->NLM, Ntab = t->Ntab, ntt = t->ntt;
   if (N > 1024 * EXL_QMAX) return false;
   // erfc kernel (pair_tei): no factorisation over elements; the element-pair products below need an exchange-ordered
@@ -975,6 +986,15 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   double pmax = 0.0;
   bool reproduced = false;
   const double *Pcur = dP;
+  static const bool no_hint = getenv("HELFEM_EXL_HINT") && atoi(getenv("HELFEM_EXL_HINT")) == 0;  // checker: always factorise
+  if (Lknown && rknown >= 0 && rknown <= EXL_RMAX && !no_hint) {
+    if (rknown > 0) {
+      HFG_HIP_CHECK(hipMemcpyAsync(a.L.p, Lknown, sizeof(double) * (size_t)N * rknown, hipMemcpyDeviceToDevice, s));
+      HFG_HIP_CHECK(hipMemcpyAsync(a.sgn.p, a.ones.p, sizeof(double) * (size_t)rknown, hipMemcpyDeviceToDevice, s));
+    }
+    rg.push_back(rknown);
+    reproduced = true;
+  }
   for (int g = 0; g < gmax && !reproduced; g++) {
     double *Lg = a.L.p + (size_t)g * N * EXL_RMAX, *sg = a.sgn.p + (size_t)g * EXL_RMAX;
     HFG_HIP_CHECK(hipMemsetAsync(a.dinfo.p, 0, 2 * sizeof(double), s));

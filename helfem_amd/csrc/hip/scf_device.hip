@@ -21,7 +21,8 @@ namespace hfg {
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
 void coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
-void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false);
+void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false, const double *Lknown = nullptr,
+                  int rknown = 0);
 void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH, double *dScal,
                  double thr);
 void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
@@ -573,20 +574,22 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     res.tJ = wall() - tJ0;
     double tK0 = wall();
     if (anyK) {
-      auto buildK = [&](const double *Ps, double *K) {  // K = kfrac K[1/r12] + kshort K[screened kernel]
+      // Ps = C_occ C_occ^T was formed from the first nocc columns of Cs above: the exchange fast path takes them as its
+      // factors instead of recovering them from Ps
+      auto buildK = [&](const double *Ps, const double *Cs, int nocc, double *K) {  // K = kfrac K[1/r12] + kshort K[screened kernel]
         if (opt.kfrac != 0.0) {
-          exchange_dev(ctx, hb, Ps, K);
+          exchange_dev(ctx, hb, Ps, K, false, Cs, nocc);
           d.axpby(0.0, K, opt.kfrac, K, NN);
         } else
           HFG_HIP_CHECK(hipMemsetAsync(K, 0, sizeof(double) * NN, s));
         if (opt.omega != 0.0) {
-          exchange_dev(ctx, hb, Ps, Krs.p, true);
+          exchange_dev(ctx, hb, Ps, Krs.p, true, Cs, nocc);
           d.axpby(opt.kshort, Krs.p, 1.0, K, NN);
         }
       };
-      buildK(d.Pa.p, d.Ka.p);
+      buildK(d.Pa.p, d.Ca.p, nela, d.Ka.p);
       if (!restr) {
-        if (nelb) buildK(d.Pb.p, d.Kb.p);
+        if (nelb) buildK(d.Pb.p, d.Cb.p, nelb, d.Kb.p);
         else HFG_HIP_CHECK(hipMemsetAsync(d.Kb.p, 0, sizeof(double) * NN, s));
       }
       if (verbose) HFG_HIP_CHECK(hipStreamSynchronize(s));
