@@ -34,6 +34,7 @@ void eig_sym_dev(hfg_ctx *ctx, int n, const double *dA, double *dE, double *dC);
 void eig_block_supports(hfg_ctx *ctx, int N, const double *dS, int nblk, const int64_t *blk_ptr, const int64_t *blk_idx,
                         std::vector<int64_t> &cols);
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void eig_gsym_sub_pair_dev(hfg_ctx *ctx, int N, const double *dFa, const double *dFb, const double *dS, int nblk, const int64_t *blk_ptr,
                            const int64_t *blk_idx, double *dEa, double *dCa, double *dEb, double *dCb);
 void eig_gsym_sub_dev(hfg_ctx *ctx, int N, const double *dF, const double *dS, int nblk, const int64_t *blk_ptr,
@@ -65,6 +66,11 @@ __global__ void k_gather_rc(const double *__restrict__ M, int N, const int64_t *
                             double *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
   if (i < n) out[(size_t)j * n + i] = M[(size_t)cols[j] * N + rows[i]];
+}
+// out (n x nc, column-major, ld n) = M(rows, 0:nc) of a matrix with N rows
+__global__ void k_gather_rows(const double *__restrict__ M, int N, const int64_t *__restrict__ rows, int n, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (i < n) out[(size_t)j * n + i] = M[(size_t)j * N + rows[i]];
 }
 // E = X - X^T for a block of order n
 __global__ void k_antisym_block(const double *__restrict__ X, int n, double *__restrict__ E) {
@@ -299,6 +305,81 @@ struct DevSCF {
       }
     gemm_tasklist_dev(ctx, be.tasks.p + 2 * nt, nt, be.nmax, be.nmax);
     gemm_tasklist_dev(ctx, be.tasks.p + 3 * nt, nt, be.nmax, be.nmax);
+  }
+  // The same blocks from the occupied orbitals: P = C_o C_o^T (formed from these columns by the loop itself), so
+  //   e_b = U Y^T - Y U^T,   U = X_b^T F_b C_o(idx_b, :),   Y = X_b^T S_b C_o(idx_b, :)
+  // -- products with nocc columns instead of four n^3 products per block (orbitals of other blocks are zero rows here and
+  // add nothing).  Three task-list launches: [F_b C | S_b C], [U | -Y] and [Y | U] (each product written where the last
+  // one needs it), e_b = [U | -Y] [Y | U]^T.
+  DevBuf<double> lrC, lrT, lrG;  // per (spin, block): C rows (nmax x nocc), F C and S C (2 x), [U | -Y] and [Y | U]
+  void blocked_error_lowrank(const double *const *F, const double *const *C, const int *nocc, double *const *errs) {
+    const size_t sl = (size_t)be.nmax * be.nmax;
+    const int nt = be.nspin * be.nblk;
+    int kmax = 0;
+    for (int sp = 0; sp < be.nspin; sp++) kmax = std::max(kmax, nocc[sp]);
+    const size_t cs = (size_t)be.nmax * std::max(kmax, 1);
+    lrC.resize(cs * nt);
+    lrT.resize(2 * cs * nt);
+    lrG.resize(4 * cs * nt);
+    std::vector<GemmTask> t;
+    std::vector<GemmTask> t1, t2, t3;
+    for (int sp = 0; sp < be.nspin; sp++)
+      for (int b = 0; b < be.nblk; b++) {
+        const int nb = be.ns[b], k = sp * be.nblk + b, no = nocc[sp];
+        if (no == 0) {
+          HFG_HIP_CHECK(hipMemsetAsync(errs[sp] + be.eoff[b], 0, sizeof(double) * (size_t)nb * nb, s));
+          continue;
+        }
+        hipLaunchKernelGGL(k_gather_rc, dim3((nb + 255) / 256, nb), dim3(256), 0, s, F[sp], (int)N, be.rows.p + be.ptr[b],
+                           be.rows.p + be.ptr[b], nb, be.Fb.p + sl * k);
+        hipLaunchKernelGGL(k_gather_rows, dim3((nb + 255) / 256, no), dim3(256), 0, s, C[sp], (int)N, be.rows.p + be.ptr[b], nb,
+                           lrC.p + cs * k);
+        double *FC = lrT.p + 2 * cs * k, *SC = FC + cs;
+        double *G1 = lrG.p + 4 * cs * k, *G2 = G1 + 2 * cs;  // [U | -Y], [Y | U], nb x 2 no each
+        GemmTask q;
+        q.M = nb;
+        q.N = no;
+        q.K = nb;
+        q.lda = q.ldb = q.ldc = nb;
+        q.B = lrC.p + cs * k;
+        q.A = be.Fb.p + sl * k;
+        q.C = FC;
+        t1.push_back(q);
+        q.A = be.Sb.p + sl * b;
+        q.C = SC;
+        t1.push_back(q);
+        q.A = be.Xb.p + sl * b;
+        q.tA = 1;
+        q.B = FC;  // U
+        q.C = G1;
+        t2.push_back(q);
+        q.C = G2 + (size_t)nb * no;
+        t2.push_back(q);
+        q.B = SC;  // Y
+        q.C = G2;
+        t2.push_back(q);
+        q.alpha = -1.0;
+        q.C = G1 + (size_t)nb * no;
+        t2.push_back(q);
+        GemmTask e;
+        e.M = e.N = nb;
+        e.K = 2 * no;
+        e.lda = e.ldb = e.ldc = nb;
+        e.A = G1;
+        e.B = G2;
+        e.tB = 1;
+        e.C = errs[sp] + be.eoff[b];
+        t3.push_back(e);
+      }
+    if (t3.empty()) return;
+    t = t1;
+    t.insert(t.end(), t2.begin(), t2.end());
+    t.insert(t.end(), t3.begin(), t3.end());
+    be.tasks.upload(t, s);
+    HFG_HIP_CHECK(hipStreamSynchronize(s));  // t lives on this stack frame
+    gemm_tasklist64_dev(ctx, be.tasks.p, (int)t1.size(), be.nmax, kmax);
+    gemm_tasklist64_dev(ctx, be.tasks.p + t1.size(), (int)t2.size(), be.nmax, kmax);
+    gemm_tasklist_dev(ctx, be.tasks.p + t1.size() + t2.size(), (int)t3.size(), be.nmax, be.nmax);
   }
 };
 
@@ -665,7 +746,13 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     if (blocked_err) {
       const double *Fs[2] = {d.Fa.p, nspin == 2 ? d.Fb.p : nullptr}, *Ps[2] = {d.Pa.p, nspin == 2 ? d.Pb.p : nullptr};
       double *Es[2] = {d.histE[slot].p, d.histE[slot].p + d.be.etot};  // the spins' blocks one after the other
-      d.blocked_error(Fs, Ps, Es);
+      // P = C_occ C_occ^T of this iteration's orbitals: the error from the occupied columns (HELFEM_DIIS_LOWRANK=0: the
+      // four n^3 products per block from F and P, the checker)
+      static const bool lowrank_off = getenv("HELFEM_DIIS_LOWRANK") && atoi(getenv("HELFEM_DIIS_LOWRANK")) == 0;
+      const double *Cs[2] = {d.Ca.p, nspin == 2 ? d.Cb.p : nullptr};
+      const int noccs[2] = {nela, nelb};
+      if (lowrank_off) d.blocked_error(Fs, Ps, Es);
+      else d.blocked_error_lowrank(Fs, Cs, noccs, Es);
     }
     for (int sp = 0; sp < nspin; sp++) {
       double *F = sp ? d.Fb.p : d.Fa.p;

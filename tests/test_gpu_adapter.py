@@ -167,8 +167,9 @@ def test_diatomic_executable_h2_hf_and_its_checkpoint(hf, tmp_path):
     assert abs(np.trace(mats["P"] @ mats["T"]) - ekin) < 1e-9
 
 
-def _run_cli(exe, args, cwd):
-    p = subprocess.run([os.path.join(BIN, exe)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=cwd)
+def _run_cli(exe, args, cwd, env=None):
+    p = subprocess.run([os.path.join(BIN, exe)] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=cwd,
+                       env=dict(os.environ, **env) if env else None)
     return p.returncode, p.stdout.decode(), p.stderr.decode()
 
 
@@ -218,6 +219,29 @@ def test_atomic_restart_from_another_basis(hf, tmp_path):
     assert abs(_etot(out2) - _etot(out3)) < 2e-7 and it2 < it3, (it2, it3, _etot(out2), _etot(out3))
     e1 = float(re.search(r"Total energy is\s+(-[0-9.]+)", out2).group(1))
     assert abs(e1 - _etot(out3)) < 5e-3, (e1, _etot(out3))
+
+
+def test_known_factors_in_the_scf_loop_change_nothing(hf, tmp_path):
+    """inside the SCF loop the exchange fast path takes the occupied orbitals as the factors of P = C_occ C_occ^T
+    (hip/exchange_lr.hip, Lknown); HELFEM_EXL_HINT=0 makes it factorise and verify P as the entry points that only see P do:
+    restricted, unrestricted and range-separated runs give the same energies either way"""
+    runs = [("atomic", ["--Z", "Be", "--nelem", "4", "--nnodes", "10", "--lmax", "0", "--mmax", "0", "--method", "HF"]),
+            ("atomic", ["--Z", "Li", "--nelem", "4", "--nnodes", "10", "--lmax", "1", "--mmax", "1", "--method", "hyb_gga_xc_pbeh",
+                        "--M", "2"]),
+            ("atomic", ["--Z", "He", "--nelem", "4", "--nnodes", "10", "--lmax", "0", "--mmax", "0", "--method", "hyb_lda_xc_cam_lda0"]),
+            ("diatomic", ["--Z1", "H", "--Z2", "H", "--Rbond", "1.4", "--lmax", "4", "--mmax", "0", "--nelem", "2", "--nnodes", "8",
+                          "--method", "HF"])]
+    runs.append(("diatomic", ["--Z1", "N", "--Z2", "N", "--Rbond", "2.068", "--lmax", "4", "--mmax", "2", "--nelem", "2", "--nnodes", "8",
+                              "--method", "gga_x_pbe-gga_c_pbe"]))
+    for exe, args in runs:
+        rc, out1, err = _run_cli(exe, args + ["--save", ""], str(tmp_path))
+        assert rc == 0, out1[-1500:] + err[-1500:]
+        # likewise the DIIS error: from the occupied orbitals (rank nocc products) or, HELFEM_DIIS_LOWRANK=0, from F and P
+        for env in ({"HELFEM_EXL_HINT": "0"}, {"HELFEM_DIIS_LOWRANK": "0"}):
+            rc, out2, err = _run_cli(exe, args + ["--save", ""], str(tmp_path), env=env)
+            assert rc == 0, out2[-1500:] + err[-1500:]
+            assert abs(_etot(out1) - _etot(out2)) < 1e-10 * max(1.0, abs(_etot(out1))), (exe, args, env, _etot(out1), _etot(out2))
+            assert len(re.findall(r"\*\*\*\* Iteration", out1)) == len(re.findall(r"\*\*\*\* Iteration", out2)), (exe, env)
 
 
 def test_functional_parameters_and_forced_occupations_through_the_command_line(hf, tmp_path):
