@@ -55,6 +55,21 @@ __global__ void k_axpby(size_t n, double a, const double *__restrict__ x, double
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += st) y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
 }
+// y = sum_k c[k] x_k, the terms added in the order k = 0, 1, ... exactly as a chain of k_axpby launches adds them
+// (one pass: every x_k is read once and y written once instead of read and written per term)
+struct LinComb {
+  const double *x[16];
+  double c[16];
+  int n;
+};
+__global__ void k_lincomb(size_t n, LinComb lc, double *__restrict__ y) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    double acc = lc.c[0] * lc.x[0][i] + 0.0;
+    for (int k = 1; k < lc.n; k++) acc = lc.c[k] * lc.x[k][i] + 1.0 * acc;
+    y[i] = acc;
+  }
+}
 // E = X - X^T
 __global__ void k_antisym(const double *__restrict__ X, int N, double *__restrict__ E) {
   int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
@@ -113,6 +128,41 @@ __global__ __launch_bounds__(256) void k_dot_partial(size_t n, const double *__r
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// K dot products against the same vector y in one pass: partial[k * gridDim.x + block]; per k the same sums in the same
+// order as k_dot_partial
+struct MultiDot {
+  const double *x[16];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_multidot_partial(size_t n, MultiDot md, const double *__restrict__ y, double *__restrict__ partial) {
+  __shared__ double sh[16][4];
+  double s[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) s[k] = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double yi = y[i];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if (k < md.n) s[k] += md.x[k][i] * yi;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (k >= md.n) break;
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < md.n) partial[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+// out[k] = sum of the nb partials of dot product k, in order (one thread per k)
+__global__ void k_finish_multidot(const double *__restrict__ partial, int nb, int K, double *__restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= K || blockIdx.x) return;
+  double s = 0.0;
+  for (int i = 0; i < nb; i++) s += partial[(size_t)k * nb + i];
+  out[k] = s;
 }
 __global__ __launch_bounds__(256) void k_maxabs_partial(size_t n, const double *__restrict__ x, double *__restrict__ partial) {
   __shared__ double sh[4];
@@ -191,6 +241,16 @@ struct DevSCF {
   void dot(const double *x, const double *y, size_t n, int slot) {
     hipLaunchKernelGGL(k_dot_partial, dim3(RED_BLOCKS), dim3(256), 0, s, n, x, y, partial.p);
     hipLaunchKernelGGL(k_finish_reduce, dim3(1), dim3(64), 0, s, partial.p, RED_BLOCKS, 0, res.p + slot);
+  }
+  // result slots slot0 .. slot0 + K - 1 <- x_k . y   (K <= 16: one pass over y)
+  void multidot(const std::vector<const double *> &xs, const double *y, size_t n, int slot0) {
+    for (size_t k0 = 0; k0 < xs.size(); k0 += 16) {
+      MultiDot md;
+      md.n = (int)std::min<size_t>(16, xs.size() - k0);
+      for (int k = 0; k < md.n; k++) md.x[k] = xs[k0 + k];
+      hipLaunchKernelGGL(k_multidot_partial, dim3(RED_BLOCKS), dim3(256), 0, s, n, md, y, partial.p);
+      hipLaunchKernelGGL(k_finish_multidot, dim3(1), dim3(64), 0, s, partial.p, RED_BLOCKS, md.n, res.p + slot0 + (int)k0);
+    }
   }
   void maxabs(const double *x, size_t n, int slot) {
     hipLaunchKernelGGL(k_maxabs_partial, dim3(RED_BLOCKS), dim3(256), 0, s, n, x, partial.p);
@@ -439,7 +499,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   for (DevBuf<double> *b : {&d.Sinvh, &d.Ca, &d.Pa, &d.P, &d.J, &d.Fa, &d.T1, &d.T2, &d.Err}) b->resize(NN);
   d.Ea.resize(N);
   d.scal.resize(4);
-  d.partial.resize(RED_BLOCKS);
+  d.partial.resize(16 * RED_BLOCKS);
   d.res.resize(8 + 3 * (size_t)std::max(1, opt.diisorder) + 8);
   if (!restr) {
     for (DevBuf<double> *b : {&d.Cb, &d.Pb, &d.Fb}) b->resize(NN);
@@ -763,10 +823,17 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     const size_t elen = blocked_err ? nspin * d.be.etot : nspin * NN;  // the stored part of an error
     d.maxabs(d.histE[slot].p, elen, 5);
     const int nh0 = (int)slots.size();
-    for (int k = 0; k < nh0; k++) {
-      d.dot(d.histE[slot].p, d.histE[slots[k]].p, elen, 8 + k);
-      d.dot(d.histP[slots[k]].p, d.histF[slot].p, nspin * NN, 8 + nh0 + k);      // T(k, n)
-      d.dot(d.histP[slot].p, d.histF[slots[k]].p, nspin * NN, 8 + 2 * nh0 + k);  // T(n, k)
+    {
+      // the new row of B and the new row and column of T: three passes (one per fixed vector) instead of 3 nh0 dot products
+      std::vector<const double *> xe, xp, xf;
+      for (int k = 0; k < nh0; k++) {
+        xe.push_back(d.histE[slots[k]].p);
+        xp.push_back(d.histP[slots[k]].p);
+        xf.push_back(d.histF[slots[k]].p);
+      }
+      d.multidot(xe, d.histE[slot].p, elen, 8);
+      d.multidot(xp, d.histF[slot].p, nspin * NN, 8 + nh0);      // T(k, n) = P_k . F_n
+      d.multidot(xf, d.histP[slot].p, nspin * NN, 8 + 2 * nh0);  // T(n, k) = P_n . F_k
     }
     d.fetch(8 + 3 * nh0);
     if (dft) {
@@ -823,7 +890,16 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
     double *Fds[2] = {d.T1.p, nspin == 2 ? FdB.p : nullptr};
     for (int sp = 0; sp < nspin; sp++) {
       double *Fd = Fds[sp];
-      for (size_t a = 0; a < nh; a++) d.axpby(coef[a], d.histF[slots[a]].p + sp * NN, a ? 1.0 : 0.0, Fd, NN);
+      if (nh >= 1 && nh <= 16) {
+        LinComb lc;
+        lc.n = (int)nh;
+        for (size_t a = 0; a < nh; a++) {
+          lc.x[a] = d.histF[slots[a]].p + sp * NN;
+          lc.c[a] = coef[a];
+        }
+        hipLaunchKernelGGL(k_lincomb, dim3(2048), dim3(256), 0, s, NN, lc, Fd);
+      } else
+        for (size_t a = 0; a < nh; a++) d.axpby(coef[a], d.histF[slots[a]].p + sp * NN, a ? 1.0 : 0.0, Fd, NN);
       const int nocc = sp ? nelb : nela;
       if (damping && nocc > 0 && n > nocc) {
         // F <- S C f C^T S with f = C^T F C, its occupied-virtual blocks scaled (C: the orbitals that built this density)
