@@ -162,20 +162,14 @@ __global__ __launch_bounds__(256) void k_exl_resid(const double *__restrict__ P,
   __syncthreads();
   double res = 0.0, pa = 0.0;
   if (i < N)
-    for (int jb = 0; jb < 32; jb += 8) {
-      // eight columns at a time: their loads of P travel together (one load per column in a rolled loop paid 32 round trips)
-      double pv[8];
+    for (int jj = 0; jj < 32 && j0 + jj < N; jj++) {
+      double pv = P[(size_t)(j0 + jj) * N + i];
+      double acc = pv;
 #pragma unroll
-      for (int u = 0; u < 8; u++) pv[u] = (j0 + jb + u < N) ? P[(size_t)(j0 + jb + u) * N + i] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        double acc = pv[u];
-#pragma unroll
-        for (int k = 0; k < EXL_RMAX; k++)
-          if (k < r) acc -= li[k] * lj[jb + u][k];
-        if (j0 + jb + u < N) res = fmax(res, fabs(acc));
-        pa = fmax(pa, fabs(pv[u]));
-      }
+      for (int k = 0; k < EXL_RMAX; k++)
+        if (k < r) acc -= li[k] * lj[jj][k];
+      res = fmax(res, fabs(acc));
+      pa = fmax(pa, fabs(pv));
     }
   for (int o = 32; o > 0; o >>= 1) {
     res = fmax(res, __shfl_down(res, o, 64));
@@ -276,11 +270,13 @@ __global__ __launch_bounds__(512) void k_exl_alpha(const double *__restrict__ V0
                                                    const double *__restrict__ disj, const int *__restrict__ LM_tab,
                                                    const int *__restrict__ LM_ilm, const double *__restrict__ LM_fac,
                                                    const double *__restrict__ sgn, int Nd, int R, int A, int E, int p, int r,
-                                                   int Ntab, int two, int rank, int nranks, double *__restrict__ aP,
+                                                   int Ntab, int two, int rank, int nranks, const int *__restrict__ ch_perm,
+                                                   const int *__restrict__ sh_perm, double *__restrict__ aP,
                                                    double *__restrict__ aQw) {
   extern __shared__ double xs[];  // this column of V0 (and of V2)
   const int col = blockIdx.x;
   const int c = col / r, o = col % r;
+  const size_t colp = (size_t)(ch_perm ? ch_perm[c] : c) * r + o;  // output column: channels M-major
   const int tab = LM_tab[c];
   const int pp = p * p;
   // multi-GPU: the (L,M) channels of the cross-element part are dealt out over the ranks
@@ -330,7 +326,7 @@ __global__ __launch_bounds__(512) void k_exl_alpha(const double *__restrict__ V0
         sq -= tq2[cc] * y2;
       }
     }
-    const size_t off = (size_t)col * Na + ((size_t)e * A + j) * p + a;  // rows ordered (element, shell, primitive)
+    const size_t off = colp * Na + ((size_t)e * A + (sh_perm ? sh_perm[j] : j)) * p + a;  // rows ordered (element, shell, primitive)
     aP[off] = sp;
     aQw[off] = w * sq;
   }
@@ -826,7 +822,7 @@ __global__ __launch_bounds__(256) void k_exl_reduce(const double *__restrict__ C
 // G holds, for every element pair e > f, the block G_ef[(j,a),(k,b)] (A p x A p, column-major) at ((e (e-1))/2 + f)
 __global__ void k_exl_assemble(const double *__restrict__ Kin, const double *__restrict__ G, int N, int A, int E, int p,
                                const int *__restrict__ pure_shell, const int *__restrict__ pure_n,
-                               double *__restrict__ K, int accumulate) {
+                               const int *__restrict__ sh_perm, double *__restrict__ K, int accumulate) {
   int row = blockIdx.x * 64 + (threadIdx.x & 63);
   int col = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (row >= N || col >= N) return;
@@ -844,7 +840,7 @@ __global__ void k_exl_assemble(const double *__restrict__ Kin, const double *__r
       if (f < 0 || f >= E) continue;
       int b = m - f * pm;
       if (b < 0 || b > pm) continue;
-      size_t ra = (size_t)j * p + a, rb = (size_t)k * p + b;
+      size_t ra = (size_t)(sh_perm ? sh_perm[j] : j) * p + a, rb = (size_t)(sh_perm ? sh_perm[k] : k) * p + b;  // G: shells m-major
       if (e == f) v += Kin[(((size_t)j * A + k) * E + e) * pp + a + p * b];
       else if (e > f) v += G[((size_t)e * (e - 1) / 2 + f) * Ap * Ap + rb * Ap + ra];
       else v += G[((size_t)f * (f - 1) / 2 + e) * Ap * Ap + ra * Ap + rb];
@@ -865,6 +861,14 @@ struct ExLRAux {
   DevBuf<GemmTask> tasks, ctasks;
   std::vector<int> hS_off;
   std::vector<int> h_nch;  // channels per slot
+  // cross-element products by blocks of equal m: in aP / aQw / G the shells are renumbered m-major (sh_perm: the shells
+  // of one m are a run [j0, j0 + nj)) and the channels M-major (ch_perm), chM0[q] .. chM0[q + 1] are the channels of the q-th value of M, and run g
+  // has a non-zero V on the M values act_lo[g] .. act_hi[g] only (a contiguous interval: M = m_j - m_i)
+  bool cross_ok = false;
+  DevBuf<int> ch_perm, sh_perm;  // channel -> M-major position, shell -> m-major position
+  struct MRun { int j0, nj, lo, hi; };
+  std::vector<MRun> runs;
+  std::vector<int> chM0;
   int max_nch = 0;
 };
 static std::map<hfg_dev_tables *, ExLRAux *> g_exlr;
@@ -929,6 +933,58 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
   a->S_off.upload(S_off, s);
   a->S_list.upload(S_list, s);
   a->pos.upload(pos, s);
+  {
+    // channels M-major (stable), runs of shells with equal m, and for every run the interval of M values on which
+    // V^t_j is not identically zero (the same test as for the slots above)
+    std::vector<int> Mv(t->h_LM_M.begin(), t->h_LM_M.begin() + NLM);
+    std::vector<int> Ms = Mv;
+    std::sort(Ms.begin(), Ms.end());
+    Ms.erase(std::unique(Ms.begin(), Ms.end()), Ms.end());
+    std::vector<int> perm(NLM), cnt(Ms.size() + 1, 0);
+    for (int c = 0; c < NLM; c++) cnt[(std::lower_bound(Ms.begin(), Ms.end(), Mv[c]) - Ms.begin()) + 1]++;
+    for (size_t q = 0; q < Ms.size(); q++) cnt[q + 1] += cnt[q];
+    a->chM0 = cnt;
+    {
+      std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+      for (int c = 0; c < NLM; c++) perm[c] = fill[std::lower_bound(Ms.begin(), Ms.end(), Mv[c]) - Ms.begin()]++;
+    }
+    a->ch_perm.upload(perm, s);
+    // shells m-major (stable)
+    std::vector<int> ms(t->h_shell_m.begin(), t->h_shell_m.begin() + A);
+    std::vector<int> mu = ms;
+    std::sort(mu.begin(), mu.end());
+    mu.erase(std::unique(mu.begin(), mu.end()), mu.end());
+    std::vector<int> sperm(A);
+    int posn = 0;
+    for (int mval : mu) {
+      ExLRAux::MRun run{posn, 0, (int)Ms.size(), -1};
+      std::vector<char> act(Ms.size(), 0);
+      for (int jj = 0; jj < A; jj++) {
+        if (ms[jj] != mval) continue;
+        sperm[jj] = posn++;
+        run.nj++;
+        for (int c = 0; c < NLM; c++) {
+          const int q = (int)(std::lower_bound(Ms.begin(), Ms.end(), Mv[c]) - Ms.begin());
+          if (act[q]) continue;
+          const int L = t->h_LM_L[c], need = ms[jj] - Mv[c];
+          for (int i = 0; i < A; i++)
+            if (ms[i] == need && (t->h_c0tab[((size_t)jj * A + i) * Lp1 + L] != 0.0 ||
+                                  t->h_c2tab[((size_t)jj * A + i) * Lp1 + L] != 0.0)) {
+              act[q] = 1;
+              break;
+            }
+        }
+      }
+      for (size_t q = 0; q < Ms.size(); q++)
+        if (act[q]) {
+          run.lo = std::min(run.lo, (int)q);
+          run.hi = std::max(run.hi, (int)q);
+        }
+      a->runs.push_back(run);
+    }
+    a->sh_perm.upload(sperm, s);
+    a->cross_ok = a->runs.size() > 1;
+  }
   std::vector<int> ps, pn;
   for (int x = 0; x < A; x++)
     for (int n = (t->h_shell_skip[x] ? 1 : 0); n < t->R; n++) {
@@ -1052,9 +1108,13 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
                      t->shell_skip.p, a.Ld.p);
   hipLaunchKernelGGL(k_exl_V, dim3(NLM, A), dim3(256), 0, s, a.Ld.p, Nd, R, A, r, a.LM_L.p, a.LM_M.p, t->shell_m.p,
                      a.c0tab.p, a.c2tab.p, t->Lp1, two, a.V0.p, a.V2.p);
-  if (!pair) {
+  // cross products by blocks of equal m (below) need the M-major column order, which only the fast alpha kernel writes
+  static const bool group_off = getenv("HELFEM_EXL_MGROUPS") && atoi(getenv("HELFEM_EXL_MGROUPS")) == 0;
   const size_t alds = (size_t)(two ? 2 : 1) * Nd * sizeof(double);
-  if (p > EXL_AP || E * p > 512 || alds > 150 * 1024)
+  const bool alpha_fast = !(p > EXL_AP || E * p > 512 || alds > 150 * 1024);
+  const bool grouped = !pair && a.cross_ok && alpha_fast && !group_off;
+  if (!pair) {
+  if (!alpha_fast)
     hipLaunchKernelGGL(k_exl_alpha_gen, dim3((unsigned)ncol, A), dim3(128), 0, s, a.V0.p, a.V2.p, t->disj.p, t->LM_tab.p,
                        t->LM_ilm.p, t->LM_fac.p, sgrp, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
                        a.aQw.p);
@@ -1064,38 +1124,63 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     if (alds > 64 * 1024)
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_alpha, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol), dim3(ng * per), alds, s, a.V0.p, two ? a.V2.p : a.V0.p, t->disj.p, t->LM_tab.p,
-                       t->LM_ilm.p, t->LM_fac.p, sgrp, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n, a.aP.p,
-                       a.aQw.p);
+                       t->LM_ilm.p, t->LM_fac.p, sgrp, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n,
+                       grouped ? a.ch_perm.p : nullptr, grouped ? a.sh_perm.p : nullptr, a.aP.p, a.aQw.p);
   }
   }
   // ---- cross-element part: G_ef = aQw_e aP_f^T for e > f (the other half of K is its transpose) ----
   if (!pair) {
     std::vector<GemmTask> ct;
+    int maxMN = 0;
+    long tiles = 0;
     for (int e = 1; e < E; e++)
       for (int f = 0; f < e; f++) {
         GemmTask g;
-        g.A = a.aQw.p + (size_t)e * Ap;
-        g.B = a.aP.p + (size_t)f * Ap;
-        g.C = a.G.p + ((size_t)e * (e - 1) / 2 + f) * Ap * Ap;
-        g.M = g.N = (int)Ap;
-        g.K = (int)ncol;
         g.lda = g.ldb = (int)Na;
         g.ldc = (int)Ap;
         g.tB = 1;
-        ct.push_back(g);
+        double *Gef = a.G.p + ((size_t)e * (e - 1) / 2 + f) * Ap * Ap;
+        if (!grouped) {
+          g.A = a.aQw.p + (size_t)e * Ap;
+          g.B = a.aP.p + (size_t)f * Ap;
+          g.C = Gef;
+          g.M = g.N = (int)Ap;
+          g.K = (int)ncol;
+          ct.push_back(g);
+          maxMN = (int)Ap;
+          tiles += (long)((Ap + 127) / 128) * ((Ap + 127) / 128);
+          continue;
+        }
+        // V^t_j vanishes unless some shell i has m_i = m_j - M: a block (run of m_j, run of m_k) of G only sums over the
+        // channels whose M both runs reach (43 % of the flops of the full products for sigma + pi shells)
+        for (const ExLRAux::MRun &rj : a.runs)
+          for (const ExLRAux::MRun &rk : a.runs) {
+            const int lo = std::max(rj.lo, rk.lo), hi = std::min(rj.hi, rk.hi);
+            if (lo > hi) continue;  // G was zeroed
+            const int k0 = a.chM0[lo], k1 = a.chM0[hi + 1];
+            g.A = a.aQw.p + (size_t)k0 * r * Na + (size_t)e * Ap + (size_t)rj.j0 * p;
+            g.B = a.aP.p + (size_t)k0 * r * Na + (size_t)f * Ap + (size_t)rk.j0 * p;
+            g.C = Gef + (size_t)rk.j0 * p * Ap + (size_t)rj.j0 * p;
+            g.M = rj.nj * p;
+            g.N = rk.nj * p;
+            g.K = (k1 - k0) * r;
+            ct.push_back(g);
+            maxMN = std::max(maxMN, std::max(g.M, g.N));
+            tiles += (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+          }
       }
+    if (grouped) HFG_HIP_CHECK(hipMemsetAsync(a.G.p, 0, sizeof(double) * (size_t)E * (E - 1) / 2 * Ap * Ap, s));
     if (!ct.empty()) {
       a.ctasks.upload(ct, s);
       HFG_HIP_CHECK(hipStreamSynchronize(s));  // ct lives on this stack frame
       // few large tiles (ten products of 8 x 8 tiles at Nbf = 4230: 640 tiles on 512 slots run as two rounds): two
       // half-K workgroups per tile into a zeroed G fill the slots evenly (two addends per element: deterministic)
-      const long tiles = (long)ct.size() * ((Ap + 127) / 128) * ((Ap + 127) / 128);
       static const bool nosplit = getenv("HELFEM_EXL_SPLITK") && atoi(getenv("HELFEM_EXL_SPLITK")) == 0;
       if (!nosplit && tiles < 2048 && ncol >= 512) {
-        HFG_HIP_CHECK(hipMemsetAsync(a.G.p, 0, sizeof(double) * ct.size() * Ap * Ap, s));
-        gemm_tasklist_split2_dev(ctx, a.ctasks.p, (int)ct.size(), (int)Ap, (int)Ap);
+        if (!grouped) HFG_HIP_CHECK(hipMemsetAsync(a.G.p, 0, sizeof(double) * ct.size() * Ap * Ap, s));
+        gemm_tasklist_split2_dev(ctx, a.ctasks.p, (int)ct.size(), maxMN, maxMN);
       } else
-        gemm_tasklist_dev(ctx, a.ctasks.p, (int)ct.size(), (int)Ap, (int)Ap);
+        gemm_tasklist_dev(ctx, a.ctasks.p, (int)ct.size(), maxMN, maxMN);
     }
   }
 
@@ -1234,7 +1319,8 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     hipLaunchKernelGGL(k_exl_reduce, dim3(A * A, E), dim3(256), 0, s, a.C.p, a.c_off.p, a.S_off.p, a.pos.p, A, E, p, Ntab,
                        a.Kin.p);
   dim3 grid((N + 63) / 64, (N + 3) / 4);
-  hipLaunchKernelGGL(k_exl_assemble, grid, dim3(256), 0, s, a.Kin.p, a.G.p, N, A, E, p, a.pure_shell.p, a.pure_n.p, dK, accumulate);
+  hipLaunchKernelGGL(k_exl_assemble, grid, dim3(256), 0, s, a.Kin.p, a.G.p, N, A, E, p, a.pure_shell.p, a.pure_n.p,
+                     grouped ? a.sh_perm.p : nullptr, dK, accumulate);
   HFG_HIP_CHECK(hipGetLastError());
   HFG_HIP_CHECK(hipStreamSynchronize(s));  // host task list and offsets live on this stack frame
   }  // factor groups
