@@ -194,23 +194,56 @@ __global__ void k_exl_expand(const double *__restrict__ L, int N, int Nd, int R,
 }
 
 // V^t[(c,o)][(j,n)] = sum_{i: m_i = m_j - M_c} c_t(j,i,L_c) Ld[(i,n),o]
-__global__ void k_exl_V(const double *__restrict__ Ld, int Nd, int R, int A, int r, const int *__restrict__ LM_L,
+__global__ __launch_bounds__(256) void k_exl_V(const double *__restrict__ Ld, int Nd, int R, int A, int r, const int *__restrict__ LM_L,
                         const int *__restrict__ LM_M, const int *__restrict__ shell_m,
                         const double *__restrict__ c0tab, const double *__restrict__ c2tab, int Lp1, int two,
                         double *__restrict__ V0, double *__restrict__ V2) {
+  // the shells i that couple to (channel c, shell j) and their two coefficients, once per workgroup (every output used to
+  // walk all A shells through three dependent scalar loads each: 12 us per output)
+  __shared__ int si[256];
+  __shared__ double sa0[256], sa2[256];
+  __shared__ int scount;
   const int c = blockIdx.x, j = blockIdx.y;
   const int L = LM_L[c], need = shell_m[j] - LM_M[c];
+  if (threadIdx.x == 0) scount = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < A; i0 += 256) {  // (A <= 256 in one pass; the list keeps the order of i: fixed summation order)
+    const int i = i0 + threadIdx.x;
+    double a0 = 0.0, a2 = 0.0;
+    bool on = false;
+    if (i < A && shell_m[i] == need) {
+      a0 = c0tab[((size_t)j * A + i) * Lp1 + L];
+      a2 = two ? c2tab[((size_t)j * A + i) * Lp1 + L] : 0.0;
+      on = (a0 != 0.0 || a2 != 0.0);
+    }
+    // ordered compaction: position = number of active threads before this one (wave ballots, four waves in order)
+    __shared__ int wcnt[4];
+    const unsigned long long bal = __ballot(on);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = scount;
+    for (int w = 0; w < wave; w++) base += wcnt[w];
+    if (on) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (pos < 256) {
+        si[pos] = i;
+        sa0[pos] = a0;
+        sa2[pos] = a2;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) scount = min(256, scount + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+    __syncthreads();
+  }
+  const int cnt = scount;
   for (int t = threadIdx.x; t < R * r; t += blockDim.x) {
     int n = t % R, o = t / R;
     double u0 = 0.0, u2 = 0.0;
-    for (int i = 0; i < A; i++) {
-      if (shell_m[i] != need) continue;
-      double a0 = c0tab[((size_t)j * A + i) * Lp1 + L];
-      double a2 = two ? c2tab[((size_t)j * A + i) * Lp1 + L] : 0.0;
-      if (a0 == 0.0 && a2 == 0.0) continue;
-      double lv = Ld[(size_t)o * Nd + i * R + n];
-      u0 += a0 * lv;
-      u2 += a2 * lv;
+    for (int q = 0; q < cnt; q++) {
+      const double lv = Ld[(size_t)o * Nd + si[q] * R + n];
+      u0 += sa0[q] * lv;
+      u2 += sa2[q] * lv;
     }
     size_t off = ((size_t)c * r + o) * Nd + (size_t)j * R + n;
     V0[off] = u0;
@@ -271,8 +304,9 @@ __global__ __launch_bounds__(512) void k_exl_alpha(const double *__restrict__ V0
                                                    const int *__restrict__ LM_ilm, const double *__restrict__ LM_fac,
                                                    const double *__restrict__ sgn, int Nd, int R, int A, int E, int p, int r,
                                                    int Ntab, int two, int rank, int nranks, const int *__restrict__ ch_perm,
-                                                   const int *__restrict__ sh_perm, double *__restrict__ aP,
-                                                   double *__restrict__ aQw) {
+                                                   const int *__restrict__ sh_perm, const int *__restrict__ ch_q,
+                                                   const int *__restrict__ sh_lo, const int *__restrict__ sh_hi,
+                                                   double *__restrict__ aP, double *__restrict__ aQw) {
   extern __shared__ double xs[];  // this column of V0 (and of V2)
   const int col = blockIdx.x;
   const int c = col / r, o = col % r;
@@ -294,24 +328,55 @@ __global__ __launch_bounds__(512) void k_exl_alpha(const double *__restrict__ V0
     const double *Q0 = disj + (((size_t)tQ0 * Ntab + tab) * E + ee) * pp;
     const double *P2 = disj + (((size_t)1 * Ntab + tab) * E + ee) * pp;
     const double *Q2 = disj + (((size_t)3 * Ntab + tab) * E + ee) * pp;
+    // unconditional loads with clamped indices, masked afterwards: loads under divergent branches are waited for one
+    // by one (60 round trips per thread: most of this kernel's 0.6 ms)
+    const double *P2c = two ? P2 : P0, *Q2c = two ? Q2 : Q0;
+#pragma unroll
+    for (int cc = 0; cc < EXL_AP; cc++) {
+      const int ix = min(cc, p - 1) * p + a;
+      tp0[cc] = P0[ix];
+      tq0[cc] = Q0[ix];
+      tp2[cc] = P2c[ix];
+      tq2[cc] = Q2c[ix];
+    }
 #pragma unroll
     for (int cc = 0; cc < EXL_AP; cc++) {
       const bool in = act && cc < p && ee * (p - 1) + cc < R;
-      tp0[cc] = in ? P0[cc * p + a] : 0.0;
-      tq0[cc] = in ? Q0[cc * p + a] : 0.0;
-      tp2[cc] = (in && two) ? P2[cc * p + a] : 0.0;
-      tq2[cc] = (in && two) ? Q2[cc * p + a] : 0.0;
+      if (!in) tp0[cc] = tq0[cc] = 0.0;
+      if (!in || !two) tp2[cc] = tq2[cc] = 0.0;
     }
   }
   double *x0s = xs, *x2s = xs + Nd;
-  for (int t = threadIdx.x; t < Nd; t += blockDim.x) {
-    x0s[t] = V0[(size_t)col * Nd + t];
-    if (two) x2s[t] = V2[(size_t)col * Nd + t];
+  {
+    // eight rounds of loads in flight (a rolled "load, store to LDS" loop pays one memory round trip per round, and this
+    // column of V was written a moment ago: it comes from beyond the L2)
+    constexpr int UN = 8;
+    const double *g0 = V0 + (size_t)col * Nd, *g2 = V2 + (size_t)col * Nd;
+    for (int t0 = threadIdx.x; t0 < Nd; t0 += UN * blockDim.x) {
+      double v0[UN], v2[UN];
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const int t = min(t0 + u * (int)blockDim.x, Nd - 1);
+        v0[u] = g0[t];
+        v2[u] = g2[t];  // (V2 = V0 when there is one table type)
+      }
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const int t = t0 + u * (int)blockDim.x;
+        if (t < Nd) {
+          x0s[t] = v0[u];
+          if (two) x2s[t] = v2[u];
+        }
+      }
+    }
   }
   __syncthreads();
   if (!act) return;
   const int n0 = e * (p - 1);
+  const int cq = sh_perm ? ch_q[c] : 0;
   for (int j = g; j < A; j += ng) {
+    // blocks of equal m: the products never read a (shell, channel) whose V vanishes identically
+    if (sh_perm && (cq < sh_lo[j] || cq > sh_hi[j])) continue;
     const double *x0 = x0s + j * R + n0, *x2 = x2s + j * R + n0;
     double sp = 0.0, sq = 0.0;
 #pragma unroll
@@ -866,6 +931,7 @@ struct ExLRAux {
   // has a non-zero V on the M values act_lo[g] .. act_hi[g] only (a contiguous interval: M = m_j - m_i)
   bool cross_ok = false;
   DevBuf<int> ch_perm, sh_perm;  // channel -> M-major position, shell -> m-major position
+  DevBuf<int> ch_q, sh_lo, sh_hi;  // channel -> index of its M; shell -> the interval of M indices its run reaches
   struct MRun { int j0, nj, lo, hi; };
   std::vector<MRun> runs;
   std::vector<int> chM0;
@@ -983,6 +1049,18 @@ static ExLRAux &exlr_for(hfg_ctx *ctx, hfg_dev_tables *t) {
       a->runs.push_back(run);
     }
     a->sh_perm.upload(sperm, s);
+    {
+      std::vector<int> chq(NLM), slo(A), shi(A);
+      for (int c = 0; c < NLM; c++) chq[c] = (int)(std::lower_bound(Ms.begin(), Ms.end(), Mv[c]) - Ms.begin());
+      for (int jj = 0; jj < A; jj++) {
+        const ExLRAux::MRun &run = a->runs[std::lower_bound(mu.begin(), mu.end(), ms[jj]) - mu.begin()];
+        slo[jj] = run.lo;
+        shi[jj] = run.hi;
+      }
+      a->ch_q.upload(chq, s);
+      a->sh_lo.upload(slo, s);
+      a->sh_hi.upload(shi, s);
+    }
     a->cross_ok = a->runs.size() > 1;
   }
   std::vector<int> ps, pn;
@@ -1024,6 +1102,8 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
   static const bool pair_off = getenv("HELFEM_EXL_PAIR") && atoi(getenv("HELFEM_EXL_PAIR")) == 0;
   if (t->pair_tei && pair_off) return false;
   ExLRAux &a = exlr_for(ctx, t);
+  for (const ExLRAux::MRun &run : a.runs)
+    if (run.nj > 256) return false;  // k_exl_V lists at most 256 coupled shells
   hipStream_t s = ctx->stream;
   const int two = (ntt == 4) ? 1 : 0;
   const int pp = p * p;
@@ -1125,7 +1205,8 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_exl_alpha, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     hipLaunchKernelGGL(k_exl_alpha, dim3((unsigned)ncol), dim3(ng * per), alds, s, a.V0.p, two ? a.V2.p : a.V0.p, t->disj.p, t->LM_tab.p,
                        t->LM_ilm.p, t->LM_fac.p, sgrp, Nd, R, A, E, p, r, Ntab, two, ctx->shard_rank, ctx->shard_n,
-                       grouped ? a.ch_perm.p : nullptr, grouped ? a.sh_perm.p : nullptr, a.aP.p, a.aQw.p);
+                       grouped ? a.ch_perm.p : nullptr, grouped ? a.sh_perm.p : nullptr, a.ch_q.p, a.sh_lo.p, a.sh_hi.p, a.aP.p,
+                       a.aQw.p);
   }
   }
   // ---- cross-element part: G_ef = aQw_e aP_f^T for e > f (the other half of K is its transpose) ----
