@@ -144,7 +144,7 @@ def test_xc_kernels_with_chunked_angular_tables(hf):
     assert "worst relative deviation" in p.stdout.decode()
 
 
-@pytest.mark.parametrize("rb", ["", "1", "4"])
+@pytest.mark.parametrize("rb", ["", "1", "4", "mgroups0"])
 def test_exchange_rb_kernels_at_large_element_order(hf, rb):
     """exact exchange against the oracle at 15, 16 and 17 nodes per element (tests/exl_worker.py, one child process per
     setting because HELFEM_EXL_RB is read once): the matrix-core RB kernel with and without a padding row in its 16 x 16
@@ -155,7 +155,10 @@ def test_exchange_rb_kernels_at_large_element_order(hf, rb):
     import sys
     env = dict(os.environ)
     env.pop("HELFEM_EXL_RB", None)
-    if rb:
+    env.pop("HELFEM_EXL_MGROUPS", None)
+    if rb == "mgroups0":
+        env["HELFEM_EXL_MGROUPS"] = "0"  # the cross-element products as ten full ones instead of blocks of equal m
+    elif rb:
         env["HELFEM_EXL_RB"] = rb
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "exl_worker.py")], env=env, stdout=subprocess.PIPE,
