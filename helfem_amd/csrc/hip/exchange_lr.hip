@@ -28,6 +28,7 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
               const double *B, int ldb, double beta, double *C, int ldc);
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 
 constexpr int EXL_RMAX = 64;
 constexpr int EXL_GMAX = 16;  // factor groups (residual factorisations) at most
@@ -1391,7 +1392,17 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
         }
       }
     }
-    gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
+    // 128 x 64 tiles: the pair counts of the tasks are padded to 64 instead of 128 columns (3.5 % instead of 7 % of idle
+    // columns) and twice as many workgroups share the slots -- 6.6 -> 6.2 ms at Nbf = 4230 (HELFEM_EXL_RECT=0: 128 x 128)
+    // ... for the shorter pair lists; with the longer lists of larger angular bases the padding is small either way and
+    // the square tiles' lower LDS traffic per flop wins (measured: Nbf = 4230, 1000 pairs per task on average, 11.6 against
+    // 12.0 ms per build; Nbf = 6102, 28.6 against 29.4 the other way round)
+    static const int rect_env = getenv("HELFEM_EXL_RECT") ? atoi(getenv("HELFEM_EXL_RECT")) : -1;
+    double ncols_tot = 0.0;
+    for (const GemmTask &q : tasks) ncols_tot += (double)q.N;
+    const bool rect_tiles = rect_env >= 0 ? rect_env != 0 : (ncols_tot < 1500.0 * (double)tasks.size());
+    if (rect_tiles) gemm_tasklist_rect_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
+    else gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
   }
   if (pair)
     hipLaunchKernelGGL(k_exl_reduce_pair, dim3(A * A, E * (E + 1) / 2), dim3(256), 0, s, a.C.p, a.c_off.p, a.S_off.p, a.pos.p,
