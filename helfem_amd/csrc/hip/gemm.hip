@@ -464,6 +464,15 @@ void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, 
   HFG_HIP_CHECK(hipGetLastError());
 }
 
+/// the same with 128 x 64 tiles
+void gemm_tasklist_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
+  if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  const int tiles = ((maxM + 127) / 128) * ((maxN + 63) / 64);
+  hipLaunchKernelGGL((k_dgemm_tasklist_split2<128, 64>), dim3(2 * tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
   if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
   ProfScope ps(ctx, "gemm");
