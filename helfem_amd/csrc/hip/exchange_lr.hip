@@ -117,7 +117,16 @@ __global__ __launch_bounds__(1024) void k_exl_factor(const double *__restrict__ 
       int i = tid + 1024 * q;
       if (i < N) {
         double v = P[(size_t)p * N + i];
-        for (int j = 0; j < k; j++) v -= ssgn[j] * L[(size_t)j * N + i] * lrow[j];
+        // eight loads of earlier columns in flight, subtracted in the same order as one by one
+        int j = 0;
+        for (; j + 8 <= k; j += 8) {
+          double lv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) lv[u] = L[(size_t)(j + u) * N + i];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v -= ssgn[j + u] * lv[u] * lrow[j + u];
+        }
+        for (; j < k; j++) v -= ssgn[j] * L[(size_t)j * N + i] * lrow[j];
         v *= inv;
         L[(size_t)k * N + i] = v;
         d[q] -= sk * v * v;

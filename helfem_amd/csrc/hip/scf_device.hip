@@ -148,8 +148,7 @@ __global__ __launch_bounds__(256) void k_multidot_partial(size_t n, MultiDot md,
   }
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    if (k >= md.n) break;
-    double v = s[k];
+    double v = s[k];  // (all 16: a loop with an exit is not unrolled and s[] would live in scratch memory)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
   }
