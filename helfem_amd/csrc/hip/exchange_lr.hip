@@ -96,15 +96,16 @@ __global__ __launch_bounds__(1024) void k_exl_factor(const double *__restrict__ 
     }
     __syncthreads();
     const int p = piv_i;
-    // the owner of row p publishes d_p and the row of L built so far (its own earlier stores)
+    // the owner of row p publishes d_p; the row of L built so far (stores of earlier steps, each followed by a workgroup
+    // barrier) is fetched by k threads at once instead of one thread's k loads in a row
     if (tid == (p & 1023)) {
       double dv = 0.0;
 #pragma unroll
       for (int q = 0; q < EXL_QMAX; q++)
         if (q == (p >> 10)) dv = d[q];
       piv_d = dv;
-      for (int j = 0; j < k; j++) lrow[j] = L[(size_t)j * N + p];
     }
+    if (tid < k) lrow[tid] = L[(size_t)tid * N + p];
     __syncthreads();
     const double dp = piv_d;
     if (k == 0) dmax0 = first ? fabs(dp) : dscale[0];
