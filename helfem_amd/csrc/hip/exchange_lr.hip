@@ -29,6 +29,7 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg, bool rect);
 void gemm_tasklist_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 
 constexpr int EXL_RMAX = 64;
@@ -932,6 +933,8 @@ struct ExLRAux {
   int kM = 0, kK = 0;  // rows and columns of one exchange-ordered element table (padded, see exlr_for)
   DevBuf<int4> rbm_list;  // workgroups of k_exl_RBm: (slot, element, block pair)
   DevBuf<double> ones;     // EXL_RMAX ones: the signs of factors handed in by the caller
+  DevBuf<int2> gwl;        // workgroups (task, tile) of the element GEMM, XCD-contiguous
+  std::vector<int2> h_gwl;
   int rbm_n = 0, rbm_shard = -1;
   DevBuf<int> info, LM_L, LM_M, tab_ch_off, tab_ch, S_off, S_list, pos, pure_shell, pure_n;
   DevBuf<long long> rb_off, c_off;
@@ -1415,7 +1418,19 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     double ncols_tot = 0.0;
     for (const GemmTask &q : tasks) ncols_tot += (double)q.N;
     const bool rect_tiles = rect_env >= 0 ? rect_env != 0 : (ncols_tot < 1500.0 * (double)tasks.size());
-    if (rect_tiles) gemm_tasklist_rect_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
+    static const bool wl_off = getenv("HELFEM_EXL_WL") && atoi(getenv("HELFEM_EXL_WL")) == 0;  // checker: plain task-list grid
+    if (!wl_off) {
+      // all tiles of a task on one XCD (its element table is then fetched from HBM once, not by all eight L2s)
+      const int BNt = rect_tiles ? 64 : 128;
+      std::vector<int2> &wl = a.h_gwl;
+      wl.clear();
+      for (size_t k = 0; k < tasks.size(); k++) {
+        const int nt = ((tasks[k].M + 127) / 128) * ((tasks[k].N + BNt - 1) / BNt);
+        for (int q = 0; q < nt; q++) wl.push_back(make_int2((int)k, q));
+      }
+      a.gwl.upload(wl, s);  // (h_gwl lives in the aux until the synchronisation at the end of the build)
+      gemm_tasklist_wl_dev(ctx, a.tasks.p, a.gwl.p, (int)wl.size(), rect_tiles);
+    } else if (rect_tiles) gemm_tasklist_rect_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
     else gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
   }
   if (pair)

@@ -62,7 +62,7 @@ __device__ __forceinline__ void dgemm_tile(int id, int transA, int transB, int M
   int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
   const bool lower = !ACC && sym == 1;  // enumerate the lower tiles only
   int nwg = lower ? nbm * (nbm + 1) / 2 : nbm * nbn;
-  {
+  if (!(over & 4)) {  // (over & 4: the caller has placed the tile itself, k_dgemm_tasklist_wl)
     int q = nwg / 8, r = nwg % 8, xcd = id % 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
   }
@@ -357,6 +357,22 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__res
                               As, Bs, sym, 0, -1, t.over);
 }
 
+// Task lists with an explicit workgroup list (task, tile), dealt out so that each XCD takes ONE contiguous eighth of the
+// list: all tiles of a task then run on the same XCD and its A operand is fetched from HBM once instead of by all eight
+// L2s (exchange_lr.hip: the 1.9 MB element table of a task was read 8 times -- 9 of the 15 GB the product fetched).
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void k_dgemm_tasklist_wl(const GemmTask *__restrict__ tasks, const int2 *__restrict__ wl, int nwg) {
+  __shared__ __attribute__((aligned(16))) double As[2][16][BM + 16];
+  __shared__ __attribute__((aligned(16))) double Bs[2][16][BN + 16];
+  const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const int q8 = nwg / 8, r8 = nwg % 8;
+  if (slot >= q8 + (xcd < r8 ? 1 : 0)) return;
+  const int2 w = wl[(xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot];
+  const GemmTask t = tasks[w.x];
+  dgemm_tile<BM, BN, false, 1>(w.y, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As, Bs, 0, 0, -1,
+                               t.over | 4);
+}
+
 // Two workgroups per tile, each half of K (rounded to the k step): for batches whose tiles do not fill the chip evenly --
 // 386 tiles of the eigensolve's products on 512 workgroup slots last two tile-times for 1.5 tile-times of average work,
 // 772 half tiles fill them with three each; the 210 lower tiles of the symmetric product become 420 units that all
@@ -461,6 +477,16 @@ void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, 
   ProfScope ps(ctx, "gemm");
   const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
   hipLaunchKernelGGL((k_dgemm_tasklist_split2<128, 128>), dim3(2 * tiles, ntasks), dim3(256), 0, ctx->stream, dtasks);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+/// task list with a workgroup list (task, tile) in XCD order; rect: 128 x 64 tiles, else 128 x 128 (beta == 0 tasks, no sym)
+void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg, bool rect) {
+  if (nwg <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  const unsigned grid = 8u * (unsigned)((nwg + 7) / 8);
+  if (rect) hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 64>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
+  else hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 128>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
   HFG_HIP_CHECK(hipGetLastError());
 }
 
