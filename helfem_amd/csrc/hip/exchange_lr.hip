@@ -30,6 +30,7 @@ void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int max
 void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg, bool rect);
+void gemm_tasklist_wl_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg);
 void gemm_tasklist_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 
 constexpr int EXL_RMAX = 64;
@@ -935,6 +936,8 @@ struct ExLRAux {
   DevBuf<double> ones;     // EXL_RMAX ones: the signs of factors handed in by the caller
   DevBuf<int2> gwl;        // workgroups (task, tile) of the element GEMM, XCD-contiguous
   std::vector<int2> h_gwl;
+  DevBuf<int2> cwl;        // the same for the cross-element products (two entries per tile: split K)
+  std::vector<int2> h_cwl;
   int rbm_n = 0, rbm_shard = -1;
   DevBuf<int> info, LM_L, LM_M, tab_ch_off, tab_ch, S_off, S_list, pos, pure_shell, pure_n;
   DevBuf<long long> rb_off, c_off;
@@ -1276,7 +1279,18 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
         if (!grouped) HFG_HIP_CHECK(hipMemsetAsync(a.G.p, 0, sizeof(double) * ct.size() * Ap * Ap, s));
         // 128 x 64 tiles: the blocks of ~300 columns pad to 320 instead of 384 (11.6 -> 11.5 ms per build; HELFEM_EXL_CRECT=0: square)
         static const bool crect = !(getenv("HELFEM_EXL_CRECT") && atoi(getenv("HELFEM_EXL_CRECT")) == 0);
-        if (crect && grouped) gemm_tasklist_split2_rect_dev(ctx, a.ctasks.p, (int)ct.size(), maxMN, maxMN);
+        static const bool cwl_off = getenv("HELFEM_EXL_WL") && atoi(getenv("HELFEM_EXL_WL")) == 0;
+        if (crect && grouped && !cwl_off) {
+          // all tiles of a product on one XCD: its operand blocks are fetched once (2.4 GB were fetched for 0.3 GB of aP, aQw)
+          std::vector<int2> &wl = a.h_cwl;
+          wl.clear();
+          for (size_t k = 0; k < ct.size(); k++) {
+            const int nt = ((ct[k].M + 127) / 128) * ((ct[k].N + 63) / 64);
+            for (int q = 0; q < 2 * nt; q++) wl.push_back(make_int2((int)k, q));
+          }
+          a.cwl.upload(wl, s);
+          gemm_tasklist_wl_split2_rect_dev(ctx, a.ctasks.p, a.cwl.p, (int)wl.size());
+        } else if (crect && grouped) gemm_tasklist_split2_rect_dev(ctx, a.ctasks.p, (int)ct.size(), maxMN, maxMN);
         else gemm_tasklist_split2_dev(ctx, a.ctasks.p, (int)ct.size(), maxMN, maxMN);
       } else
         gemm_tasklist_dev(ctx, a.ctasks.p, (int)ct.size(), maxMN, maxMN);

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist(const GemmTask *__res
 // Task lists with an explicit workgroup list (task, tile), dealt out so that each XCD takes ONE contiguous eighth of the
 // list: all tiles of a task then run on the same XCD and its A operand is fetched from HBM once instead of by all eight
 // L2s (exchange_lr.hip: the 1.9 MB element table of a task was read 8 times -- 9 of the 15 GB the product fetched).
-template <int BM, int BN>
+// SPLIT: the list holds two entries per tile, (task, 2 tile + half): each forms half of K and adds it to a zeroed C
+// (k_dgemm_tasklist_split2's scheme).
+template <int BM, int BN, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist_wl(const GemmTask *__restrict__ tasks, const int2 *__restrict__ wl, int nwg) {
   __shared__ __attribute__((aligned(16))) double As[2][16][BM + 16];
   __shared__ __attribute__((aligned(16))) double Bs[2][16][BN + 16];
@@ -369,8 +371,17 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_tasklist_wl(const GemmTask *__
   if (slot >= q8 + (xcd < r8 ? 1 : 0)) return;
   const int2 w = wl[(xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot];
   const GemmTask t = tasks[w.x];
-  dgemm_tile<BM, BN, false, 1>(w.y, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As, Bs, 0, 0, -1,
-                               t.over | 4);
+  if constexpr (SPLIT) {
+    const int half = w.y & 1;
+    const int Kh = ((t.K / 2 + 15) / 16) * 16;
+    const int kbeg = half ? Kh : 0, kend = half ? t.K : Kh;
+    if (kbeg >= kend) return;
+    dgemm_tile<BM, BN, false, 1>(w.y >> 1, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, 0.0, t.C, t.ldc, As, Bs, 0, kbeg,
+                                 kend, t.over | 4);
+  } else {
+    dgemm_tile<BM, BN, false, 1>(w.y, t.tA, t.tB, t.M, t.N, t.K, t.alpha, t.A, t.lda, t.B, t.ldb, t.beta, t.C, t.ldc, As, Bs, 0, 0, -1,
+                                 t.over | 4);
+  }
 }
 
 // Two workgroups per tile, each half of K (rounded to the k step): for batches whose tiles do not fill the chip evenly --
@@ -487,6 +498,14 @@ void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl,
   const unsigned grid = 8u * (unsigned)((nwg + 7) / 8);
   if (rect) hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 64>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
   else hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 128>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
+  HFG_HIP_CHECK(hipGetLastError());
+}
+
+/// split-K form of the above with 128 x 64 tiles: two list entries per tile, C zeroed by the caller
+void gemm_tasklist_wl_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg) {
+  if (nwg <= 0) return;
+  ProfScope ps(ctx, "gemm");
+  hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 64, true>), dim3(8u * (unsigned)((nwg + 7) / 8)), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
   HFG_HIP_CHECK(hipGetLastError());
 }
 
