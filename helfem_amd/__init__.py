@@ -432,6 +432,49 @@ class DFTGrid(object):
         return Ha, Hb, exc.value, nel.value, ekin.value
 
 
+    def eval_Fxc_dev(self, x_func, c_func, P, Pb=None, thr=1e-12):
+        """the device-buffer entry points hfg_xc_fock_dev / hfg_xc_fock_pol_dev, which honour the context's shard
+        (Context.set_shard: only the radial points Q % n == rank contribute, dftgrid.cpp:779): the partial matrices
+        and sums one rank of a multi-GPU run produces.  torch tensors serve as the HBM buffers.
+        Returns (H, Exc, Nel, Ekin) or, with Pb, (Ha, Hb, Exc, Nel, Ekin)."""
+        import torch
+        b = self.basis
+        if b._uploaded != (self.ldft, self.mdft):
+            b.upload(self.ldft, self.mdft)
+        dev = torch.device("cuda", b.ctx.device)
+        N = b.Nbf()
+
+        def up(M):
+            return torch.from_numpy(np.asfortranarray(M, dtype=np.float64).ravel(order="F").copy()).to(dev)
+
+        def ptr(t):
+            return ctypes.c_void_p(t.data_ptr())
+        scal = torch.zeros(3, dtype=torch.float64, device=dev)
+        dP = up(P)
+        dH = torch.zeros(N * N, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        L = lib()
+        if Pb is None:
+            L.hfg_xc_fock_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+            _check(L.hfg_xc_fock_dev(b.ctx.h, b.h, int(x_func), int(c_func), ptr(dP), ptr(dH), ptr(scal), float(thr)))
+            b.ctx.synchronize()
+            sc = scal.cpu().numpy()
+            return dH.cpu().numpy().reshape((N, N), order="F"), sc[0], sc[1], sc[2]
+        dPb = up(Pb)
+        dHb = torch.zeros(N * N, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        L.hfg_xc_fock_pol_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_double]
+        _check(L.hfg_xc_fock_pol_dev(b.ctx.h, b.h, int(x_func), int(c_func), ptr(dP), ptr(dPb), ptr(dH), ptr(dHb), ptr(scal),
+                                     float(thr)))
+        b.ctx.synchronize()
+        sc = scal.cpu().numpy()
+        return (dH.cpu().numpy().reshape((N, N), order="F"), dHb.cpu().numpy().reshape((N, N), order="F"), sc[0], sc[1],
+                sc[2])
+
+
 class scf(object):
     """namespace helfem::scf (src/general/scf_helpers.h)."""
 

@@ -42,7 +42,9 @@ Mat enforce_fock_symmetry(const Mat &F, const std::vector<std::vector<size_t> > 
 /// shard_n > 1: only the (L,|M|) channels with ilm % shard_n == shard_rank contribute (the multi-GPU shard of J)
 Mat coulomb(const helfem::diatomic::TwoDBasis &b, const Mat &P0, int shard_rank = 0, int shard_n = 1);
 /// TwoDBasis::exchange      src/diatomic/basis.cpp:1532-1733
-Mat exchange(const helfem::diatomic::TwoDBasis &b, const Mat &P0);
+/// only != nullptr: just the listed output blocks (jang, kang) are built (the reference's loop is per output block,
+/// basis.cpp:1575-1579), every other block of the result stays zero -- what the full-size parity tests can afford
+Mat exchange(const helfem::diatomic::TwoDBasis &b, const Mat &P0, const std::vector<std::pair<int, int> > *only = nullptr);
 /// DFTGrid::eval_Fxc (restricted)  src/diatomic/dftgrid.cpp:769-810; radial points
 /// [q_begin,q_end) of the E*nq list only (q_end<0: all) so that the bench can time a bounded sample; shard_n > 1:
 /// only the radial points with q % shard_n == shard_rank (the multi-GPU shard of the XC quadrature)
@@ -51,7 +53,8 @@ void eval_Fxc(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_fu
               int shard_rank = 0, int shard_n = 1);
 /// DFTGrid::eval_Fxc (unrestricted)  src/diatomic/dftgrid.cpp:812-856
 void eval_Fxc_pol(const helfem::diatomic::TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa,
-                  const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin, double thr);
+                  const Mat &Pb, Mat &Ha, Mat &Hb, double &Exc, double &Nel, double &Ekin, double thr, long q_begin = 0,
+                  long q_end = -1, int shard_rank = 0, int shard_n = 1);
 /// TwoDGrid::model_potential  src/diatomic/twodquadrature.cpp:213-232, 351-375 (initial-guess potential of two
 /// screened nuclei by quadrature on the (mu, nu, phi) product grid)
 Mat model_potential(const helfem::diatomic::TwoDBasis &b, int lang, int mang, const helfem::ModelPotential &p1,

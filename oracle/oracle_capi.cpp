@@ -83,6 +83,16 @@ int orc_exchange(void *h, const double *P, double *K) {
   memcpy(K, Km.memptr(), sizeof(double) * N * N);
   ORC_CATCH
 }
+int orc_exchange_blocks(void *h, const double *P, double *K, int nsel, const int *jsel, const int *ksel) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  std::vector<std::pair<int, int> > only;
+  for (int i = 0; i < nsel; i++) only.push_back(std::make_pair(jsel[i], ksel[i]));
+  Mat Km = exchange(*b, to_mat(P, N, N), &only);
+  memcpy(K, Km.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
 int orc_coulomb_shard(void *h, const double *P, double *J, int shard_rank, int shard_n) {
   ORC_TRY
   TwoDBasis *b = (TwoDBasis *)h;
@@ -109,6 +119,18 @@ int orc_eval_fxc(void *h, int lang, int mang, int x_func, int c_func, const doub
   Mat Hm;
   eval_Fxc(*b, lang, mang, x_func, c_func, to_mat(P, N, N), Hm, *Exc, *Nel, *Ekin, thr, q_begin, q_end);
   memcpy(H, Hm.memptr(), sizeof(double) * N * N);
+  ORC_CATCH
+}
+int orc_eval_fxc_pol_range(void *h, int lang, int mang, int x_func, int c_func, const double *Pa, const double *Pb, double *Ha,
+                           double *Hb, double *Exc, double *Nel, double *Ekin, double thr, long q_begin, long q_end) {
+  ORC_TRY
+  TwoDBasis *b = (TwoDBasis *)h;
+  size_t N = b->Nbf();
+  Mat Ham, Hbm;
+  eval_Fxc_pol(*b, lang, mang, x_func, c_func, to_mat(Pa, N, N), to_mat(Pb, N, N), Ham, Hbm, *Exc, *Nel, *Ekin, thr, q_begin,
+               q_end);
+  memcpy(Ha, Ham.memptr(), sizeof(double) * N * N);
+  memcpy(Hb, Hbm.memptr(), sizeof(double) * N * N);
   ORC_CATCH
 }
 int orc_grid_overlap(void *h, int lang, int mang, double *S) {

@@ -125,7 +125,7 @@ Mat coulomb(const TwoDBasis &b, const Mat &P0, int shard_rank, int shard_n) {
   return b.remove_boundaries(J);
 }
 
-Mat exchange(const TwoDBasis &b, const Mat &P0) {
+Mat exchange(const TwoDBasis &b, const Mat &P0, const std::vector<std::pair<int, int> > *only) {
   if (!b.have_ktei) throw std::logic_error("Primitive teis have not been computed!\n");
   Mat P(b.expand_boundaries(P0));
   const size_t Nel = b.Nel(), Nrad = b.Nrad(), Nlm = b.lm_map.size();
@@ -134,6 +134,13 @@ Mat exchange(const TwoDBasis &b, const Mat &P0) {
 
   for (size_t jang = 0; jang < lval.size(); jang++)
     for (size_t kang = 0; kang < lval.size(); kang++) {
+      // output-block filter of the full-size parity tests: the reference's loop is per (jang, kang) (basis.cpp:1575-1579),
+      // each block's arithmetic is independent of the others, so a subset of blocks is still the reference algorithm
+      if (only) {
+        bool sel = false;
+        for (const auto &jk : *only) sel = sel || ((size_t)jk.first == jang && (size_t)jk.second == kang);
+        if (!sel) continue;
+      }
       int lj = lval[jang], mj = mval[jang], lk = lval[kang], mk = mval[kang];
       std::vector<Mat> R00(Nlm, Mat(Nrad, Nrad)), R02(Nlm, Mat(Nrad, Nrad)), R20(Nlm, Mat(Nrad, Nrad)),
           R22(Nlm, Mat(Nrad, Nrad));
@@ -315,15 +322,19 @@ void eval_Fxc(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, co
 }
 
 void eval_Fxc_pol(const TwoDBasis &b, int lang, int mang, int x_func, int c_func, const Mat &Pa0, const Mat &Pb0, Mat &Haout,
-                  Mat &Hbout, double &Exc, double &Nel, double &Ekin, double thr) {
+                  Mat &Hbout, double &Exc, double &Nel, double &Ekin, double thr, long q_begin, long q_end, int shard_rank,
+                  int shard_n) {
   Mat Ha(b.Ndummy(), b.Ndummy()), Hb(b.Ndummy(), b.Ndummy());
   Mat Pa(b.expand_boundaries(Pa0)), Pb(b.expand_boundaries(Pb0));
   double exc = 0.0, nel = 0.0, ekin = 0.0;
   GridWorker grid(b, lang, mang);
   grid.do_grad = (x_func > 0 && xc_is_gga(x_func)) || (c_func > 0 && xc_is_gga(c_func));
   grid.do_tau = (x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func));
+  long q = 0;
   for (size_t iel = 0; iel < b.Nel(); iel++)
-    for (size_t irad = 0; irad < (size_t)b.nquad(); irad++) {
+    for (size_t irad = 0; irad < (size_t)b.nquad(); irad++, q++) {
+      if (q < q_begin || (q_end >= 0 && q >= q_end)) continue;
+      if ((int)(q % shard_n) != shard_rank) continue;
       grid.compute_bf(iel, irad);
       grid.update_density(Pa, Pb);
       nel += grid.compute_Nel();

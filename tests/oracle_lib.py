@@ -29,6 +29,11 @@ def lib():
         L.orc_eval_fxc_shard.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double,
                                          ctypes.c_int, ctypes.c_int]
+        L.orc_eval_fxc_pol_range.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                             c_double_p, ctypes.c_double, ctypes.c_long, ctypes.c_long]
+        L.orc_exchange_blocks.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.orc_xc_polarized.argtypes = [ctypes.c_int, ctypes.c_int64, c_double_p, c_double_p, c_double_p, c_double_p,
                                        c_double_p, ctypes.c_double]
         for nm in ("orc_eval_fxc_pol", "orc_atomic_eval_fxc_pol"):
@@ -145,6 +150,48 @@ class OracleBasis(object):
         _check(lib().orc_exchange(self.h, _p(P), _p(K)))
         return K
 
+    def exchange_blocks(self, P, pairs):
+        """only the output blocks (jang, kang) of `pairs` (the reference loops over them one by one, basis.cpp:1575-1579);
+        the rest of the returned matrix is zero"""
+        P = _f(P)
+        K = np.zeros_like(P, order="F")
+        js = (ctypes.c_int * len(pairs))(*[int(p[0]) for p in pairs])
+        ks = (ctypes.c_int * len(pairs))(*[int(p[1]) for p in pairs])
+        _check(lib().orc_exchange_blocks(self.h, _p(P), _p(K), len(pairs), js, ks))
+        return K
+
+    def eval_Fxc_points(self, lang, mang, x_func, c_func, P, points, thr=1e-12, Pb=None, threads=8):
+        """the contributions of the listed radial points (indices into the E * nq list of dftgrid.cpp:779-801) summed;
+        one point per call on `threads` host threads (ctypes releases the GIL).  Pb given: the unrestricted driver,
+        returns (Ha, Hb, Exc, Nel, Ekin), else (H, Exc, Nel, Ekin)."""
+        import threading
+        work = list(points)
+        lock = threading.Lock()
+        res = []
+
+        def run():
+            while True:
+                with lock:
+                    if not work:
+                        return
+                    q = work.pop()
+                if Pb is None:
+                    r = self.eval_Fxc(lang, mang, x_func, c_func, P, thr, q_begin=q, q_end=q + 1)
+                else:
+                    r = self.eval_Fxc_pol(lang, mang, x_func, c_func, P, Pb, thr, q_begin=q, q_end=q + 1)
+                with lock:
+                    res.append((q, r))
+
+        ths = [threading.Thread(target=run) for _ in range(max(1, min(threads, len(work))))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        res.sort(key=lambda x: x[0])  # fixed summation order
+        nmat = 1 if Pb is None else 2
+        out = [sum(r[1][k] for r in res) for k in range(nmat + 3)]
+        return tuple(out)
+
     def eval_Fxc(self, lang, mang, x_func, c_func, P, thr=1e-12, q_begin=0, q_end=-1):
         P = _f(P)
         H = np.zeros_like(P, order="F")
@@ -153,12 +200,12 @@ class OracleBasis(object):
                                   ctypes.byref(nel), ctypes.byref(ekin), thr, q_begin, q_end))
         return H, exc.value, nel.value, ekin.value
 
-    def eval_Fxc_pol(self, lang, mang, x_func, c_func, Pa, Pb, thr=1e-12):
+    def eval_Fxc_pol(self, lang, mang, x_func, c_func, Pa, Pb, thr=1e-12, q_begin=0, q_end=-1):
         Pa, Pb = _f(Pa), _f(Pb)
         Ha, Hb = np.zeros_like(Pa, order="F"), np.zeros_like(Pb, order="F")
         exc, nel, ekin = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        _check(getattr(lib(), self._fxc_pol)(self.h, lang, mang, x_func, c_func, _p(Pa), _p(Pb), _p(Ha), _p(Hb),
-                                             ctypes.byref(exc), ctypes.byref(nel), ctypes.byref(ekin), thr))
+        _check(lib().orc_eval_fxc_pol_range(self.h, lang, mang, x_func, c_func, _p(Pa), _p(Pb), _p(Ha), _p(Hb),
+                                            ctypes.byref(exc), ctypes.byref(nel), ctypes.byref(ekin), thr, q_begin, q_end))
         return Ha, Hb, exc.value, nel.value, ekin.value
 
     def grid_overlap(self, lang, mang):

@@ -1,9 +1,15 @@
 """The hot path at BASELINE.json's full size (configs[3] sizing of bench.py: N2, PBE, 5 elements x 15 nodes,
-lmmax = [20,20] -> Nbf = 4230, symmetry blocks 1380/1470/1380, XC grid 92 x 13).  The oracle cannot run at this size in
-seconds (its XC build alone extrapolates to a quarter of an hour), so parity is checked through size-independent
-properties of each stage: orthonormality and residuals of the eigensolve, Tr PS, linearity and symmetry of J and K, the
-sign of the exchange energy, the electron count of the XC quadrature and the consistency of the XC matrix with the
-derivative of the XC energy."""
+lmmax = [20,20] -> Nbf = 4230, symmetry blocks 1380/1470/1380, XC grid 92 x 13; configs[4] sizing: LiF, Nbf = 6102).
+
+Two kinds of checks:
+  * DIRECT comparison with the oracle / LAPACK wherever that costs seconds (the `*_against_the_oracle` tests below):
+    the whole Coulomb matrix, the eigenvalues of the Fock matrix of one SCF step against LAPACK per symmetry block, the XC
+    matrix and sums of a radial shard (Context.set_shard(r, 25): 15 of the 375 radial points -- the oracle's dense
+    algorithm needs 2.4 s per point), restricted and spin-polarised, and a sample of output blocks of the exchange
+    matrix (the reference builds K block by block, basis.cpp:1575-1579; the oracle takes a block list);
+  * size-independent properties of each stage for what the oracle cannot reach in seconds: orthonormality and
+    residuals of the eigensolve, Tr PS, linearity and symmetry of J and K, the sign of the exchange energy, the electron
+    count of the XC quadrature and the consistency of the XC matrix with the derivative of the XC energy."""
 import os
 import sys
 
@@ -33,7 +39,129 @@ def full(native_libs):
     X = hf.scf.form_Sinvh(S, False, blocks)
     H0 = np.asfortranarray(T + V)
     E, C = hf.scf.eig_gsym_sub(H0, X, blocks)
-    return dict(hf=hf, basis=basis, ldft=ldft, mdft=mdft, N=N, S=S, H0=H0, X=X, blocks=blocks, E=E, C=C, w=w)
+    return dict(hf=hf, basis=basis, ldft=ldft, mdft=mdft, N=N, S=S, H0=H0, X=X, blocks=blocks, E=E, C=C, w=w, bval=bval, lval=lval,
+                mval=mval)
+
+
+def _oracle_basis(fx, exchange):
+    """the CPU checker's basis of a bench workload (tests/oracle_lib.py; tables on all host threads)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import oracle_lib as orc
+    os.environ.setdefault("HELFEM_NUM_THREADS", str(bench.usable_cores()))
+    w = fx["w"]
+    ob = orc.OracleBasis(w["Z1"], w["Z2"], 0.5 * w["Rbond"], w["nnodes"], 5 * w["nnodes"], fx["bval"], fx["lval"], fx["mval"], 10)
+    ob.compute_tei(exchange)
+    return ob
+
+
+def _sample_pairs(basis):
+    """output blocks (jang, kang) of K covering sigma-sigma, sigma-pi, pi-pi', pi-pi with equal m, low and high l"""
+    l, m = basis.lval, basis.mval
+    def first(ll, mm):
+        return next(i for i in range(len(l)) if l[i] == ll and m[i] == mm)
+    lmax_s = max(l[i] for i in range(len(l)) if m[i] == 0)
+    lmax_p = max(l[i] for i in range(len(l)) if m[i] == 1)
+    s0, s1, sh = first(0, 0), first(1, 0), first(lmax_s, 0)
+    p1, pm1, ph = first(1, 1), first(1, -1), first(lmax_p, 1)
+    return [(s0, s0), (s0, s1), (s1, sh), (s0, p1), (p1, s1), (p1, pm1), (p1, p1), (pm1, ph), (sh, ph)]
+
+
+def _block_of(basis, jang):
+    """pure (boundary-cleaned) indices of angular shell jang (basis.cpp:482: m != 0 shells drop their first radial function)"""
+    Nrad = basis.Nrad()
+    off = 0
+    for a in range(jang):
+        off += Nrad - (1 if basis.mval[a] != 0 else 0)
+    return np.arange(off, off + Nrad - (1 if basis.mval[jang] != 0 else 0))
+
+
+def _step_fock(ctx_fixture):
+    """the Fock matrix of one bench step from the core-Hamiltonian density: F = H0 + J + XC (PBE), block-masked"""
+    hf, basis, C, N = ctx_fixture["hf"], ctx_fixture["basis"], ctx_fixture["C"], ctx_fixture["N"]
+    nocc = ctx_fixture["w"]["nocc"]
+    P = np.asfortranarray(2.0 * hf.scf.form_density(C, nocc))
+    J = basis.coulomb(P)
+    H = hf.DFTGrid(basis, ctx_fixture["ldft"], ctx_fixture["mdft"]).eval_Fxc(101, 130, P)[0]
+    F = np.zeros((N, N), order="F")
+    Fd = ctx_fixture["H0"] + J + H
+    for b in ctx_fixture["blocks"]:
+        F[np.ix_(b, b)] = Fd[np.ix_(b, b)]
+    return P, J, F
+
+
+def _check_coulomb_eig_xc_k(fx, shard_rank):
+    """the four direct comparisons at one full-size workload"""
+    hf, basis, N, blocks, X = fx["hf"], fx["basis"], fx["N"], fx["blocks"], fx["X"]
+    w = fx["w"]
+    ob = _oracle_basis(fx, True)
+    assert ob.Nbf == N
+    P, J, F = _step_fock(fx)
+    # (i) Coulomb: the whole matrix (TwoDBasis::coulomb, basis.cpp:1359)
+    Jo = ob.coulomb(P)
+    assert np.max(np.abs(J - Jo)) < 1e-12 * np.max(np.abs(Jo))
+    # (ii) eigenvalues of the step's Fock matrix per symmetry block against LAPACK (scf::eig_gsym_sub, scf_helpers.cpp:142)
+    E, C = hf.scf.eig_gsym_sub(F, X, blocks)
+    try:
+        import torch
+        eigh = lambda A: torch.linalg.eigvalsh(torch.from_numpy(np.ascontiguousarray(A))).numpy()
+    except ImportError:
+        eigh = np.linalg.eigvalsh
+    Eref = []
+    for b in blocks:
+        cols = np.where(np.max(np.abs(X[b, :]), axis=0) > 0)[0]
+        Xb = X[np.ix_(b, cols)]
+        Eref.append(eigh(Xb.T @ F[np.ix_(b, b)] @ Xb))
+    Eref = np.sort(np.concatenate(Eref))
+    assert np.max(np.abs(E - Eref)) < 1e-10 * np.max(np.abs(Eref))
+    # (iii) XC on a radial shard: 15 of the 375 points (Q % 25 == r), restricted and spin-polarised
+    # (DFTGrid::eval_Fxc, dftgrid.cpp:769 / :812)
+    NQ = w["nelem"] * 5 * w["nnodes"]
+    pts = [q for q in range(NQ) if q % 25 == shard_rank]
+    grid = hf.DFTGrid(basis, fx["ldft"], fx["mdft"])
+    basis.ctx.set_shard(shard_rank, 25)
+    try:
+        H, Exc, Nel, _ = grid.eval_Fxc_dev(101, 130, P)
+        Pa = np.asfortranarray(hf.scf.form_density(fx["C"], w["nocc"]))
+        Pb = np.asfortranarray(hf.scf.form_density(fx["C"], w["nocc"] - 1))  # a doublet-like spin density
+        Ha, Hb, Excp, Nelp, _ = grid.eval_Fxc_dev(101, 130, Pa, Pb)
+    finally:
+        basis.ctx.set_shard(0, 1)
+    import bench
+    nth = bench.usable_cores()
+    Ho, Exco, Nelo, _ = ob.eval_Fxc_points(fx["ldft"], fx["mdft"], 101, 130, P, pts, threads=nth)
+    sc = np.max(np.abs(Ho))
+    assert sc > 1e-3  # the shard really carries part of the matrix
+    assert np.max(np.abs(H - Ho)) < 1e-10 * sc, np.max(np.abs(H - Ho)) / sc
+    assert abs(Exc - Exco) < 1e-11 * abs(Exco) and abs(Nel - Nelo) < 1e-11 * abs(Nelo)
+    Hao, Hbo, Excpo, Nelpo, _ = ob.eval_Fxc_points(fx["ldft"], fx["mdft"], 101, 130, Pa, pts, Pb=Pb, threads=nth)
+    sc = max(np.max(np.abs(Hao)), np.max(np.abs(Hbo)))
+    assert np.max(np.abs(Ha - Hao)) < 1e-10 * sc and np.max(np.abs(Hb - Hbo)) < 1e-10 * sc
+    assert np.max(np.abs(Hao - Hbo)) > 1e-6 * sc  # the two spins really differ
+    assert abs(Excp - Excpo) < 1e-11 * abs(Excpo) and abs(Nelp - Nelpo) < 1e-11 * abs(Nelpo)
+    # (iv) exchange: a sample of output blocks (TwoDBasis::exchange, basis.cpp:1532; the reference loops over (jang, kang))
+    # density: the closed shell plus one orbital that mixes the three m blocks, so that the sigma-pi and pi-pi' blocks of K
+    # do not vanish by symmetry (K_jk needs m_j - m_i = m_k - m_l with P_il != 0)
+    u = np.zeros(N)
+    for b in blocks:
+        cols = np.where(np.max(np.abs(fx["C"][b, :]), axis=0) > 1e-8)[0]
+        u += fx["C"][:, cols[0]]
+    Ph = np.asfortranarray(0.5 * P + 0.3 * np.outer(u, u))
+    K = basis.exchange(Ph)
+    pairs = _sample_pairs(basis)
+    Ko = ob.exchange_blocks(Ph, pairs)
+    sk = np.max(np.abs(K))
+    for (j, k) in pairs:
+        rj, rk = _block_of(basis, j), _block_of(basis, k)
+        blk, blko = K[np.ix_(rj, rk)], Ko[np.ix_(rj, rk)]
+        assert np.max(np.abs(blko)) > 1e-8 * sk
+        assert np.max(np.abs(blk - blko)) < 1e-11 * sk, ((j, k), np.max(np.abs(blk - blko)) / sk)
+
+
+def test_fullsize_stages_against_the_oracle(full):
+    """Nbf = 4230 (BASELINE configs[3]): J, eigenvalues, an XC radial shard (restricted + polarised) and nine blocks of K
+    compared directly with the CPU checker / LAPACK"""
+    _check_coulomb_eig_xc_k(full, shard_rank=3)
 
 
 def test_fullsize_half_inverse_and_eigensolve(full):
@@ -161,7 +289,8 @@ def lif(native_libs):
     assert sorted(len(b) for b in blocks) == [2001, 2001, 2100]
     X = hf.scf.form_Sinvh(S, False, blocks)
     E, C = hf.scf.eig_gsym_sub(H0, X, blocks)
-    return dict(hf=hf, basis=basis, ldft=ldft, mdft=mdft, N=N, S=S, H0=H0, X=X, blocks=blocks, E=E, C=C, w=w)
+    return dict(hf=hf, basis=basis, ldft=ldft, mdft=mdft, N=N, S=S, H0=H0, X=X, blocks=blocks, E=E, C=C, w=w, bval=bval, lval=lval,
+                mval=mval)
 
 
 def test_lif_nbf6102_eigensolve(lif):
@@ -181,6 +310,11 @@ def test_lif_nbf6102_eigensolve(lif):
     R = lif["w"]["Rbond"]
     assert abs(E[0] - (-40.5 - 3.0 / R)) < 0.1 and abs(E[1] - (-81.0 / 8.0 - 3.0 / R)) < 0.3
     assert np.min(np.abs(E[:8] - (-4.5 - 9.0 / R))) < 0.1
+
+
+def test_lif_nbf6102_stages_against_the_oracle(lif):
+    """Nbf = 6102 (BASELINE configs[4] sizing): the same direct comparisons"""
+    _check_coulomb_eig_xc_k(lif, shard_rank=11)
 
 
 def test_lif_nbf6102_coulomb_exchange_xc(lif):
