@@ -17,7 +17,7 @@ LIBDIR = os.path.join(ROOT, "helfem_amd", "lib")
 OBJDIR = os.path.join(ROOT, "helfem_amd", "build")
 
 HOST_SRCS = ["host/fem.cpp", "host/special.cpp", "host/atomic_basis.cpp", "host/diatomic_basis.cpp", "host/scf.cpp", "host/diis.cpp", "host/checkpoint.cpp", "host/dftfuncs.cpp"]
-HIP_SRCS = ["hip/tables.cpp", "hip/capi.cpp", "hip/fock.hip", "hip/exchange.hip", "hip/exchange_lr.hip", "hip/gemm.hip", "hip/eig.hip", "hip/dc.hip", "hip/trd.hip",
+HIP_SRCS = ["hip/tables.cpp", "hip/capi.cpp", "hip/fock.hip", "hip/exchange.hip", "hip/exchange_lr.hip", "hip/gemm.hip", "hip/eig.hip", "hip/dc.hip", "hip/trd.hip", "hip/trdp.hip",
             "hip/misc.hip", "hip/scf_gpu.cpp", "hip/scf_device.hip", "hip/tei_dev.hip", "hip/sb.hip"]
 
 

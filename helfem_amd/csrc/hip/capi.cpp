@@ -42,6 +42,8 @@ void compute_tei_dev(hfg_ctx *ctx, hfg_basis *basis);
 void eig_release(hfg_ctx *ctx);
 void dc_release(hfg_ctx *ctx);
 void trd_release(hfg_ctx *ctx);
+void trdp_release(hfg_ctx *ctx);
+void trdp_check_status(hfg_ctx *ctx);
 void trd_measure_gemv(hfg_ctx *ctx, double *ms, int64_t *launches);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc);
@@ -208,6 +210,7 @@ int hfg_ctx_destroy(hfg_ctx *c) {
   eig_release(c);
   dc_release(c);
   trd_release(c);
+  trdp_release(c);
   for (auto &kv : c->prof)
     for (auto &ev : kv.second.pending) {
       (void)hipEventDestroy(ev.first);
@@ -229,6 +232,7 @@ int hfg_ctx_destroy(hfg_ctx *c) {
 int hfg_ctx_synchronize(hfg_ctx *c) {
   HFG_TRY
   HFG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  trdp_check_status(c);  // a persistent tridiagonalisation that ran into a spin limit fails here, loudly
   HFG_CATCH
 }
 

@@ -931,9 +931,11 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
   HFG_HIP_CHECK(hipGetLastError());
 }
 
+void trdp_check_status(hfg_ctx *ctx);  // trdp.hip
 static void check_status(hfg_ctx *ctx, EigWork &w, int nblk) {
   if (w.used_dc) {
     if (dc_status(ctx) != 0) throw std::logic_error("Eigendecomposition failed!\n");
+    trdp_check_status(ctx);  // the stream has just been synchronised: the status word of a persistent launch is home
     return;
   }
   for (int i = 0; i < nblk; i++) {

@@ -29,6 +29,8 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
+bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
+                               double *const *tau);  // trdp.hip
 
 constexpr int TB_MAXB = 8;
 constexpr int TB_NB = 16;   // panel width (measured: 16 beats 8 and 32 at n ~ 1400 x 3 blocks; 32 again after the DPP work: 11.7 vs 7.6 us per column)
@@ -1186,6 +1188,13 @@ void trd_release(hfg_ctx *ctx) {
 void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
                           double *const *tau) {
   if (nblk > TB_MAXB) throw std::logic_error("tridiagonalize_batch: too many blocks");
+  // one cooperative launch with the matrices resident in the register file when the batch fits the chip (trdp.hip);
+  // the chain of launches below otherwise
+  if (tridiagonalize_persistent(ctx, nblk, ns, A, d, e, tau)) {
+    auto itp = g_trd.find(ctx);
+    if (itp != g_trd.end()) itp->second->last_ns.clear();
+    return;
+  }
   TrdWork *wp;
   auto it = g_trd.find(ctx);
   if (it == g_trd.end()) {

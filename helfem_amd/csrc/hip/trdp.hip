@@ -1,0 +1,574 @@
+// Persistent, register-resident Householder tridiagonalisation of symmetric matrices on gfx950 (LAPACK dsytd2 algebra,
+// lower variant; the reduction stage of the dsyevd the reference reaches through arma::eig_sym,
+// src/general/scf_helpers.cpp:135), batched over the symmetry blocks of scf::eig_gsym_sub (scf_helpers.cpp:142-186).
+//
+// ONE cooperative launch per batch.  The rows of every matrix are dealt out to workgroups (TP_NRG * R consecutive rows
+// each, full symmetric storage) and stay in the REGISTER FILE of that workgroup's CU for the whole factorisation: the
+// three trailing matrices of the bench workload (48 MB) fit the 128 MB of vector registers of the chip.  Per Householder
+// column the workgroups of a matrix exchange one message through device memory (readable model and check of the algebra:
+// tools/trdp_model.py):
+//
+//   every workgroup k   y[R_k]  = A^(j-1)[R_k, j+1:] x_j        its rows of the product with the UNNORMALISED column x_j,
+//                                                               formed before the rank-2 update of column j-1 reaches
+//                                                               its registers (that update runs while the data travel)
+//                       dot_k   = sum_{r in R_k} x_j[r] y[r]
+//   owner of row j+1    z       = A^(j)[j+1, j+1:]              that row fully updated
+//
+// From (y, z, dots) and x_j, v_{j-1}, w_{j-1} every workgroup derives beta, tau, v_j, w_j, d[j+1] and x_{j+1}
+// redundantly, with identical arithmetic and summation orders (bitwise the same everywhere, reproducible run to run):
+//   q = y - v_{j-1} c1 - w_{j-1} c2 (c1 = w_{j-1}.x_j, c2 = v_{j-1}.x_j),  x.q = sum dots - 2 c1 c2,
+//   v = s (x - beta e1),  p = tau s (q - beta z),  v.p = tau s^2 (x.q - 2 beta q_0 + beta^2 z_0),
+//   w = p - (tau/2)(v.p) v,  x_{j+1} = (z - w_0 v - w)[1:],  d[j+1] = z_0 - 2 w_0.
+// No norm barrier, no second exchange, no atomics.
+//
+// Exchange words are 8-byte doubles stored write-through (sc1) and polled with sc1 loads; the data are their own flag: a
+// ring of four slots per matrix is filled with a sentinel (all bits set, a NaN no arithmetic here produces) by one
+// hipMemsetAsync before the launch, and every workgroup re-poisons the words IT will write two exchanges later (each
+// word has one writer, which is also its poisoner: no write-after-read hazard between workgroups).  Every spin is
+// bounded by a wall-clock limit; a workgroup that runs into it sets the status word and the launch drains.
+// Co-residency of the grid is checked by hipLaunchCooperativeKernel; when it refuses, or the matrices do not fit the
+// register file, tridiagonalize_batch (trd.hip) runs its chain of launches instead.
+#include "common.h"
+#include "wave.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace hfg {
+
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+constexpr int TP_MAXB = 8;
+constexpr int TP_NT = 512;               // threads per workgroup: one workgroup per CU, two waves per SIMD, up to 256 VGPRs
+                                         // (with 1024 threads and 128 VGPRs the 3 x 12 register tile spilled 96 of them)
+constexpr int TP_NCG = 128;              // column groups: thread (rg, cg) holds columns cg, cg + 128, ...
+constexpr int TP_NRG = TP_NT / TP_NCG;   // row groups
+constexpr int TP_NW = TP_NT / 64;
+constexpr int TP_SLOTS = 4;
+constexpr int TP_MAXG = 256;             // workgroups per matrix (landing area of the dot words)
+constexpr unsigned long long TP_SENT = ~0ull;
+
+struct TrdpDesc {
+  int nblk;
+  int wg0[TP_MAXB + 1];  // first workgroup of every matrix
+  int n[TP_MAXB], G[TP_MAXB];
+  double *A[TP_MAXB], *d[TP_MAXB], *e[TP_MAXB], *tau[TP_MAXB];
+  unsigned long long *xb[TP_MAXB];  // exchange ring: TP_SLOTS x (G x SEG + NP) words
+  int *status;                      // 1: a spin ran into its limit (poisoned to -1 before the launch)
+  unsigned long long *stamps;       // measurement only (nullptr in the product path): 4 wall-clock stamps per column
+  long long spin_limit;             // wall-clock ticks (100 MHz)
+};
+
+__device__ __forceinline__ unsigned long long tp_load(const gu64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tp_store(gu64 *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long tp_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ double tp_dbl(unsigned long long b) { return __longlong_as_double((long long)b); }
+/// sum of the TP_NW wave partials held by lanes (lane % TP_NW), in every lane, same order everywhere
+__device__ __forceinline__ double tp_wsum(double v) {
+  if constexpr (TP_NW == 8) return oct_sum(v);
+  else return row16_sum(v);
+}
+
+template <int R, int U, bool STAMPS>
+__global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp) {
+  constexpr int M = TP_NRG * R;   // rows per workgroup
+  constexpr int NP = TP_NCG * U;  // padded order
+  constexpr int SEG = ((M + 1 + 15) / 16) * 16;  // words of a workgroup's exchange segment: its rows of y, then dot
+  constexpr int EPT = (NP + TP_NT - 1) / TP_NT;  // vector elements per thread in the element-wise phase
+  constexpr int NL = NP + 64;                    // LDS vectors: rows of the last workgroup may lie beyond NP
+  static_assert(M <= 63, "the rows of a workgroup and its dot word are published by one wave");
+  // Register budget: the tile takes 2 R U of the 256 VGPRs a thread of a 512-thread workgroup can have, and everything
+  // else in the loop has to fit beside it.  What was measured while shaping this kernel (hipcc 7.2, -Rpass-analysis):
+  // every conditional block inside the loop costs registers (four optional stamp stores: 45 spilled registers more on
+  // the 6 x 12 tile), so the loop body below avoids predicates: clamped indices instead of bounds tests, whole rows
+  // published including dead columns, dead rows updated with stale vectors (never read again).
+  __shared__ double X[NL], VP[NL], WP[NL];
+  __shared__ double YL[NL], ZL[NL];  // landing area of an exchange (each thread re-reads only what it stored itself)
+  __shared__ double part[M][2];
+  __shared__ double red[3][TP_NW];
+  __shared__ double dots[TP_MAXG];
+  __shared__ double zq0[2];
+  __shared__ int abort_flag;
+  const TrdpDesc &D = *dp;
+  int blk = 0;
+  while (blk + 1 < D.nblk && (int)blockIdx.x >= D.wg0[blk + 1]) blk++;
+  const int k = (int)blockIdx.x - D.wg0[blk];
+  const int n = D.n[blk], G = D.G[blk];
+  gdouble *A = (gdouble *)D.A[blk];
+  gdouble *dw = (gdouble *)D.d[blk], *ew = (gdouble *)D.e[blk], *tauw = (gdouble *)D.tau[blk];
+  gu64 *xb = (gu64 *)D.xb[blk];
+  const int slotw = G * SEG + NP;
+  const long long spin_limit = D.spin_limit;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = tid & (TP_NCG - 1), rg = tid >> 7;
+  const int row0 = k * M + rg * R;  // first row of this thread
+  if (k * M >= n) return;
+
+  // ---- registers: a[i][u] = A(row0 + i, cg + 128 u); the lower triangle is the input (LAPACK uplo = 'L') ----
+  double a[R][U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int c = cg + TP_NCG * u;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const int r = row0 + i;
+      double v = 0.0;
+      if (r < n && c < n) v = (r >= c) ? A[(size_t)c * n + r] : A[(size_t)r * n + c];
+      a[i][u] = v;
+    }
+    // a few column chunks at a time: with every load of the tile in flight their 64-bit addresses alone cost 2 R U registers
+    if ((u & 3) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  for (int r = tid; r < NL; r += TP_NT) {
+    X[r] = 0.0;
+    VP[r] = 0.0;
+    WP[r] = 0.0;
+    YL[r] = 0.0;
+    ZL[r] = 0.0;
+  }
+  if (tid == 0) abort_flag = 0;
+  for (int r = tid; r < TP_MAXG; r += TP_NT) dots[r] = 0.0;
+  __syncthreads();
+  // ---- prologue: column 0 is the first x, nothing to correct ----
+  {
+    double ps = 0.0;
+    for (int r = 1 + tid; r < n; r += TP_NT) {
+      const double xv = A[r];
+      X[r] = xv;
+      if (r > 1) ps += xv * xv;
+    }
+    ps = wave_sum(ps);
+    if (lane == 0) {
+      red[0][wave] = 0.0;
+      red[1][wave] = 0.0;
+      red[2][wave] = ps;
+    }
+    if (k == 0 && tid == 0) dw[0] = A[0];
+  }
+
+  // scalars of the column being reduced, carried from the end of one pass to the exchange of the next
+  double c1 = 0.0, c2 = 0.0, beta = 0.0, tau = 0.0, scl = 0.0;
+
+  // pass j: (j >= 0) consume exchange j -> v_j, w_j, x_{j+1};  then publish exchange j+1.  Pass -1 only publishes.
+  int j = -1;
+  for (;; j++) {
+    const int j1 = j + 1;
+    if ((k + 1) * M - 1 < j1) return;  // no row of the trailing matrix left here
+    // =============== rank-2 update of column j-1 on the registers ===============
+    // (runs while the exchange of column j is in flight: the workgroup published its part just before.  At the top of
+    // the loop body, in front of every use of the tile in this pass, so that the tile is updated in place -- with the
+    // update behind its uses the compiler kept two copies of the tile.  VP = WP = 0 in the first two passes; rows and
+    // columns already reduced are updated with stale values and never read again.)
+    {
+      double vr[R], wr[R];
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        vr[i] = VP[row0 + i];
+        wr[i] = WP[row0 + i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const double vc = VP[cg + TP_NCG * u], wc = WP[cg + TP_NCG * u];
+#pragma unroll
+        for (int i = 0; i < R; i++) a[i][u] -= vr[i] * wc + wr[i] * vc;
+      }
+    }
+    if (j >= 0) {
+      // =============== exchange j: wait for y (rows >= j+1), z (columns >= j+1), dots ===============
+      gu64 *sb = xb + (size_t)(j & (TP_SLOTS - 1)) * slotw;
+      const int kf = j1 / M;  // first workgroup that still owns rows
+      unsigned long long yb[EPT], zb[EPT], dd = TP_SENT;
+#pragma unroll
+      for (int h = 0; h < EPT; h++) yb[h] = zb[h] = TP_SENT;
+      const int kd = min(kf + tid, G - 1);  // clamped: surplus threads poll the last word again
+      {
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int h = 0; h < EPT; h++) {
+            const int r = min(j1 + tid + TP_NT * h, n - 1);
+            if (yb[h] == TP_SENT) yb[h] = tp_load(sb + (size_t)(r / M) * SEG + (r % M));
+            if (zb[h] == TP_SENT) zb[h] = tp_load(sb + (size_t)G * SEG + r);
+          }
+          if (dd == TP_SENT) dd = tp_load(sb + (size_t)kd * SEG + M);
+#pragma unroll
+          for (int h = 0; h < EPT; h++) ok = ok && yb[h] != TP_SENT && zb[h] != TP_SENT;
+          ok = ok && dd != TP_SENT;
+          if (ok) break;
+          if (((++spins) & 15u) == 0u && (long long)(wall_clock64() - t0) > spin_limit) {
+            abort_flag = 1;
+            __hip_atomic_store((__attribute__((address_space(1))) int *)D.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < EPT; h++) {
+        const int r = min(j1 + tid + TP_NT * h, n - 1);
+        YL[r] = tp_dbl(yb[h]);
+        ZL[r] = tp_dbl(zb[h]);
+      }
+      if (tid == 0) {
+        // element r = j+1: z_0 and q_0 = y_0 - v_{j-1}[j+1] c1 - w_{j-1}[j+1] c2 for everybody
+        zq0[0] = tp_dbl(zb[0]);
+        zq0[1] = tp_dbl(yb[0]) - VP[j1] * c1 - WP[j1] * c2;
+      }
+      if (tid < TP_MAXG) dots[tid] = (kf + tid < G) ? tp_dbl(dd) : 0.0;
+      __syncthreads();  // (1)
+      if (abort_flag) return;
+      if constexpr (STAMPS) {
+        if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 0] = wall_clock64();
+      }
+      // ---- scalars, redundantly in every wave (fixed orders: bitwise the same in every workgroup) ----
+      double dsum = (dots[lane] + dots[lane + 64]) + (dots[lane + 128] + dots[lane + 192]);
+      dsum = wave_sum(dsum);
+      const double zz0 = zq0[0], q0 = zq0[1];
+      const double xtq = dsum - 2.0 * c1 * c2;
+      const double vtp = tau * scl * scl * (xtq - 2.0 * beta * q0 + beta * beta * zz0);
+      const double aa = -0.5 * tau * vtp;
+      const double ts = tau * scl;
+      const double w0 = ts * (q0 - beta * zz0) + aa;
+      // ---- element-wise: v_j, w_j, x_{j+1}; partial sums for the next column (rolled: the register tile needs the room) ----
+      double pc1 = 0.0, pc2 = 0.0, ps = 0.0;
+#pragma unroll 1
+      for (int r = j1 + tid; r < n; r += TP_NT) {
+        const double y = YL[r], z = ZL[r];
+        const double xo = X[r];
+        const double q = y - VP[r] * c1 - WP[r] * c2;
+        const double vn = (r == j1) ? 1.0 : scl * xo;
+        const double wn = ts * (q - beta * z) + aa * vn;
+        double xn = 0.0;
+        if (r > j1) {
+          xn = z - vn * w0 - wn;
+          pc1 += wn * xn;
+          pc2 += vn * xn;
+          if (r > j1 + 1) ps += xn * xn;
+          if (r / M == k) A[(size_t)j * n + r] = vn;  // reflector for the back-transformation (LAPACK layout)
+        }
+        X[r] = xn;
+        VP[r] = vn;
+        WP[r] = wn;
+      }
+      pc1 = wave_sum(pc1);
+      pc2 = wave_sum(pc2);
+      ps = wave_sum(ps);
+      if (lane == 0) {
+        red[0][wave] = pc1;
+        red[1][wave] = pc2;
+        red[2][wave] = ps;
+      }
+      if (k == kf && tid == 0) {
+        dw[j1] = zz0 - 2.0 * w0;
+        ew[j] = beta;
+        tauw[j] = tau;
+      }
+    }
+    __syncthreads();  // (2): X = x_{j+1}, VP = v_j, WP = w_j
+    if constexpr (STAMPS) {
+      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 1] = wall_clock64();
+    }
+    if (j == n - 3) break;  // the last column has no successor to prepare
+
+    // =============== publish exchange j+1 ===============
+    gu64 *sb1 = xb + (size_t)((j + 1) & (TP_SLOTS - 1)) * slotw;
+    const int j2 = j + 2;
+    // the owner of row j+2 publishes it with the update of column j applied on the fly (all of the row's columns: the
+    // reduced ones are not read by anybody)
+    if (k == j2 / M && rg == (j2 % M) / R) {
+      const int iz = (j2 % M) % R;
+      const double vz = VP[j2], wz = WP[j2];
+      // staged through LDS (every thread re-reads only its own words) so that the stores can be a ROLLED loop: unrolled,
+      // their twelve 64-bit addresses were hoisted out of the column loop and cost 24 registers for its whole duration
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int c = cg + TP_NCG * u;
+        double av = a[0][u];
+#pragma unroll
+        for (int i = 1; i < R; i++)
+          if (i == iz) av = a[i][u];
+        ZL[c] = av - vz * WP[c] - wz * VP[c];
+      }
+      gu64 *zrow = sb1 + (size_t)G * SEG;
+#pragma unroll 1
+      for (int c = cg; c < NP; c += TP_NCG) tp_store(zrow + c, tp_bits(ZL[c]));
+    }
+    // rows of the product with x_{j+1} (registers still lack the update of column j; X is zero on reduced columns)
+    {
+      double acc[R];
+#pragma unroll
+      for (int i = 0; i < R; i++) acc[i] = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const double xc = X[cg + TP_NCG * u];
+#pragma unroll
+        for (int i = 0; i < R; i++) acc[i] += a[i][u] * xc;
+      }
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const double t = wave_sum(acc[i]);
+        if (lane == 0) part[rg * R + i][wave & 1] = t;
+      }
+    }
+    __syncthreads();  // (3)
+    if (wave == 0) {
+      const int r = k * M + lane;
+      const bool live = lane < M && r >= j2 && r < n;
+      double yv = 0.0, dc = 0.0;
+      if (lane < M) yv = part[lane][0] + part[lane][1];
+      if (live) {
+        tp_store(sb1 + (size_t)k * SEG + lane, tp_bits(yv));
+        dc = X[r] * yv;
+      }
+      dc = wave_sum(dc);
+      if (lane == 0) tp_store(sb1 + (size_t)k * SEG + M, tp_bits(dc));
+      // poison what this workgroup writes for exchange j+3 (its slot held exchange j-1, which everybody has consumed:
+      // exchange j could only complete after every workgroup had published it, i.e. after it had read exchange j-1)
+      gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
+      if (lane <= M) tp_store(sb3 + (size_t)k * SEG + lane, TP_SENT);
+    }
+    if (j + 4 < n && (j + 4) / M == k) {
+      gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
+      for (int c = tid; c < NP; c += TP_NT) tp_store(sb3 + (size_t)G * SEG + c, TP_SENT);
+    }
+    if constexpr (STAMPS) {
+      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 2] = wall_clock64();
+    }
+    // scalars of column j+1: c1, c2, |x[1:]|^2 from the wave partials (same order in every wave and workgroup)
+    {
+      c1 = tp_wsum(red[0][lane & (TP_NW - 1)]);
+      c2 = tp_wsum(red[1][lane & (TP_NW - 1)]);
+      const double xn2 = tp_wsum(red[2][lane & (TP_NW - 1)]);
+      const double alpha = X[j2];
+      if (xn2 == 0.0) {
+        tau = 0.0;
+        beta = alpha;
+        scl = 0.0;
+      } else {
+        const double nrm = sqrt(alpha * alpha + xn2);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scl = 1.0 / (alpha - beta);
+      }
+    }
+  }
+  // ---- last column done: e[n-2] is the one element of x_{n-2}; d[n-1] from the registers of the last row, which lack the
+  // update of column n-3 ----
+  const int rl = n - 1;
+  if (k == rl / M) {
+    const int rgl = (rl % M) / R, il = (rl % M) % R, cgl = rl % TP_NCG, ul = rl / TP_NCG;
+    if (rg == rgl && cg == cgl) {
+      double av = 0.0;
+#pragma unroll
+      for (int i = 0; i < R; i++)
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (i == il && u == ul) av = a[i][u];
+      dw[n - 1] = av - 2.0 * VP[rl] * WP[rl];
+      ew[n - 2] = X[rl];
+      ew[n - 1] = 0.0;
+      tauw[n - 2] = 0.0;
+      tauw[n - 1] = 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct TrdpWork {
+  DevBuf<unsigned long long> ring;  // status block (16 words) + the exchange rings of all matrices
+  DevBuf<unsigned long long> stamps;
+  DevBuf<TrdpDesc> desc;
+  std::vector<TrdpDesc> h_desc;
+  int *h_status = nullptr;  // pinned: the status word of the last launch, copied back asynchronously
+  bool pending = false;
+  int ncu = 0;
+  std::vector<int> last_ns;
+  int last_R = 0, last_U = 0, last_grid = 0;
+};
+static std::map<hfg_ctx *, TrdpWork *> g_trdp;
+
+void trdp_release(hfg_ctx *ctx) {
+  auto it = g_trdp.find(ctx);
+  if (it != g_trdp.end()) {
+    if (it->second->h_status) (void)hipHostFree(it->second->h_status);
+    delete it->second;
+    g_trdp.erase(it);
+  }
+}
+
+/// throws when the last persistent launch of this context ended through a spin limit (call after a synchronisation)
+void trdp_check_status(hfg_ctx *ctx) {
+  auto it = g_trdp.find(ctx);
+  if (it == g_trdp.end() || !it->second->pending) return;
+  TrdpWork &w = *it->second;
+  w.pending = false;
+  if (*w.h_status == 1)
+    throw std::runtime_error("persistent tridiagonalisation: an exchange between workgroups ran into its time limit");
+  // HELFEM_TRDP_STAMPS=1 (measurement builds of the kernel): phase durations of the last launch, printed once per launch
+  if (w.stamps.p && !w.last_ns.empty()) {
+    const int n0 = w.last_ns[0];
+    std::vector<unsigned long long> st((size_t)4 * (n0 + 2));
+    HFG_HIP_CHECK(hipMemcpy(st.data(), w.stamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+    // stamps of pass j (index j+1): 0 exchange landed | 1 element-wise done (barrier 2) | 2 published
+    double wait = 0, elem = 0, pub = 0, total = 0;
+    int cnt = 0;
+    for (int i = 2; i + 1 < n0 - 2; i++) {
+      const double t0 = (double)st[(size_t)i * 4 + 0], t1 = (double)st[(size_t)i * 4 + 1], t2 = (double)st[(size_t)i * 4 + 2];
+      const double p2 = (double)st[(size_t)(i - 1) * 4 + 2], n0s = (double)st[(size_t)(i + 1) * 4 + 0];
+      if (t0 == 0 || p2 == 0 || n0s == 0) continue;
+      wait += t0 - p2;   // published pass i-1 -> exchange i landed (includes the register update)
+      elem += t1 - t0;   // scalars + element-wise
+      pub += t2 - t1;    // row of z, product, publish
+      total += n0s - t0;
+      cnt++;
+    }
+    if (cnt)
+      fprintf(stderr, "k_trdp stamps (n = %d, R = %d, U = %d, grid %d; us per column over %d columns): column %.3f = update+wait %.3f | scalars+element-wise %.3f | product+publish %.3f\n",
+              n0, w.last_R, w.last_U, w.last_grid, cnt, total / cnt * 0.01, wait / cnt * 0.01, elem / cnt * 0.01, pub / cnt * 0.01);
+  }
+}
+
+typedef void (*trdp_kernel_t)(const TrdpDesc *);
+template <int R, int U, bool STAMPS>
+static trdp_kernel_t trdp_kernel() {
+  return k_trdp<R, U, STAMPS>;
+}
+static trdp_kernel_t trdp_pick(int R, int U, bool stamps) {
+#define TP_CASE(r, u) \
+  if (R == r && U == u) return stamps ? trdp_kernel<r, u, true>() : trdp_kernel<r, u, false>();
+  TP_CASE(1, 6) TP_CASE(2, 6) TP_CASE(3, 6) TP_CASE(4, 6) TP_CASE(6, 6)
+  TP_CASE(2, 12) TP_CASE(3, 12) TP_CASE(4, 12) TP_CASE(5, 12) TP_CASE(6, 12)
+#undef TP_CASE
+  return nullptr;
+}
+static const int tp_rows_choices[] = {1, 2, 3, 4, 5, 6};
+
+/// Persistent path of tridiagonalize_batch: returns false (nothing launched, nothing touched) when the batch does not
+/// fit -- order beyond the register tiles, more workgroups than CUs, the runtime refusing the cooperative launch -- or
+/// when HELFEM_TRD selects another variant.  Same outputs as the chain: d, e, tau, reflectors below the subdiagonal.
+bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
+                               double *const *tau) {
+  static const char *mode = getenv("HELFEM_TRD");
+  if (mode && strcmp(mode, "persistent") != 0) return false;
+  if (nblk < 1 || nblk > TP_MAXB) return false;
+  int nmax = 0, nmin = 1 << 30;
+  for (int i = 0; i < nblk; i++) {
+    nmax = std::max(nmax, ns[i]);
+    nmin = std::min(nmin, ns[i]);
+  }
+  static const int min_order = getenv("HELFEM_TRDP_MIN") ? atoi(getenv("HELFEM_TRDP_MIN")) : 256;
+  if (nmin < 3 || nmax < min_order) return false;
+  const int U = nmax <= 6 * TP_NCG ? 6 : (nmax <= 12 * TP_NCG ? 12 : 0);
+  if (U == 0) return false;
+  TrdpWork *wp;
+  auto it = g_trdp.find(ctx);
+  if (it == g_trdp.end()) {
+    wp = new TrdpWork();
+    g_trdp[ctx] = wp;
+    HFG_HIP_CHECK(hipDeviceGetAttribute(&wp->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    HFG_HIP_CHECK(hipHostMalloc((void **)&wp->h_status, 64, hipHostMallocDefault));
+    *wp->h_status = -1;
+  } else
+    wp = it->second;
+  TrdpWork &w = *wp;
+  if (w.pending) {
+    // the previous launch's status was copied back on this stream; by now that copy has long completed in any loop
+    // that consumed the eigenvalues, but it is only READ here when the event says so
+    if (hipStreamQuery(ctx->stream) == hipSuccess) trdp_check_status(ctx);
+  }
+  static const int forceR = getenv("HELFEM_TRDP_R") ? atoi(getenv("HELFEM_TRDP_R")) : 0;
+  int R = 0, grid = 0;
+  for (int r : tp_rows_choices) {
+    if (forceR && r != forceR) continue;
+    if (!trdp_pick(r, U, false)) continue;
+    int g = 0;
+    for (int i = 0; i < nblk; i++) g += (ns[i] + TP_NRG * r - 1) / (TP_NRG * r);
+    if (g <= w.ncu) {
+      R = r;
+      grid = g;
+      break;
+    }
+  }
+  if (R == 0) return false;
+  static const bool want_stamps = getenv("HELFEM_TRDP_STAMPS") && atoi(getenv("HELFEM_TRDP_STAMPS")) != 0;
+  trdp_kernel_t kern = trdp_pick(R, U, want_stamps);
+  if (!kern) return false;
+  const int M = TP_NRG * R, NP = TP_NCG * U, SEG = ((M + 1 + 15) / 16) * 16;
+  TrdpDesc D{};
+  D.nblk = nblk;
+  size_t words = 16;
+  std::vector<size_t> off(nblk);
+  int wg = 0;
+  for (int i = 0; i < nblk; i++) {
+    const int G = (ns[i] + M - 1) / M;
+    D.wg0[i] = wg;
+    wg += G;
+    D.n[i] = ns[i];
+    D.G[i] = G;
+    D.A[i] = A[i];
+    D.d[i] = d[i];
+    D.e[i] = e[i];
+    D.tau[i] = tau[i];
+    off[i] = words;
+    words += (size_t)TP_SLOTS * ((size_t)G * SEG + NP);
+    if (G > TP_MAXG) return false;  // the landing area of the dot words
+  }
+  for (int i = nblk; i <= TP_MAXB; i++) D.wg0[i] = wg;
+  words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
+  w.ring.resize(words);
+  for (int i = 0; i < nblk; i++) D.xb[i] = w.ring.p + off[i];
+  D.status = (int *)w.ring.p;
+  D.stamps = nullptr;
+  if (want_stamps) {
+    w.stamps.resize((size_t)4 * (nmax + 2));
+    HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, (size_t)4 * (nmax + 2) * 8, ctx->stream));
+    D.stamps = w.stamps.p;
+  }
+  static const long long limit_ms = getenv("HELFEM_TRDP_LIMIT_MS") ? atoll(getenv("HELFEM_TRDP_LIMIT_MS")) : 200;
+  D.spin_limit = limit_ms * 100000ll;  // 100 MHz wall clock
+  hipStream_t s = ctx->stream;
+  upload_cached(w.desc, w.h_desc, std::vector<TrdpDesc>(1, D), s);
+  HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, words * sizeof(unsigned long long), s));
+  const TrdpDesc *dptr = w.desc.p;
+  void *args[] = {(void *)&dptr};
+  hipError_t err = hipLaunchCooperativeKernel((const void *)kern, dim3(grid), dim3(TP_NT), args, 0, s);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();  // refused (grid not co-resident on this device): the chain runs instead
+    static bool told = false;
+    if (!told) {
+      fprintf(stderr, "helfem_amd: cooperative launch of the persistent tridiagonalisation refused (%s): grid %d; using the launch chain\n",
+              hipGetErrorString(err), grid);
+      told = true;
+    }
+    return false;
+  }
+  HFG_HIP_CHECK(hipMemcpyAsync(w.h_status, w.ring.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  w.pending = true;
+  w.last_ns.assign(ns, ns + nblk);
+  w.last_R = R;
+  w.last_U = U;
+  w.last_grid = grid;
+  return true;
+}
+
+/// replay of the last batch's launch on scratch copies is not possible (the kernel consumes its input); the bench
+/// times the launch inside the eigensolve through the profiling events of the "eig_tridiag" scope instead.
+void trdp_last_shape(hfg_ctx *ctx, int *R, int *U, int *grid) {
+  *R = *U = *grid = 0;
+  auto it = g_trdp.find(ctx);
+  if (it == g_trdp.end()) return;
+  *R = it->second->last_R;
+  *U = it->second->last_U;
+  *grid = it->second->last_grid;
+}
+
+}  // namespace hfg
