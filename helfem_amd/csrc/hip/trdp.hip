@@ -90,7 +90,8 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   // published including dead columns, dead rows updated with stale vectors (never read again).
   __shared__ double X[NL], VP[NL], WP[NL];
   __shared__ double YL[NL], ZL[NL];  // landing area of an exchange (each thread re-reads only what it stored itself)
-  __shared__ double part[M][2];
+  __shared__ double part[M][8];
+  __shared__ double ZS[NP];  // staging of the row z (owner only)
   __shared__ double red[3][TP_NW];
   __shared__ double dots[TP_MAXG];
   __shared__ double zq0[2];
@@ -137,35 +138,25 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   for (int r = tid; r < TP_MAXG; r += TP_NT) dots[r] = 0.0;
   __syncthreads();
   // ---- prologue: column 0 is the first x, nothing to correct ----
-  {
-    double ps = 0.0;
-    for (int r = 1 + tid; r < n; r += TP_NT) {
-      const double xv = A[r];
-      X[r] = xv;
-      if (r > 1) ps += xv * xv;
-    }
-    ps = wave_sum(ps);
-    if (lane == 0) {
-      red[0][wave] = 0.0;
-      red[1][wave] = 0.0;
-      red[2][wave] = ps;
-    }
-    if (k == 0 && tid == 0) dw[0] = A[0];
-  }
+  for (int r = 1 + tid; r < n; r += TP_NT) X[r] = A[r];
+  if (k == 0 && tid == 0) dw[0] = A[0];
+  __syncthreads();
 
   // scalars of the column being reduced, carried from the end of one pass to the exchange of the next
   double c1 = 0.0, c2 = 0.0, beta = 0.0, tau = 0.0, scl = 0.0;
 
   // pass j: (j >= 0) consume exchange j -> v_j, w_j, x_{j+1};  then publish exchange j+1.  Pass -1 only publishes.
+  // Critical path of a column: exchange lands -> barrier 1 -> scalars, element-wise -> barrier 2 -> rows of the product
+  // -> barrier 3 -> publish.  Everything else (register update, the row z, partial sums and scalars of the next column)
+  // runs between the publish and the next landing.
   int j = -1;
   for (;; j++) {
-    const int j1 = j + 1;
+    const int j1 = j + 1, j2 = j + 2;
     if ((k + 1) * M - 1 < j1) return;  // no row of the trailing matrix left here
     // =============== rank-2 update of column j-1 on the registers ===============
-    // (runs while the exchange of column j is in flight: the workgroup published its part just before.  At the top of
-    // the loop body, in front of every use of the tile in this pass, so that the tile is updated in place -- with the
-    // update behind its uses the compiler kept two copies of the tile.  VP = WP = 0 in the first two passes; rows and
-    // columns already reduced are updated with stale values and never read again.)
+    // (At the top of the loop body, in front of every use of the tile in this pass, so that the tile is updated in
+    // place -- with the update behind its uses the compiler kept two copies of the tile.  VP = WP = 0 in the first two
+    // passes; rows and columns already reduced are updated with stale values and never read again.)
     {
       double vr[R], wr[R];
 #pragma unroll
@@ -180,10 +171,32 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
         for (int i = 0; i < R; i++) a[i][u] -= vr[i] * wc + wr[i] * vc;
       }
     }
+    // =============== row j+2 for exchange j+1, one exchange AHEAD of the products ===============
+    // The registers now hold A^(j) (every update up to column j-1).  The owner of row j+2 publishes it RAW; the
+    // consumers apply the update of column j themselves (z = raw - v_j[j+2] w_j - w_j[j+2] v_j: they know v_j and w_j
+    // in full by then), so this row never sits on the critical path of a column.
+    if (j < n - 3 && k == j2 / M && rg == (j2 % M) / R) {
+      const int iz = (j2 % M) % R;
+      // staged through LDS (every thread re-reads only its own words) so that the stores can be a ROLLED loop: unrolled,
+      // their twelve 64-bit addresses were hoisted out of the column loop and cost 24 registers for its whole duration
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        double av = a[0][u];
+#pragma unroll
+        for (int i = 1; i < R; i++)
+          if (i == iz) av = a[i][u];
+        ZS[cg + TP_NCG * u] = av;
+      }
+      gu64 *zrow = xb + (size_t)(j1 & (TP_SLOTS - 1)) * slotw + (size_t)G * SEG;
+#pragma unroll 1
+      for (int c = cg; c < NP; c += TP_NCG) tp_store(zrow + c, tp_bits(ZS[c]));
+    }
+    double pc1 = 0.0, pc2 = 0.0, ps = 0.0;  // partial sums for the next column
     if (j >= 0) {
-      // =============== exchange j: wait for y (rows >= j+1), z (columns >= j+1), dots ===============
+      // =============== exchange j: wait for y (rows >= j+1), raw z (columns >= j+1), dots ===============
       gu64 *sb = xb + (size_t)(j & (TP_SLOTS - 1)) * slotw;
       const int kf = j1 / M;  // first workgroup that still owns rows
+      const double vz = VP[j1], wz = WP[j1];  // v_{j-1}, w_{j-1} at the row that is now the pivot row
       unsigned long long yb[EPT], zb[EPT], dd = TP_SENT;
 #pragma unroll
       for (int h = 0; h < EPT; h++) yb[h] = zb[h] = TP_SENT;
@@ -219,9 +232,9 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
         ZL[r] = tp_dbl(zb[h]);
       }
       if (tid == 0) {
-        // element r = j+1: z_0 and q_0 = y_0 - v_{j-1}[j+1] c1 - w_{j-1}[j+1] c2 for everybody
-        zq0[0] = tp_dbl(zb[0]);
-        zq0[1] = tp_dbl(yb[0]) - VP[j1] * c1 - WP[j1] * c2;
+        // element r = j+1: z_0 = raw - 2 v w there, q_0 = y_0 - v_{j-1}[j+1] c1 - w_{j-1}[j+1] c2, for everybody
+        zq0[0] = tp_dbl(zb[0]) - 2.0 * vz * wz;
+        zq0[1] = tp_dbl(yb[0]) - vz * c1 - wz * c2;
       }
       if (tid < TP_MAXG) dots[tid] = (kf + tid < G) ? tp_dbl(dd) : 0.0;
       __syncthreads();  // (1)
@@ -238,40 +251,35 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       const double aa = -0.5 * tau * vtp;
       const double ts = tau * scl;
       const double w0 = ts * (q0 - beta * zz0) + aa;
-      // ---- element-wise: v_j, w_j, x_{j+1}; partial sums for the next column (rolled: the register tile needs the room) ----
-      double pc1 = 0.0, pc2 = 0.0, ps = 0.0;
+      // ---- element-wise: v_j, w_j, x_{j+1} (rolled: the register tile needs the room) ----
+      const int own0 = k * M;
 #pragma unroll 1
       for (int r = j1 + tid; r < n; r += TP_NT) {
-        const double y = YL[r], z = ZL[r];
-        const double xo = X[r];
-        const double q = y - VP[r] * c1 - WP[r] * c2;
-        const double vn = (r == j1) ? 1.0 : scl * xo;
+        const double vpo = VP[r], wpo = WP[r];
+        const double z = ZL[r] - vz * wpo - wz * vpo;  // row j+1 with the update of column j-1 applied
+        const double q = YL[r] - vpo * c1 - wpo * c2;
+        const double vn = (r == j1) ? 1.0 : scl * X[r];
         const double wn = ts * (q - beta * z) + aa * vn;
         double xn = 0.0;
         if (r > j1) {
           xn = z - vn * w0 - wn;
           pc1 += wn * xn;
           pc2 += vn * xn;
-          if (r > j1 + 1) ps += xn * xn;
-          if (r / M == k) A[(size_t)j * n + r] = vn;  // reflector for the back-transformation (LAPACK layout)
+          if (r > j2) ps += xn * xn;
+          if ((unsigned)(r - own0) < (unsigned)M) A[(size_t)j * n + r] = vn;  // reflector for the back-transformation (LAPACK layout)
         }
         X[r] = xn;
         VP[r] = vn;
         WP[r] = wn;
-      }
-      pc1 = wave_sum(pc1);
-      pc2 = wave_sum(pc2);
-      ps = wave_sum(ps);
-      if (lane == 0) {
-        red[0][wave] = pc1;
-        red[1][wave] = pc2;
-        red[2][wave] = ps;
       }
       if (k == kf && tid == 0) {
         dw[j1] = zz0 - 2.0 * w0;
         ew[j] = beta;
         tauw[j] = tau;
       }
+    } else {
+      // pass -1: |x_0[1:]|^2 of column 0
+      for (int r = 2 + tid; r < n; r += TP_NT) ps += X[r] * X[r];
     }
     __syncthreads();  // (2): X = x_{j+1}, VP = v_j, WP = w_j
     if constexpr (STAMPS) {
@@ -279,30 +287,9 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
     }
     if (j == n - 3) break;  // the last column has no successor to prepare
 
-    // =============== publish exchange j+1 ===============
-    gu64 *sb1 = xb + (size_t)((j + 1) & (TP_SLOTS - 1)) * slotw;
-    const int j2 = j + 2;
-    // the owner of row j+2 publishes it with the update of column j applied on the fly (all of the row's columns: the
-    // reduced ones are not read by anybody)
-    if (k == j2 / M && rg == (j2 % M) / R) {
-      const int iz = (j2 % M) % R;
-      const double vz = VP[j2], wz = WP[j2];
-      // staged through LDS (every thread re-reads only its own words) so that the stores can be a ROLLED loop: unrolled,
-      // their twelve 64-bit addresses were hoisted out of the column loop and cost 24 registers for its whole duration
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int c = cg + TP_NCG * u;
-        double av = a[0][u];
-#pragma unroll
-        for (int i = 1; i < R; i++)
-          if (i == iz) av = a[i][u];
-        ZL[c] = av - vz * WP[c] - wz * VP[c];
-      }
-      gu64 *zrow = sb1 + (size_t)G * SEG;
-#pragma unroll 1
-      for (int c = cg; c < NP; c += TP_NCG) tp_store(zrow + c, tp_bits(ZL[c]));
-    }
-    // rows of the product with x_{j+1} (registers still lack the update of column j; X is zero on reduced columns)
+    // =============== publish exchange j+1: rows of the product with x_{j+1} ===============
+    // (registers still lack the update of column j; X is zero on reduced columns)
+    gu64 *sb1 = xb + (size_t)(j1 & (TP_SLOTS - 1)) * slotw;
     {
       double acc[R];
 #pragma unroll
@@ -313,10 +300,13 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
 #pragma unroll
         for (int i = 0; i < R; i++) acc[i] += a[i][u] * xc;
       }
+      // sums over the 16 lanes of a DPP row (four butterfly steps, the R chains interleave); the eight row sums of a
+      // matrix row meet in LDS and the publishing lane adds them in a fixed order
 #pragma unroll
-      for (int i = 0; i < R; i++) {
-        const double t = wave_sum(acc[i]);
-        if (lane == 0) part[rg * R + i][wave & 1] = t;
+      for (int i = 0; i < R; i++) acc[i] = row16_sum(acc[i]);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < R; i++) part[rg * R + i][(wave & 1) * 4 + (lane >> 4)] = acc[i];
       }
     }
     __syncthreads();  // (3)
@@ -324,7 +314,10 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       const int r = k * M + lane;
       const bool live = lane < M && r >= j2 && r < n;
       double yv = 0.0, dc = 0.0;
-      if (lane < M) yv = part[lane][0] + part[lane][1];
+      if (lane < M) {
+        const double *pp = part[lane];
+        yv = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
+      }
       if (live) {
         tp_store(sb1 + (size_t)k * SEG + lane, tp_bits(yv));
         dc = X[r] * yv;
@@ -336,14 +329,25 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
       if (lane <= M) tp_store(sb3 + (size_t)k * SEG + lane, TP_SENT);
     }
+    if constexpr (STAMPS) {
+      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 2] = wall_clock64();
+    }
+    // the row of exchange j+3 is published (raw, see above) at the top of pass j+2 by the owner of row j+4: that
+    // workgroup poisons the words now
     if (j + 4 < n && (j + 4) / M == k) {
       gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
       for (int c = tid; c < NP; c += TP_NT) tp_store(sb3 + (size_t)G * SEG + c, TP_SENT);
     }
-    if constexpr (STAMPS) {
-      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 2] = wall_clock64();
+    // =============== off the critical path: partial sums and scalars of column j+1 ===============
+    pc1 = wave_sum(pc1);
+    pc2 = wave_sum(pc2);
+    ps = wave_sum(ps);
+    if (lane == 0) {
+      red[0][wave] = pc1;
+      red[1][wave] = pc2;
+      red[2][wave] = ps;
     }
-    // scalars of column j+1: c1, c2, |x[1:]|^2 from the wave partials (same order in every wave and workgroup)
+    __syncthreads();  // (4)
     {
       c1 = tp_wsum(red[0][lane & (TP_NW - 1)]);
       c2 = tp_wsum(red[1][lane & (TP_NW - 1)]);
