@@ -55,7 +55,7 @@ struct TrdpDesc {
   int wg0[TP_MAXB + 1];  // first workgroup of every matrix
   int n[TP_MAXB], G[TP_MAXB];
   double *A[TP_MAXB], *d[TP_MAXB], *e[TP_MAXB], *tau[TP_MAXB];
-  unsigned long long *xb[TP_MAXB];  // exchange ring: TP_SLOTS x (G x SEG + NP) words
+  unsigned long long *xb[TP_MAXB];  // exchange ring: TP_SLOTS x (y: NP + 64 | z: NP | dots: TP_MAXG) words
   int *status;                      // 1: a spin ran into its limit (poisoned to -1 before the launch)
   unsigned long long *stamps;       // measurement only (nullptr in the product path): 4 wall-clock stamps per column
   long long spin_limit;             // wall-clock ticks (100 MHz)
@@ -75,11 +75,16 @@ __device__ __forceinline__ double tp_wsum(double v) {
   else return row16_sum(v);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every wave would wait at
+// every barrier for the write-through stores of the exchange (about a microsecond each) and for the prefetch of the next
+// row z: everything the threads of a workgroup tell each other goes through LDS, and words of the exchange that are
+// written twice (poison, then data) are written by the SAME thread both times, so no barrier has to order them.
+#define TP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 template <int R, int U, bool STAMPS>
 __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp) {
   constexpr int M = TP_NRG * R;   // rows per workgroup
   constexpr int NP = TP_NCG * U;  // padded order
-  constexpr int SEG = ((M + 1 + 15) / 16) * 16;  // words of a workgroup's exchange segment: its rows of y, then dot
   constexpr int EPT = (NP + TP_NT - 1) / TP_NT;  // vector elements per thread in the element-wise phase
   constexpr int NL = NP + 64;                    // LDS vectors: rows of the last workgroup may lie beyond NP
   static_assert(M <= 63, "the rows of a workgroup and its dot word are published by one wave");
@@ -104,7 +109,8 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   gdouble *A = (gdouble *)D.A[blk];
   gdouble *dw = (gdouble *)D.d[blk], *ew = (gdouble *)D.e[blk], *tauw = (gdouble *)D.tau[blk];
   gu64 *xb = (gu64 *)D.xb[blk];
-  const int slotw = G * SEG + NP;
+  // a slot: y by row (the rows of the last workgroup may reach beyond NP) | z by column | one dot word per workgroup
+  constexpr int ZOFF = NP + 64, DOFF = 2 * NP + 64, slotw = DOFF + TP_MAXG;
   const long long spin_limit = D.spin_limit;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,6 +155,9 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   // Critical path of a column: exchange lands -> barrier 1 -> scalars, element-wise -> barrier 2 -> rows of the product
   // -> barrier 3 -> publish.  Everything else (register update, the row z, partial sums and scalars of the next column)
   // runs between the publish and the next landing.
+  unsigned long long zb[EPT];  // words of z of the NEXT exchange, fetched at the end of a pass
+#pragma unroll
+  for (int h = 0; h < EPT; h++) zb[h] = TP_SENT;
   int j = -1;
   for (;; j++) {
     const int j1 = j + 1, j2 = j + 2;
@@ -175,21 +184,25 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
     // The registers now hold A^(j) (every update up to column j-1).  The owner of row j+2 publishes it RAW; the
     // consumers apply the update of column j themselves (z = raw - v_j[j+2] w_j - w_j[j+2] v_j: they know v_j and w_j
     // in full by then), so this row never sits on the critical path of a column.
-    if (j < n - 3 && k == j2 / M && rg == (j2 % M) / R) {
-      const int iz = (j2 % M) % R;
-      // staged through LDS (every thread re-reads only its own words) so that the stores can be a ROLLED loop: unrolled,
-      // their twelve 64-bit addresses were hoisted out of the column loop and cost 24 registers for its whole duration
+    if (j < n - 3 && k == j2 / M) {
+      // staged through LDS so that ALL threads store (three words each, the same thread that poisoned the word): the
+      // workgroup that owns the row is also the one every other workgroup ends up waiting for
+      if (rg == (j2 % M) / R) {
+        const int iz = (j2 % M) % R;
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        double av = a[0][u];
+        for (int u = 0; u < U; u++) {
+          double av = a[0][u];
 #pragma unroll
-        for (int i = 1; i < R; i++)
-          if (i == iz) av = a[i][u];
-        ZS[cg + TP_NCG * u] = av;
+          for (int i = 1; i < R; i++)
+            if (i == iz) av = a[i][u];
+          ZS[cg + TP_NCG * u] = av;
+        }
       }
-      gu64 *zrow = xb + (size_t)(j1 & (TP_SLOTS - 1)) * slotw + (size_t)G * SEG;
-#pragma unroll 1
-      for (int c = cg; c < NP; c += TP_NCG) tp_store(zrow + c, tp_bits(ZS[c]));
+      TP_LDS_BARRIER();
+      gu64 *zrow = xb + (size_t)(j1 & (TP_SLOTS - 1)) * slotw + ZOFF;
+#pragma unroll
+      for (int h = 0; h < EPT; h++)
+        if (tid + TP_NT * h < NP) tp_store(zrow + tid + TP_NT * h, tp_bits(ZS[tid + TP_NT * h]));
     }
     double pc1 = 0.0, pc2 = 0.0, ps = 0.0;  // partial sums for the next column
     if (j >= 0) {
@@ -197,33 +210,57 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       gu64 *sb = xb + (size_t)(j & (TP_SLOTS - 1)) * slotw;
       const int kf = j1 / M;  // first workgroup that still owns rows
       const double vz = VP[j1], wz = WP[j1];  // v_{j-1}, w_{j-1} at the row that is now the pivot row
-      unsigned long long yb[EPT], zb[EPT], dd = TP_SENT;
-#pragma unroll
-      for (int h = 0; h < EPT; h++) yb[h] = zb[h] = TP_SENT;
+      // The words of y carry their own arrival (sentinel), but re-reading all of them until the last one has landed
+      // costs the memory fabric 2.5 MB per attempt (212 workgroups x 12 KB: 0.5 us of its time); so after ONE attempt a
+      // thread spins on the dot word of the workgroup that owns its row -- stored behind that workgroup's rows of y by the
+      // same wave, a few cache lines per wave -- and fetches the row again when that word has landed.  The words of z were
+      // published a whole exchange earlier and fetched at the end of the previous pass (zb); they are re-read only in
+      // the unlikely case that they had not landed then.
+      unsigned long long yb[EPT], dd = TP_SENT;
       const int kd = min(kf + tid, G - 1);  // clamped: surplus threads poll the last word again
+      if constexpr (STAMPS) {
+        if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 3] = wall_clock64();
+      }
+#pragma unroll
+      for (int h = 0; h < EPT; h++) yb[h] = tp_load(sb + min(j1 + tid + TP_NT * h, n - 1));
+      dd = tp_load(sb + DOFF + kd);
       {
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
         for (;;) {
-          bool ok = true;
-#pragma unroll
-          for (int h = 0; h < EPT; h++) {
-            const int r = min(j1 + tid + TP_NT * h, n - 1);
-            if (yb[h] == TP_SENT) yb[h] = tp_load(sb + (size_t)(r / M) * SEG + (r % M));
-            if (zb[h] == TP_SENT) zb[h] = tp_load(sb + (size_t)G * SEG + r);
-          }
-          if (dd == TP_SENT) dd = tp_load(sb + (size_t)kd * SEG + M);
+          bool ok = dd != TP_SENT;
 #pragma unroll
           for (int h = 0; h < EPT; h++) ok = ok && yb[h] != TP_SENT && zb[h] != TP_SENT;
-          ok = ok && dd != TP_SENT;
+          if constexpr (STAMPS) {
+            if (blk == 0 && k == G - 1 && spins == 0) {
+              // first check: how many lanes of each wave miss y / z / dot (wave 0 .. 7 -> stamps 4, packed by 8 bits x 3)
+              bool my = false, mz = false;
+#pragma unroll
+              for (int h = 0; h < EPT; h++) {
+                my = my || yb[h] == TP_SENT;
+                mz = mz || zb[h] == TP_SENT;
+              }
+              const unsigned long long cy = __popcll(__ballot(my)), cz = __popcll(__ballot(mz)), cd = __popcll(__ballot(dd == TP_SENT));
+              if (lane == 0) atomicAdd((unsigned long long *)D.stamps + (size_t)j1 * 8 + 4, cy | (cz << 16) | (cd << 32));
+            }
+          }
           if (ok) break;
           if (((++spins) & 15u) == 0u && (long long)(wall_clock64() - t0) > spin_limit) {
             abort_flag = 1;
             __hip_atomic_store((__attribute__((address_space(1))) int *)D.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int h = 0; h < EPT; h++) {
+            const int r = min(j1 + tid + TP_NT * h, n - 1);
+            if (yb[h] == TP_SENT && tp_load(sb + DOFF + r / M) != TP_SENT) yb[h] = tp_load(sb + r);
+            if (zb[h] == TP_SENT) zb[h] = tp_load(sb + ZOFF + r);
+          }
+          if (dd == TP_SENT) dd = tp_load(sb + DOFF + kd);
         }
+      }
+      if constexpr (STAMPS) {
+        if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 5] = wall_clock64();
       }
 #pragma unroll
       for (int h = 0; h < EPT; h++) {
@@ -237,10 +274,10 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
         zq0[1] = tp_dbl(yb[0]) - vz * c1 - wz * c2;
       }
       if (tid < TP_MAXG) dots[tid] = (kf + tid < G) ? tp_dbl(dd) : 0.0;
-      __syncthreads();  // (1)
+      TP_LDS_BARRIER();  // (1)
       if (abort_flag) return;
       if constexpr (STAMPS) {
-        if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 0] = wall_clock64();
+        if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 0] = wall_clock64();
       }
       // ---- scalars, redundantly in every wave (fixed orders: bitwise the same in every workgroup) ----
       double dsum = (dots[lane] + dots[lane + 64]) + (dots[lane + 128] + dots[lane + 192]);
@@ -281,9 +318,9 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       // pass -1: |x_0[1:]|^2 of column 0
       for (int r = 2 + tid; r < n; r += TP_NT) ps += X[r] * X[r];
     }
-    __syncthreads();  // (2): X = x_{j+1}, VP = v_j, WP = w_j
+    TP_LDS_BARRIER();  // (2): X = x_{j+1}, VP = v_j, WP = w_j
     if constexpr (STAMPS) {
-      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 1] = wall_clock64();
+      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 1] = wall_clock64();
     }
     if (j == n - 3) break;  // the last column has no successor to prepare
 
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
         for (int i = 0; i < R; i++) part[rg * R + i][(wave & 1) * 4 + (lane >> 4)] = acc[i];
       }
     }
-    __syncthreads();  // (3)
+    TP_LDS_BARRIER();  // (3)
     if (wave == 0) {
       const int r = k * M + lane;
       const bool live = lane < M && r >= j2 && r < n;
@@ -319,26 +356,30 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
         yv = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
       }
       if (live) {
-        tp_store(sb1 + (size_t)k * SEG + lane, tp_bits(yv));
+        tp_store(sb1 + r, tp_bits(yv));
         dc = X[r] * yv;
       }
       dc = wave_sum(dc);
-      if (lane == 0) tp_store(sb1 + (size_t)k * SEG + M, tp_bits(dc));
+      if (lane == 0) tp_store(sb1 + DOFF + k, tp_bits(dc));  // behind this wave's rows of y: doubles as their arrival flag
       // poison what this workgroup writes for exchange j+3 (its slot held exchange j-1, which everybody has consumed:
       // exchange j could only complete after every workgroup had published it, i.e. after it had read exchange j-1)
       gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
-      if (lane <= M) tp_store(sb3 + (size_t)k * SEG + lane, TP_SENT);
+      if (lane < M) tp_store(sb3 + k * M + lane, TP_SENT);  // the same lanes that store the data: program order
+      if (lane == 0) tp_store(sb3 + DOFF + k, TP_SENT);
     }
     if constexpr (STAMPS) {
-      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 4 + 2] = wall_clock64();
+      if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 2] = wall_clock64();
     }
     // the row of exchange j+3 is published (raw, see above) at the top of pass j+2 by the owner of row j+4: that
     // workgroup poisons the words now
     if (j + 4 < n && (j + 4) / M == k) {
       gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
-      for (int c = tid; c < NP; c += TP_NT) tp_store(sb3 + (size_t)G * SEG + c, TP_SENT);
+      for (int c = tid; c < NP; c += TP_NT) tp_store(sb3 + ZOFF + c, TP_SENT);
     }
-    // =============== off the critical path: partial sums and scalars of column j+1 ===============
+    // =============== off the critical path: z of exchange j+1 (published at the top of this pass), partial sums and
+    // scalars of column j+1 ===============
+#pragma unroll
+    for (int h = 0; h < EPT; h++) zb[h] = tp_load(sb1 + ZOFF + min(j2 + tid + TP_NT * h, n - 1));
     pc1 = wave_sum(pc1);
     pc2 = wave_sum(pc2);
     ps = wave_sum(ps);
@@ -347,7 +388,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       red[1][wave] = pc2;
       red[2][wave] = ps;
     }
-    __syncthreads();  // (4)
+    TP_LDS_BARRIER();  // (4)
     {
       c1 = tp_wsum(red[0][lane & (TP_NW - 1)]);
       c2 = tp_wsum(red[1][lane & (TP_NW - 1)]);
@@ -420,24 +461,34 @@ void trdp_check_status(hfg_ctx *ctx) {
   // HELFEM_TRDP_STAMPS=1 (measurement builds of the kernel): phase durations of the last launch, printed once per launch
   if (w.stamps.p && !w.last_ns.empty()) {
     const int n0 = w.last_ns[0];
-    std::vector<unsigned long long> st((size_t)4 * (n0 + 2));
+    std::vector<unsigned long long> st((size_t)8 * (n0 + 2));
     HFG_HIP_CHECK(hipMemcpy(st.data(), w.stamps.p, st.size() * 8, hipMemcpyDeviceToHost));
-    // stamps of pass j (index j+1): 0 exchange landed | 1 element-wise done (barrier 2) | 2 published
-    double wait = 0, elem = 0, pub = 0, total = 0;
+    // stamps of pass j (index j+1): 3 poll starts | 0 exchange landed | 1 element-wise done (barrier 2) | 2 published
+    double wait = 0, post = 0, elem = 0, pub = 0, total = 0;
     int cnt = 0;
     for (int i = 2; i + 1 < n0 - 2; i++) {
-      const double t0 = (double)st[(size_t)i * 4 + 0], t1 = (double)st[(size_t)i * 4 + 1], t2 = (double)st[(size_t)i * 4 + 2];
-      const double p2 = (double)st[(size_t)(i - 1) * 4 + 2], n0s = (double)st[(size_t)(i + 1) * 4 + 0];
-      if (t0 == 0 || p2 == 0 || n0s == 0) continue;
-      wait += t0 - p2;   // published pass i-1 -> exchange i landed (includes the register update)
+      const double t0 = (double)st[(size_t)i * 8 + 0], t1 = (double)st[(size_t)i * 8 + 1], t2 = (double)st[(size_t)i * 8 + 2];
+      const double t3 = (double)st[(size_t)i * 8 + 3];
+      const double p2 = (double)st[(size_t)(i - 1) * 8 + 2], n0s = (double)st[(size_t)(i + 1) * 8 + 0];
+      if (t0 == 0 || p2 == 0 || n0s == 0 || t3 == 0) continue;
+      post += t3 - p2;   // published pass i-1 -> poll of exchange i starts: sums, scalars, register update, row z
+      wait += t0 - t3;   // poll -> landed
       elem += t1 - t0;   // scalars + element-wise
-      pub += t2 - t1;    // row of z, product, publish
+      pub += t2 - t1;    // product, publish
       total += n0s - t0;
       cnt++;
     }
+    if (getenv("HELFEM_TRDP_STAMPS") && atoi(getenv("HELFEM_TRDP_STAMPS")) >= 2 && n0 > 200) {
+      fprintf(stderr, "k_trdp stamps, columns 100..160 (us): column | post-publish work | poll | element-wise | product+publish || thread 0 done polling at | lanes missing y, z, dot at the first check\n");
+      for (int i = 100; i < 160; i++)
+        fprintf(stderr, "  %4d  %.2f | %.2f | %.2f | %.2f | %.2f || %.2f | %llu %llu %llu\n", i, (double)(st[(size_t)(i + 1) * 8] - st[(size_t)i * 8]) * 0.01,
+                (double)(st[(size_t)i * 8 + 3] - st[(size_t)(i - 1) * 8 + 2]) * 0.01, (double)(st[(size_t)i * 8] - st[(size_t)i * 8 + 3]) * 0.01,
+                (double)(st[(size_t)i * 8 + 1] - st[(size_t)i * 8]) * 0.01, (double)(st[(size_t)i * 8 + 2] - st[(size_t)i * 8 + 1]) * 0.01, (double)(st[(size_t)i * 8 + 5] - st[(size_t)i * 8 + 3]) * 0.01,
+                st[(size_t)i * 8 + 4] & 0xffff, (st[(size_t)i * 8 + 4] >> 16) & 0xffff, (st[(size_t)i * 8 + 4] >> 32) & 0xffff);
+    }
     if (cnt)
-      fprintf(stderr, "k_trdp stamps (n = %d, R = %d, U = %d, grid %d; us per column over %d columns): column %.3f = update+wait %.3f | scalars+element-wise %.3f | product+publish %.3f\n",
-              n0, w.last_R, w.last_U, w.last_grid, cnt, total / cnt * 0.01, wait / cnt * 0.01, elem / cnt * 0.01, pub / cnt * 0.01);
+      fprintf(stderr, "k_trdp stamps (n = %d, R = %d, U = %d, grid %d; us per column over %d columns): column %.3f = sums+scalars+update %.3f | poll %.3f | scalars+element-wise %.3f | product+publish %.3f\n",
+              n0, w.last_R, w.last_U, w.last_grid, cnt, total / cnt * 0.01, post / cnt * 0.01, wait / cnt * 0.01, elem / cnt * 0.01, pub / cnt * 0.01);
   }
 }
 
@@ -506,7 +557,7 @@ bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   static const bool want_stamps = getenv("HELFEM_TRDP_STAMPS") && atoi(getenv("HELFEM_TRDP_STAMPS")) != 0;
   trdp_kernel_t kern = trdp_pick(R, U, want_stamps);
   if (!kern) return false;
-  const int M = TP_NRG * R, NP = TP_NCG * U, SEG = ((M + 1 + 15) / 16) * 16;
+  const int M = TP_NRG * R, NP = TP_NCG * U;
   TrdpDesc D{};
   D.nblk = nblk;
   size_t words = 16;
@@ -523,7 +574,7 @@ bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     D.e[i] = e[i];
     D.tau[i] = tau[i];
     off[i] = words;
-    words += (size_t)TP_SLOTS * ((size_t)G * SEG + NP);
+    words += (size_t)TP_SLOTS * ((size_t)2 * NP + 64 + TP_MAXG);
     if (G > TP_MAXG) return false;  // the landing area of the dot words
   }
   for (int i = nblk; i <= TP_MAXB; i++) D.wg0[i] = wg;
@@ -533,8 +584,8 @@ bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   D.status = (int *)w.ring.p;
   D.stamps = nullptr;
   if (want_stamps) {
-    w.stamps.resize((size_t)4 * (nmax + 2));
-    HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, (size_t)4 * (nmax + 2) * 8, ctx->stream));
+    w.stamps.resize((size_t)8 * (nmax + 2));
+    HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, (size_t)8 * (nmax + 2) * 8, ctx->stream));
     D.stamps = w.stamps.p;
   }
   static const long long limit_ms = getenv("HELFEM_TRDP_LIMIT_MS") ? atoll(getenv("HELFEM_TRDP_LIMIT_MS")) : 200;
