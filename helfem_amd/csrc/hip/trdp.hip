@@ -155,9 +155,9 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   // Critical path of a column: exchange lands -> barrier 1 -> scalars, element-wise -> barrier 2 -> rows of the product
   // -> barrier 3 -> publish.  Everything else (register update, the row z, partial sums and scalars of the next column)
   // runs between the publish and the next landing.
-  unsigned long long zb[EPT];  // words of z of the NEXT exchange, fetched at the end of a pass
+  unsigned long long zb[EPT], yb[EPT], dd = TP_SENT;  // words of the NEXT exchange, first fetched at the end of a pass
 #pragma unroll
-  for (int h = 0; h < EPT; h++) zb[h] = TP_SENT;
+  for (int h = 0; h < EPT; h++) zb[h] = yb[h] = TP_SENT;
   int j = -1;
   for (;; j++) {
     const int j1 = j + 1, j2 = j + 2;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       for (int u = 0; u < U; u++) {
         const double vc = VP[cg + TP_NCG * u], wc = WP[cg + TP_NCG * u];
 #pragma unroll
-        for (int i = 0; i < R; i++) a[i][u] -= vr[i] * wc + wr[i] * vc;
+        for (int i = 0; i < R; i++) a[i][u] = fma(-wr[i], vc, fma(-vr[i], wc, a[i][u]));  // two instructions per element
       }
     }
     // =============== row j+2 for exchange j+1, one exchange AHEAD of the products ===============
@@ -188,15 +188,15 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       // staged through LDS so that ALL threads store (three words each, the same thread that poisoned the word): the
       // workgroup that owns the row is also the one every other workgroup ends up waiting for
       if (rg == (j2 % M) / R) {
+        // one of the R rows of this thread; a branch per row instead of a chain of selects per element (2 (R - 1) U
+        // instructions in the workgroup every other one is waiting for)
         const int iz = (j2 % M) % R;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          double av = a[0][u];
+        for (int i = 0; i < R; i++)
+          if (i == iz) {
 #pragma unroll
-          for (int i = 1; i < R; i++)
-            if (i == iz) av = a[i][u];
-          ZS[cg + TP_NCG * u] = av;
-        }
+            for (int u = 0; u < U; u++) ZS[cg + TP_NCG * u] = a[i][u];
+          }
       }
       TP_LDS_BARRIER();
       gu64 *zrow = xb + (size_t)(j1 & (TP_SLOTS - 1)) * slotw + ZOFF;
@@ -216,14 +216,12 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       // same wave, a few cache lines per wave -- and fetches the row again when that word has landed.  The words of z were
       // published a whole exchange earlier and fetched at the end of the previous pass (zb); they are re-read only in
       // the unlikely case that they had not landed then.
-      unsigned long long yb[EPT], dd = TP_SENT;
       const int kd = min(kf + tid, G - 1);  // clamped: surplus threads poll the last word again
       if constexpr (STAMPS) {
         if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 3] = wall_clock64();
       }
-#pragma unroll
-      for (int h = 0; h < EPT; h++) yb[h] = tp_load(sb + min(j1 + tid + TP_NT * h, n - 1));
-      dd = tp_load(sb + DOFF + kd);
+      // (the first attempt was issued at the end of the previous pass, behind the partial sums: its round trip, 0.45 us,
+      // runs under the scalars of this column, the register update and the row z)
       {
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
@@ -389,6 +387,10 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       red[2][wave] = ps;
     }
     TP_LDS_BARRIER();  // (4)
+    // first attempt at exchange j+1 (the workgroup every other one waits for finds its data there already)
+#pragma unroll
+    for (int h = 0; h < EPT; h++) yb[h] = tp_load(sb1 + min(j2 + tid + TP_NT * h, n - 1));
+    dd = tp_load(sb1 + DOFF + min(j2 / M + tid, G - 1));
     {
       c1 = tp_wsum(red[0][lane & (TP_NW - 1)]);
       c2 = tp_wsum(red[1][lane & (TP_NW - 1)]);
@@ -401,8 +403,12 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       } else {
         const double nrm = sqrt(alpha * alpha + xn2);
         beta = (alpha >= 0.0) ? -nrm : nrm;
-        tau = (beta - alpha) / beta;
-        scl = 1.0 / (alpha - beta);
+        // one division for both quotients: 1 / (beta (alpha - beta)); the product cannot overflow or vanish for matrices
+        // whose squared norms are representable (|beta| <= |alpha - beta| <= 2 |beta|)
+        const double amb = alpha - beta;
+        const double rq = 1.0 / (beta * amb);
+        tau = -amb * amb * rq;  // (beta - alpha) / beta
+        scl = beta * rq;        // 1 / (alpha - beta)
       }
     }
   }
