@@ -313,7 +313,7 @@ def main():
 
     fams = {}
     for name in ("coulomb", "xc", "scatter", "eig_reduce", "eig_tridiag", "eig_tridiag_solve", "eig_backtransform",
-                 "gemm", "eig_products", "density"):
+                 "gemm", "eig_products", "density", "k_trdp"):
         ms, n = ctx.profile_get(name)
         fams[name] = dict(ms_per_step=ms / args.steps, calls=n)
     ctx.profile(False)
@@ -330,9 +330,16 @@ def main():
     # events on the launch stream (3 repetitions, the last is kept)
     # (rank 0 only: it always owns symmetry block 0; ranks beyond the number of blocks never ran the factorisation)
     ctx_gemv = (0.0, 0)
+    trd_kernel = TRD_KERNEL
     if rank == 0:
-        for _ in range(3):
-            ctx_gemv = ctx.measure_kernel(TRD_KERNEL)
+        if fams["k_trdp"]["calls"] > 0:
+            # persistent tridiagonalisation: ONE cooperative launch per eigensolve, timed by HIP events around each of
+            # the launches of the timed region itself on the launch stream (nothing to replay: the kernel consumes its input)
+            trd_kernel = "k_trdp"
+            ctx_gemv = (fams["k_trdp"]["ms_per_step"] * args.steps, fams["k_trdp"]["calls"])
+        else:
+            for _ in range(3):
+                ctx_gemv = ctx.measure_kernel(TRD_KERNEL)
 
     if rank == 0:
         sizes = [len(b) for b in blocks]
@@ -342,7 +349,7 @@ def main():
         # column streams one triangle of the trailing matrix once, 4 (n-k)^2 B; summed over the columns of a
         # block that is (4/3) n^3 B.  Duration: HIP events around every launch on the launch stream.
         gemv_ms, gemv_launches = ctx_gemv
-        launches_per_step = float(gemv_launches)
+        launches_per_step = float(gemv_launches) / (args.steps if trd_kernel == "k_trdp" else 1.0)
         alg_bytes_step = sum(sum(4.0 * float(n - k - 1) ** 2 for k in range(n - 2)) for n in my_sizes)
         alg_bytes = alg_bytes_step / launches_per_step if launches_per_step else 0.0
         avg_ms = gemv_ms / gemv_launches if gemv_launches else 0.0
@@ -359,7 +366,7 @@ def main():
                 traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]
                 with open(traffic_file) as fh:
                     for kname, rec in json.load(fh).items():  # "void hfg::k_trdf<1024>" (template) or "hfg::k_trdb_gemv"
-                        if ("hfg::" + TRD_KERNEL) in kname:
+                        if ("hfg::" + trd_kernel) in kname:
                             traffic = rec.get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
@@ -384,9 +391,13 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": ("profiles/%s (committed rocprofv3 --pmc passes of this command, not "
                                             "measured in this run)" % os.path.basename(traffic_file)) if traffic is not None else None,
-                         "kernel": "hfg::" + TRD_KERNEL, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "hfg::" + trd_kernel, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_ms * 1e3, "launches_per_step": launches_per_step,
-                         "note": "latency-bound: one dependent launch per Householder column (see DESIGN.md 3.4)"},
+                         "note": ("one cooperative launch per eigensolve, the trailing matrices resident in the register file: "
+                                  "the algorithmic bytes (one triangle of the trailing matrix per Householder column, SURVEY 8d) "
+                                  "never cross HBM; bound by one exchange between workgroups per column (DESIGN.md 3.4)")
+                         if trd_kernel == "k_trdp" else
+                         "latency-bound: one dependent launch per Householder column (see DESIGN.md 3.4)"},
             "stages_ms": {k: round(v["ms_per_step"], 4) for k, v in fams.items()},
             # the other stages against their own bounds (stage time of this run, algorithmic work)
             "stage_rooflines": stage_rooflines(basis, w, my_sizes, fams),

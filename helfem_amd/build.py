@@ -18,7 +18,7 @@ OBJDIR = os.path.join(ROOT, "helfem_amd", "build")
 
 HOST_SRCS = ["host/fem.cpp", "host/special.cpp", "host/atomic_basis.cpp", "host/diatomic_basis.cpp", "host/scf.cpp", "host/diis.cpp", "host/checkpoint.cpp", "host/dftfuncs.cpp"]
 HIP_SRCS = ["hip/tables.cpp", "hip/capi.cpp", "hip/fock.hip", "hip/exchange.hip", "hip/exchange_lr.hip", "hip/gemm.hip", "hip/eig.hip", "hip/dc.hip", "hip/trd.hip", "hip/trdp.hip",
-            "hip/misc.hip", "hip/scf_gpu.cpp", "hip/scf_device.hip", "hip/tei_dev.hip", "hip/sb.hip"]
+            "hip/misc.hip", "hip/scf_gpu.cpp", "hip/scf_device.hip", "hip/tei_dev.hip"]
 
 
 # Kernel arguments preloaded into SGPRs at wave launch (gfx940+): every launch of the eigensolver's dependent chains
@@ -118,6 +118,22 @@ def build_adapter_test(verbose=True):
     return exe
 
 
+def build_probe(verbose=True):
+    """tests/gpu_probe/libtwostage_probe.so: the two-stage tridiagonalisation of round 2 (measured slower than the product
+    path, kept as a probe with its test), linked against the product library for the GEMM task lists"""
+    src = os.path.join(ROOT, "tests", "gpu_probe", "two_stage.hip")
+    out = os.path.join(ROOT, "tests", "gpu_probe", "libtwostage_probe.so")
+    lib = os.path.join(LIBDIR, "libhelfem_amd.so")
+    if _newer(src, out, tuple(_headers()) + (lib,)):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-result"] + EXTRA_FLAGS + [
+            src, "-o", out, "-L" + LIBDIR, "-lhelfem_amd", "-Wl,-rpath,$ORIGIN/../../helfem_amd/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_oracle(verbose=True):
     cmd = ["make", "-C", os.path.join(ROOT, "oracle"), "-j8"]
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
@@ -129,4 +145,5 @@ def build_oracle(verbose=True):
 
 if __name__ == "__main__":
     build_product(force="--force" in sys.argv)
+    build_probe()
     build_oracle()

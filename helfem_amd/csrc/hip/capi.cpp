@@ -17,14 +17,6 @@ void xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const d
                  double thr);
 void exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK, bool rs = false, const double *Lknown = nullptr,
                   int rknown = 0);
-void sb_reduce_to_band(hfg_ctx *ctx, int nblk, const int *ns, double *const *A);
-void sb_fetch_band(hfg_ctx *ctx, int blk, int n, double *hostAB);
-void sb_fetch_debug(hfg_ctx *ctx, int which, int n, double *host, size_t count);
-void sb_chase(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, double *const *e, int G, int delayed);
-int sb_chase_status(hfg_ctx *ctx);
-int sb_bandwidth();
-int sb_ldb();
-bool sb_supported(int nblk, const int *ns);
 void set_xc_params(hfg_ctx *ctx, int x_func, const double *x_pars, int nx, int c_func, const double *c_pars, int nc);
 void xc_fock_pol_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dPa, const double *dPb,
                      double *dHa, double *dHb, double *dScal, double thr);
@@ -601,108 +593,6 @@ int hfg_chk_read_diatomic_basis(hfg_chk *chk, int lpad, hfg_basis **out) {
     throw;
   }
   *out = b;
-  HFG_CATCH
-}
-
-// Diagnostic access to the first stage of the two-stage tridiagonalisation (hip/sb.hip): nrep copies of the symmetric
-// matrix A (n x n) are reduced to band form in one batch; AB receives the band storage of the first copy
-// (AB[j * ldb + d] = A_band[j + d][j]), ms the device time of the reduction.
-int hfg_debug_band_reduce(hfg_ctx *ctx, int64_t n, const double *A, int nrep, double *AB, int *bandwidth, int *ldb, double *ms) {
-  HFG_TRY
-  if (nrep < 1 || nrep > 8) throw std::logic_error("hfg_debug_band_reduce: 1..8 copies\n");
-  HFG_HIP_CHECK(hipSetDevice(ctx->device));
-  std::vector<int> ns(nrep, (int)n);
-  if (!sb_supported(nrep, ns.data())) throw std::logic_error("hfg_debug_band_reduce: size outside the kernels' range\n");
-  std::vector<DevBuf<double> > dA(nrep);
-  std::vector<double *> ptr(nrep);
-  for (int k = 0; k < nrep; k++) {
-    dA[k].resize((size_t)n * n + 2);
-    HFG_HIP_CHECK(hipMemcpy(dA[k].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
-    ptr[k] = dA[k].p;
-  }
-  sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());  // warm-up (buffers, task lists)
-  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < nrep; k++) HFG_HIP_CHECK(hipMemcpy(dA[k].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  HFG_HIP_CHECK(hipEventCreate(&e0));
-  HFG_HIP_CHECK(hipEventCreate(&e1));
-  HFG_HIP_CHECK(hipEventRecord(e0, ctx->stream));
-  sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());
-  HFG_HIP_CHECK(hipEventRecord(e1, ctx->stream));
-  HFG_HIP_CHECK(hipEventSynchronize(e1));
-  float t = 0.f;
-  HFG_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  if (ms) *ms = t;
-  if (bandwidth) *bandwidth = sb_bandwidth();
-  if (ldb) *ldb = sb_ldb();
-  if (AB) sb_fetch_band(ctx, 0, (int)n, AB);
-  HFG_CATCH
-}
-// both stages on nrep copies of A: d, e (n each) of copy 0, the times of the stages in ms (warm second run)
-int hfg_debug_two_stage(hfg_ctx *ctx, int64_t n, const double *A, int nrep, int G, int delayed, double *d, double *e, double *ms1, double *ms2) {
-  HFG_TRY
-  HFG_HIP_CHECK(hipSetDevice(ctx->device));
-  std::vector<int> ns(nrep, (int)n);
-  if (!sb_supported(nrep, ns.data())) throw std::logic_error("hfg_debug_two_stage: size outside the kernels' range\n");
-  std::vector<DevBuf<double>> dA(nrep), dd(nrep), de(nrep);
-  std::vector<double *> ptr(nrep), pd(nrep), pe(nrep);
-  for (int i = 0; i < nrep; i++) {
-    dA[i].resize((size_t)n * n + 2);
-    dd[i].resize(n);
-    de[i].resize(n);
-    ptr[i] = dA[i].p;
-    pd[i] = dd[i].p;
-    pe[i] = de[i].p;
-  }
-  hipEvent_t e0, e1, e2;
-  HFG_HIP_CHECK(hipEventCreate(&e0));
-  HFG_HIP_CHECK(hipEventCreate(&e1));
-  HFG_HIP_CHECK(hipEventCreate(&e2));
-  for (int rep = 0; rep < 2; rep++) {
-    for (int i = 0; i < nrep; i++) HFG_HIP_CHECK(hipMemcpy(dA[i].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
-    HFG_HIP_CHECK(hipEventRecord(e0, ctx->stream));
-    sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());
-    HFG_HIP_CHECK(hipEventRecord(e1, ctx->stream));
-    sb_chase(ctx, nrep, ns.data(), pd.data(), pe.data(), G, delayed);
-    HFG_HIP_CHECK(hipEventRecord(e2, ctx->stream));
-    HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (sb_chase_status(ctx) != 0) throw std::runtime_error("hfg_debug_two_stage: a bulge-chasing wave gave up waiting\n");
-  }
-  float t1 = 0, t2 = 0;
-  HFG_HIP_CHECK(hipEventElapsedTime(&t1, e0, e1));
-  HFG_HIP_CHECK(hipEventElapsedTime(&t2, e1, e2));
-  *ms1 = t1;
-  *ms2 = t2;
-  HFG_HIP_CHECK(hipMemcpy(d, dd[0].p, sizeof(double) * n, hipMemcpyDeviceToHost));
-  HFG_HIP_CHECK(hipMemcpy(e, de[0].p, sizeof(double) * n, hipMemcpyDeviceToHost));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipEventDestroy(e2);
-  HFG_CATCH
-}
-// work arrays of the last hfg_debug_band_reduce (which: 0 A after the reduction -- only meaningful with nrep = 1 and while
-// the call's buffers live, so this copies from the work area kept by the library --, 1 Vx, 2 T, 3 X, 4 [Y|V], 5 [V|U])
-int hfg_debug_band_fetch(hfg_ctx *ctx, int which, int64_t n, double *out, int64_t count) {
-  HFG_TRY
-  if (which == 0) throw std::logic_error("hfg_debug_band_fetch: the reduced matrix is returned by hfg_debug_band_reduce_keep\n");
-  sb_fetch_debug(ctx, which, (int)n, out, (size_t)count);
-  HFG_CATCH
-}
-// the same reduction on ONE copy, returning the whole reduced matrix (n x n) as the kernels left it
-int hfg_debug_band_reduce_keep(hfg_ctx *ctx, int64_t n, const double *A, double *Aout) {
-  HFG_TRY
-  HFG_HIP_CHECK(hipSetDevice(ctx->device));
-  int ns = (int)n;
-  if (!sb_supported(1, &ns)) throw std::logic_error("hfg_debug_band_reduce_keep: size outside the kernels' range\n");
-  DevBuf<double> dA;
-  dA.resize((size_t)n * n + 2);
-  HFG_HIP_CHECK(hipMemcpy(dA.p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
-  double *ptr = dA.p;
-  sb_reduce_to_band(ctx, 1, &ns, &ptr);
-  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  HFG_HIP_CHECK(hipMemcpy(Aout, dA.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
   HFG_CATCH
 }
 

@@ -601,7 +601,11 @@ bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, words * sizeof(unsigned long long), s));
   const TrdpDesc *dptr = w.desc.p;
   void *args[] = {(void *)&dptr};
-  hipError_t err = hipLaunchCooperativeKernel((const void *)kern, dim3(grid), dim3(TP_NT), args, 0, s);
+  hipError_t err;
+  {
+    ProfScope pk(ctx, "k_trdp");  // HIP events around this launch alone on the launch stream (bench.py: roofline)
+    err = hipLaunchCooperativeKernel((const void *)kern, dim3(grid), dim3(TP_NT), args, 0, s);
+  }
   if (err != hipSuccess) {
     (void)hipGetLastError();  // refused (grid not co-resident on this device): the chain runs instead
     static bool told = false;

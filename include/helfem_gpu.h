@@ -359,13 +359,6 @@ int hfg_chk_read_int(hfg_chk *chk, const char *name, int *v);
 /* Checkpoint::read(diatomic::basis::TwoDBasis &): a basis object from the stored constructor arguments */
 int hfg_chk_read_diatomic_basis(hfg_chk *chk, int lpad, hfg_basis **basis);
 
-/* Diagnostic: first stage of the two-stage tridiagonalisation alone (dense -> band, hip/sb.hip) on nrep copies of A;
- * AB (n x ldb, may be NULL) receives the band storage AB[j*ldb + d] = A_band[j+d][j] of the first copy. */
-int hfg_debug_band_reduce(hfg_ctx *ctx, int64_t n, const double *A, int nrep, double *AB, int *bandwidth, int *ldb, double *ms);
-int hfg_debug_two_stage(hfg_ctx *ctx, int64_t n, const double *A, int nrep, int G, int delayed, double *d, double *e, double *ms1, double *ms2);
-int hfg_debug_band_reduce_keep(hfg_ctx *ctx, int64_t n, const double *A, double *Aout);
-int hfg_debug_band_fetch(hfg_ctx *ctx, int which, int64_t n, double *out, int64_t count);
-
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled, every kernel family is bracketed by hipEvents on the context's stream; the
  * accumulated device time (ms) and launch count per family can be read back after a synchronize.

@@ -4,8 +4,8 @@
 // STATUS: both stages are correct (tests/test_gpu_twostage.py) and were MEASURED SLOWER than the one-stage chain of
 // trd.hip at the sizes of this path (3 x 1470: stage 1 11.2 ms, stage 2 23.7 ms against 12.1 ms; DESIGN.md section 7 has the
 // numbers and the reason -- a dependent step through device memory costs 3.5 us inside a kernel, 1.8 us as a kernel
-// boundary).  The product path does not call this file; it is reachable through hfg_debug_band_reduce /
-// hfg_debug_two_stage only and kept as the record of that measurement.  The back-transformation described below was
+// boundary).  The product path does not call this file; it is reachable through probe_band_reduce /
+// probe_two_stage (libtwostage_probe.so) only and kept as the record of that measurement.  The back-transformation described below was
 // therefore not written.
 //
 //   stage 1  dense -> band of half-width SB = 32: per panel of SB columns a Householder QR of the block below the band
@@ -18,8 +18,8 @@
 //   back-transformation  Z <- Q1 (Q2 Z):  Q2 (the SB-long reflectors of stage 2) applied sweep by sweep to column slabs
 //            of Z resident in LDS, Q1 through the compact-WY machinery of eig.hip.
 // tools/two_stage_model.py is the NumPy statement of the same algorithm with the same index conventions.
-#include "common.h"
-#include "wave.h"
+#include "../../helfem_amd/csrc/hip/common.h"
+#include "../../helfem_amd/csrc/hip/wave.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -780,3 +780,128 @@ int sb_bandwidth() { return SB; }
 int sb_ldb() { return SB_LDB; }
 
 }  // namespace hfg
+
+
+// -------------------------------------------------------------------------------------------------------------------
+// C entry points of this PROBE (tests/test_gpu_twostage.py, tools/sb_test.py, tools/sb_debug.py).  The two-stage
+// reduction is not part of the product: it was built and measured in round 2 (stage 2's critical path of 3 n dependent
+// tasks loses to the one-stage sweep at every order the product meets) and lives here, in a
+// library of its own (tests/gpu_probe/libtwostage_probe.so, linked against libhelfem_amd.so for the GEMM task lists).
+using namespace hfg;
+#define HFG_TRY try {
+#define HFG_CATCH                       \
+  }                                     \
+  catch (const std::exception &e) {     \
+    hfg::set_error(e.what());           \
+    return 2;                           \
+  }                                     \
+  return 0;
+extern "C" {
+// Diagnostic access to the first stage of the two-stage tridiagonalisation (this file): nrep copies of the symmetric
+// matrix A (n x n) are reduced to band form in one batch; AB receives the band storage of the first copy
+// (AB[j * ldb + d] = A_band[j + d][j]), ms the device time of the reduction.
+int probe_band_reduce(hfg_ctx *ctx, int64_t n, const double *A, int nrep, double *AB, int *bandwidth, int *ldb, double *ms) {
+  HFG_TRY
+  if (nrep < 1 || nrep > 8) throw std::logic_error("probe_band_reduce: 1..8 copies\n");
+  HFG_HIP_CHECK(hipSetDevice(ctx->device));
+  std::vector<int> ns(nrep, (int)n);
+  if (!sb_supported(nrep, ns.data())) throw std::logic_error("probe_band_reduce: size outside the kernels' range\n");
+  std::vector<DevBuf<double> > dA(nrep);
+  std::vector<double *> ptr(nrep);
+  for (int k = 0; k < nrep; k++) {
+    dA[k].resize((size_t)n * n + 2);
+    HFG_HIP_CHECK(hipMemcpy(dA[k].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
+    ptr[k] = dA[k].p;
+  }
+  sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());  // warm-up (buffers, task lists)
+  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < nrep; k++) HFG_HIP_CHECK(hipMemcpy(dA[k].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HFG_HIP_CHECK(hipEventCreate(&e0));
+  HFG_HIP_CHECK(hipEventCreate(&e1));
+  HFG_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+  sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());
+  HFG_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+  HFG_HIP_CHECK(hipEventSynchronize(e1));
+  float t = 0.f;
+  HFG_HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (ms) *ms = t;
+  if (bandwidth) *bandwidth = sb_bandwidth();
+  if (ldb) *ldb = sb_ldb();
+  if (AB) sb_fetch_band(ctx, 0, (int)n, AB);
+  HFG_CATCH
+}
+// both stages on nrep copies of A: d, e (n each) of copy 0, the times of the stages in ms (warm second run)
+int probe_two_stage(hfg_ctx *ctx, int64_t n, const double *A, int nrep, int G, int delayed, double *d, double *e, double *ms1, double *ms2) {
+  HFG_TRY
+  HFG_HIP_CHECK(hipSetDevice(ctx->device));
+  std::vector<int> ns(nrep, (int)n);
+  if (!sb_supported(nrep, ns.data())) throw std::logic_error("probe_two_stage: size outside the kernels' range\n");
+  std::vector<DevBuf<double>> dA(nrep), dd(nrep), de(nrep);
+  std::vector<double *> ptr(nrep), pd(nrep), pe(nrep);
+  for (int i = 0; i < nrep; i++) {
+    dA[i].resize((size_t)n * n + 2);
+    dd[i].resize(n);
+    de[i].resize(n);
+    ptr[i] = dA[i].p;
+    pd[i] = dd[i].p;
+    pe[i] = de[i].p;
+  }
+  hipEvent_t e0, e1, e2;
+  HFG_HIP_CHECK(hipEventCreate(&e0));
+  HFG_HIP_CHECK(hipEventCreate(&e1));
+  HFG_HIP_CHECK(hipEventCreate(&e2));
+  for (int rep = 0; rep < 2; rep++) {
+    for (int i = 0; i < nrep; i++) HFG_HIP_CHECK(hipMemcpy(dA[i].p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
+    HFG_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    sb_reduce_to_band(ctx, nrep, ns.data(), ptr.data());
+    HFG_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    sb_chase(ctx, nrep, ns.data(), pd.data(), pe.data(), G, delayed);
+    HFG_HIP_CHECK(hipEventRecord(e2, ctx->stream));
+    HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (sb_chase_status(ctx) != 0) throw std::runtime_error("probe_two_stage: a bulge-chasing wave gave up waiting\n");
+  }
+  float t1 = 0, t2 = 0;
+  HFG_HIP_CHECK(hipEventElapsedTime(&t1, e0, e1));
+  HFG_HIP_CHECK(hipEventElapsedTime(&t2, e1, e2));
+  *ms1 = t1;
+  *ms2 = t2;
+  HFG_HIP_CHECK(hipMemcpy(d, dd[0].p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HFG_HIP_CHECK(hipMemcpy(e, de[0].p, sizeof(double) * n, hipMemcpyDeviceToHost));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipEventDestroy(e2);
+  HFG_CATCH
+}
+// work arrays of the last probe_band_reduce (which: 0 A after the reduction -- only meaningful with nrep = 1 and while
+// the call's buffers live, so this copies from the work area kept by the library --, 1 Vx, 2 T, 3 X, 4 [Y|V], 5 [V|U])
+int probe_band_fetch(hfg_ctx *ctx, int which, int64_t n, double *out, int64_t count) {
+  HFG_TRY
+  if (which == 0) throw std::logic_error("probe_band_fetch: the reduced matrix is returned by probe_band_reduce_keep\n");
+  sb_fetch_debug(ctx, which, (int)n, out, (size_t)count);
+  HFG_CATCH
+}
+// the same reduction on ONE copy, returning the whole reduced matrix (n x n) as the kernels left it
+int probe_band_reduce_keep(hfg_ctx *ctx, int64_t n, const double *A, double *Aout) {
+  HFG_TRY
+  HFG_HIP_CHECK(hipSetDevice(ctx->device));
+  int ns = (int)n;
+  if (!sb_supported(1, &ns)) throw std::logic_error("probe_band_reduce_keep: size outside the kernels' range\n");
+  DevBuf<double> dA;
+  dA.resize((size_t)n * n + 2);
+  HFG_HIP_CHECK(hipMemcpy(dA.p, A, sizeof(double) * n * n, hipMemcpyHostToDevice));
+  double *ptr = dA.p;
+  sb_reduce_to_band(ctx, 1, &ns, &ptr);
+  HFG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  HFG_HIP_CHECK(hipMemcpy(Aout, dA.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+  HFG_CATCH
+}
+
+int probe_release(hfg_ctx *ctx) {
+  HFG_TRY
+  hfg::sb_release(ctx);
+  HFG_CATCH
+}
+}  // extern "C"

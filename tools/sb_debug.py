@@ -1,4 +1,4 @@
-"""Step-by-step comparison of stage 1 (hip/sb.hip) with tools/two_stage_model.py: run with HELFEM_SB_NPANEL=1 and
+"""Step-by-step comparison of stage 1 (tests/gpu_probe/two_stage.hip) with tools/two_stage_model.py: run with HELFEM_SB_NPANEL=1 and
 HELFEM_SB_STEP=1..4 in the environment."""
 import ctypes, os, sys
 import numpy as np
@@ -6,18 +6,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import helfem_amd as hf
 import two_stage_model as tm
-L = hf.lib(); ctx = hf.default_context()
+import ctypes as _ct
+from helfem_amd import build as _b
+L = _ct.CDLL(_b.build_probe(verbose=False)); ctx = hf.default_context()
 dp = ctypes.POINTER(ctypes.c_double)
-L.hfg_debug_band_reduce_keep.argtypes = [ctypes.c_void_p, ctypes.c_int64, dp, dp]
-L.hfg_debug_band_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, dp, ctypes.c_int64]
+L.probe_band_reduce_keep.argtypes = [ctypes.c_void_p, ctypes.c_int64, dp, dp]
+L.probe_band_fetch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, dp, ctypes.c_int64]
 n, b = 200, 32
 rng = np.random.RandomState(1)
 A0 = rng.standard_normal((n, n)); A0 = np.asfortranarray(A0 + A0.T)
 Aout = np.zeros((n, n), order="F")
-assert L.hfg_debug_band_reduce_keep(ctx.h, n, A0.ctypes.data_as(dp), Aout.ctypes.data_as(dp)) == 0, L.hfg_last_error()
+assert L.probe_band_reduce_keep(ctx.h, n, A0.ctypes.data_as(dp), Aout.ctypes.data_as(dp)) == 0, hf.lib().hfg_last_error()
 def fetch(which, count):
     out = np.zeros(count)
-    assert L.hfg_debug_band_fetch(ctx.h, which, n, out.ctypes.data_as(dp), count) == 0
+    assert L.probe_band_fetch(ctx.h, which, n, out.ctypes.data_as(dp), count) == 0
     return out
 Vx = fetch(1, n * n).reshape((n, n), order="F")
 T = fetch(2, 32 * 32).reshape((32, 32), order="F")

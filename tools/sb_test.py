@@ -8,19 +8,21 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import helfem_amd as hf
 
-L = hf.lib()
+import ctypes as _ct
+from helfem_amd import build as _b
+L = _ct.CDLL(_b.build_probe(verbose=False))  # tests/gpu_probe/libtwostage_probe.so
 ctx = hf.default_context()
 dp = ctypes.POINTER(ctypes.c_double)
-L.hfg_debug_band_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int64, dp, ctypes.c_int, dp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), dp]
+L.probe_band_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int64, dp, ctypes.c_int, dp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), dp]
 for n, nrep in ((200, 1), (333, 2), (1380, 1), (1470, 3), (1400, 3)):
     rng = np.random.RandomState(n)
     A = rng.standard_normal((n, n))
     A = np.asfortranarray(A + A.T)
     AB = np.zeros(n * 64)
     bw, ldb, ms = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
-    rc = L.hfg_debug_band_reduce(ctx.h, n, A.ctypes.data_as(dp), nrep, AB.ctypes.data_as(dp), ctypes.byref(bw), ctypes.byref(ldb), ctypes.byref(ms))
+    rc = L.probe_band_reduce(ctx.h, n, A.ctypes.data_as(dp), nrep, AB.ctypes.data_as(dp), ctypes.byref(bw), ctypes.byref(ldb), ctypes.byref(ms))
     if rc:
-        print("FAILED", n, L.hfg_last_error())
+        print("FAILED", n, hf.lib().hfg_last_error())
         continue
     b, ld = bw.value, ldb.value
     AB = AB.reshape(n, ld)
@@ -35,16 +37,16 @@ for n, nrep in ((200, 1), (333, 2), (1380, 1), (1470, 3), (1400, 3)):
 
 # both stages: eigenvalues of the tridiagonal matrix against the input's
 import scipy.linalg as sl
-L.hfg_debug_two_stage.argtypes = [ctypes.c_void_p, ctypes.c_int64, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp]
+L.probe_two_stage.argtypes = [ctypes.c_void_p, ctypes.c_int64, dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp]
 for n, nrep, G, delayed in ((200, 1, 4, 0), (333, 2, 8, 0), (1470, 3, 16, 0), (1470, 3, 16, 1), (1470, 3, 24, 0), (1400, 3, 12, 0)):
     rng = np.random.RandomState(n)
     A = rng.standard_normal((n, n))
     A = np.asfortranarray(A + A.T)
     d, e = np.zeros(n), np.zeros(n)
     m1, m2 = ctypes.c_double(), ctypes.c_double()
-    rc = L.hfg_debug_two_stage(ctx.h, n, A.ctypes.data_as(dp), nrep, G, delayed, d.ctypes.data_as(dp), e.ctypes.data_as(dp), ctypes.byref(m1), ctypes.byref(m2))
+    rc = L.probe_two_stage(ctx.h, n, A.ctypes.data_as(dp), nrep, G, delayed, d.ctypes.data_as(dp), e.ctypes.data_as(dp), ctypes.byref(m1), ctypes.byref(m2))
     if rc:
-        print("FAILED", n, L.hfg_last_error(), flush=True)
+        print("FAILED", n, hf.lib().hfg_last_error(), flush=True)
         break
     w0 = np.linalg.eigvalsh(A)
     w1 = sl.eigvalsh_tridiagonal(d, e[:-1])

@@ -1,4 +1,4 @@
-"""NumPy model of the two-stage tridiagonalisation in helfem_amd/csrc/hip/sb.hip (stage 1: dense -> band by panel
+"""NumPy model of the two-stage tridiagonalisation in tests/gpu_probe/two_stage.hip (stage 1: dense -> band by panel
 QR + compact-WY two-sided updates; stage 2: band -> tridiagonal by bulge chasing, one column per sweep) and of the two
 back-transformations.  Same index conventions and storage as the kernels; used to fix them before any GPU run and kept
 as the readable statement of the algorithm.  Also checks the wavefront schedule of stage 2: tasks (s, k) with equal
