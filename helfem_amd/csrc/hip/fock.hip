@@ -1206,6 +1206,11 @@ void xc_compact(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const do
   const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
   int do_grad = ((x_func > 0 && xc::is_gga(x_func)) || (c_func > 0 && xc::is_gga(c_func))) ? 1 : 0;
   int do_tau = ((x_func > 0 && xc::is_mgga(x_func)) || (c_func > 0 && xc::is_mgga(c_func))) ? 1 : 0;
+  // meta-GGAs: a floor under the density threshold.  Below 1e-50 the tau-dependent expressions overflow (tau_unif ~ n^(5/3),
+  // p ~ sigma / n^(8/3)) and return NaN where the point carries nothing; libxc keeps such points out with its own tau and
+  // sigma thresholds, --dftthr 0 would switch the density threshold off.  Far-field densities of an SCF density are
+  // rounding noise of the eigensolver at that level (tests/test_gpu_fullsize.py::test_fullsize_xc_without_density_threshold).
+  if (do_tau) thr = std::max(thr, 1e-40);
   a.D0.resize(NQ * AA);
   a.D1.resize(NQ * AA);
   a.GA.resize(NQ * AA);
@@ -1301,6 +1306,11 @@ void xc_compact_pol(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, cons
   const size_t NQ = (size_t)E * nq, AA = (size_t)A * A;
   int do_grad = ((x_func > 0 && xc::is_gga(x_func)) || (c_func > 0 && xc::is_gga(c_func))) ? 1 : 0;
   int do_tau = ((x_func > 0 && xc::is_mgga(x_func)) || (c_func > 0 && xc::is_mgga(c_func))) ? 1 : 0;
+  // meta-GGAs: a floor under the density threshold.  Below 1e-50 the tau-dependent expressions overflow (tau_unif ~ n^(5/3),
+  // p ~ sigma / n^(8/3)) and return NaN where the point carries nothing; libxc keeps such points out with its own tau and
+  // sigma thresholds, --dftthr 0 would switch the density threshold off.  Far-field densities of an SCF density are
+  // rounding noise of the eigensolver at that level (tests/test_gpu_fullsize.py::test_fullsize_xc_without_density_threshold).
+  if (do_tau) thr = std::max(thr, 1e-40);
   const int npl = do_tau ? 5 : 3;
   a.D0.resize(NQ * AA);
   a.D1.resize(NQ * AA);

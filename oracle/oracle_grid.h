@@ -138,6 +138,8 @@ struct DenseGrid {
   }
 
   void compute_xc(int x_func, int c_func, double thr) {
+    // meta-GGAs: floor under the density threshold, see hip/fock.hip xc_compact (tau-dependent terms overflow below 1e-50)
+    if ((x_func > 0 && xc_is_mgga(x_func)) || (c_func > 0 && xc_is_mgga(c_func))) thr = std::max(thr, 1e-40);
     const size_t nr = polarized ? 2 : 1, ns = polarized ? 3 : 1;
     exc.assign(Ng, 0.0);
     vxc.assign(nr * Ng, 0.0);
