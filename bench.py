@@ -28,6 +28,11 @@ WORKLOADS = {
     # BASELINE configs[4] sizing: LiF, lmmax=[29,29], 5 x 15 -> Nang 88, Nbf 6102; symmetry blocks 2100/2001/2001
     "lif_pbe_nbf6102": dict(Z1=3, Z2=9, Rbond=2.955, lmmax=[29, 29], nelem=5, nnodes=15, x=101, c=130, nocc=6),
     "n2_pbe_small": dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[6, 6], nelem=3, nnodes=8, x=101, c=130, nocc=7),
+    # exact-exchange kernel path (BASELINE configs[4]; the diatomic program has no range-separated exchange -- the reference
+    # refuses it too, main.cpp:393 -- so the global hybrid PBE0: J + 0.25 K + XC(hyb_gga_xc_pbeh) + eig, main.cpp:820-877)
+    "lif_pbe0_nbf6102": dict(Z1=3, Z2=9, Rbond=2.955, lmmax=[29, 29], nelem=5, nnodes=15, x=406, c=0, nocc=6, kfrac=0.25),
+    "n2_pbe0_nbf4230": dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[20, 20], nelem=5, nnodes=15, x=406, c=0, nocc=7, kfrac=0.25),
+    "n2_pbe0_small": dict(Z1=7, Z2=7, Rbond=2.068, lmmax=[6, 6], nelem=3, nnodes=8, x=406, c=0, nocc=7, kfrac=0.25),
 }
 
 
@@ -235,13 +240,45 @@ def cpu_baseline(w, bval, lval, mval, ldft, mdft, P, F, Sinvh, blocks):
         del Cb, Eb
     tE = time.time() - t0
     _progress("cpu_baseline: eigensolve %.2f s" % tE)
-    total = tJ + tXC + tE
+    # exact exchange (hybrid workloads): the oracle builds K output block by output block like the reference
+    # (basis.cpp:1575-1579, no OpenMP over blocks there either: scratch is allocated per block); a sample of blocks spread
+    # over the shell list, one per thread, scaled to the A^2 blocks
+    tK, ksample = 0.0, ""
+    if float(w.get("kfrac", 0.0)) != 0.0:
+        ob.compute_tei(True)
+        A = len(lval)
+        nks = max(1, min(cores, 16))
+        pairs = [((7 * q) % A, (11 * q + 3) % A) for q in range(nks)]
+        Ph = np.asfortranarray(0.5 * P)
+        kwork = list(pairs)
+
+        def kworker():
+            while True:
+                with lock:
+                    if not kwork:
+                        return
+                    jk = kwork.pop()
+                ob.exchange_blocks(Ph, [jk])
+
+        kth = [threading.Thread(target=kworker) for _ in range(nks)]
+        t0 = time.time()
+        for t in kth:
+            t.start()
+        for t in kth:
+            t.join()
+        tK_sample = time.time() - t0
+        tK = tK_sample * (A * A) / float(len(pairs))
+        ksample = ("; exchange: oracle, %d of %d output blocks (jang, kang) on %d threads (%.2f s wall, scaled x%.1f)"
+                   % (len(pairs), A * A, nks, tK_sample, A * A / float(len(pairs))))
+        _progress("cpu_baseline: exchange sample %.2f s for %d blocks" % (tK_sample, len(pairs)))
+    total = tJ + tXC + tE + tK
     return dict(value=total * 1e3, unit="ms", cores=cores, kind="port+lapack", cpu=cpu_model,
-                parts_ms=dict(coulomb=tJ * 1e3, xc=tXC * 1e3, eig=tE * 1e3),
+                parts_ms=dict(coulomb=tJ * 1e3, xc=tXC * 1e3, eig=tE * 1e3, exchange=tK * 1e3),
+                threads=dict(coulomb=1, xc=nth, eig=cores, exchange=(min(cores, 16) if tK else 0)),
                 sample="Coulomb: oracle, full build, 1 thread as the reference (%.2f s); XC: oracle, %d of %d radial points spread "
                        "over the %d elements on %d threads (%.2f s wall, scaled x%.1f); eigensolve: all blocks %s with "
-                       "LAPACK dsyevd + 3 GEMMs (torch CPU, MKL, %d threads, %.2f s)"
-                       % (tJ, len(pts), NQ, w["nelem"], nth, tXC_sample, NQ / float(len(pts)), sizes, cores, tE))
+                       "LAPACK dsyevd + 3 GEMMs (torch CPU, MKL, %d threads, %.2f s)%s"
+                       % (tJ, len(pts), NQ, w["nelem"], nth, tXC_sample, NQ / float(len(pts)), sizes, cores, tE, ksample))
 
 
 def main():
@@ -267,13 +304,17 @@ def main():
 
     w = WORKLOADS[args.workload]
     basis, bval, lval, mval, ldft, mdft = build_basis(hf, w)
-    basis.compute_tei(False)
+    kfrac = float(w.get("kfrac", 0.0))
     N = basis.Nbf()
     # one rank per GPU; HELFEM_BENCH_DEVICE pins every rank to one device (rehearsal of the N>1 path on a 1-GPU box
     # together with HELFEM_DIST_BACKEND=gloo)
     dev_index = int(os.environ.get("HELFEM_BENCH_DEVICE", local_rank))
+    if kfrac == 0.0:
+        basis.compute_tei(False)
+    # hybrid workloads: the in-element tables and their exchange-ordered copies are built on the device (the 2-3 GB never
+    # exist on the host)
     step = hf.DeviceSCFStep(basis, w["x"], w["c"], ldft, mdft, w["nocc"], symmetry=args.symmetry, device=dev_index, rank=rank,
-                            nranks=world)
+                            nranks=world, kfrac=kfrac, device_tei=(kfrac != 0.0))
     ctx = step.ctx
     S = basis.overlap()
     H0 = basis.kinetic() + basis.nuclear()
@@ -293,11 +334,12 @@ def main():
         step.step(allred, xblocks)
         step.P.mul_(2.0)  # closed shell: P = Pa + Pb
 
-    step.set_density(P0)
+    C_guess = C0 if args.density == "core" else None
+    step.set_density(P0, C_guess)
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    step.set_density(P0)
+    step.set_density(P0, C_guess)
     ctx.profile(True)
     ctx.profile_reset()
     parallel.barrier()
@@ -313,13 +355,13 @@ def main():
 
     fams = {}
     for name in ("coulomb", "xc", "scatter", "eig_reduce", "eig_tridiag", "eig_tridiag_solve", "eig_backtransform",
-                 "gemm", "eig_products", "density", "k_trdp"):
+                 "gemm", "eig_products", "density", "k_trdp", "exchange", "exl_element_gemm", "exl_element_gemm_gflop"):
         ms, n = ctx.profile_get(name)
         fams[name] = dict(ms_per_step=ms / args.steps, calls=n)
     ctx.profile(False)
     # self-check of the timed path, independent of the number of ranks: ONE step from the fixed guess density
     # (the undamped iteration itself is chaotic from a core guess, its later iterates are not comparable)
-    step.set_density(P0)
+    step.set_density(P0, C_guess)
     one_step()
     torch.cuda.synchronize()
     check = {"sum_lowest_eigenvalues_after_one_step": float(step.E[:w["nocc"]].sum().item()),
@@ -376,11 +418,13 @@ def main():
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "diatomic Z1=%d Z2=%d R=%.3f PBE, nelem=%d nnodes=%d nquad=%d lmmax=%s (Nbf=%d, "
-                                   "Nang=%d, Nrad=%d), XC grid %dx%d, symmetry blocks %s: J+XC Fock build + "
+            "config": {"workload": "diatomic Z1=%d Z2=%d R=%.3f %s, nelem=%d nnodes=%d nquad=%d lmmax=%s (Nbf=%d, "
+                                   "Nang=%d, Nrad=%d), XC grid %dx%d, symmetry blocks %s: %s Fock build + "
                                    "eig_gsym_sub + density per step" % (
-                                       w["Z1"], w["Z2"], w["Rbond"], w["nelem"], w["nnodes"], 5 * w["nnodes"],
-                                       str(w["lmmax"]).replace(" ", ""), N, basis.Nang(), basis.Nrad(), ldft, mdft, sizes),
+                                       w["Z1"], w["Z2"], w["Rbond"], "PBE0 (hyb_gga_xc_pbeh, 0.25 exact exchange)" if kfrac else "PBE",
+                                       w["nelem"], w["nnodes"], 5 * w["nnodes"],
+                                       str(w["lmmax"]).replace(" ", ""), N, basis.Nang(), basis.Nrad(), ldft, mdft, sizes,
+                                       "J + 0.25 K + XC" if kfrac else "J+XC"),
                        "name": args.workload, "parallelism": "shard%d" % world,
                        "density": "occupied orbitals of the core Hamiltonian" if args.density == "core"
                        else "seeded std::mt19937_64(20260130) block-diagonal orbitals (BASELINE.md section 2)",
@@ -404,6 +448,36 @@ def main():
             # size-independent self-check of the timed path: must not depend on the number of ranks
             "check": check,
         }
+        if kfrac != 0.0 and fams["exl_element_gemm"]["calls"] > 0:
+            # exact-exchange workloads: the dominant kernel of the exchange build is the in-element task-list GEMM
+            # (k_dgemm_tasklist_wl: C[p^2 x pairs] = ktei[p^2 x 4 p^2] RB[4 p^2 x pairs] per table slot and element).
+            # achieved = USEFUL flops (no tile padding) / HIP-event time of its launches in the timed region.
+            g_ms = fams["exl_element_gemm"]["ms_per_step"] * args.steps
+            g_n = fams["exl_element_gemm"]["calls"]
+            g_gflop = fams["exl_element_gemm_gflop"]["ms_per_step"] * args.steps  # accumulated GFLOP (see exchange_lr.hip)
+            tf = g_gflop / g_ms if g_ms > 0 else 0.0  # GFLOP / ms = TFLOP/s
+            ktraffic, ktraffic_file = None, None
+            try:
+                import glob
+                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_exchange_pmc_traffic_%s.json" % args.workload)))
+                if cand:
+                    ktraffic_file = cand[-1]
+                    with open(ktraffic_file) as fh:
+                        for kname, rec in json.load(fh).items():
+                            if "k_dgemm_tasklist_wl" in kname:
+                                ktraffic = rec.get("traffic_bytes_per_launch")
+            except Exception:
+                ktraffic = None
+            out["roofline_tridiagonalisation"] = out["roofline"]
+            out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                               "traffic": ktraffic,
+                               "traffic_source": ("profiles/%s (committed rocprofv3 --pmc passes, tools/exchange_pmc.sh; not measured "
+                                                  "in this run)" % os.path.basename(ktraffic_file)) if ktraffic is not None else None,
+                               "kernel": "hfg::k_dgemm_tasklist_wl (in-element GEMM of the exchange build)",
+                               "useful_gflop_per_launch": g_gflop / g_n if g_n else 0.0, "avg_launch_us": g_ms / g_n * 1e3 if g_n else 0.0,
+                               "launches_per_step": g_n / float(args.steps),
+                               "note": "FP64 MFMA (v_mfma_f64_16x16x4_f64); peak 78.6 TFLOP/s is AMD's data-sheet figure, "
+                                       "reproduced at 77 TFLOP/s by tests/gpu_probe/fp64_rate.hip"}
         if not args.no_cpu_baseline and world == 1:
             P = step.numpy(step.P, (N, N))
             F = step.numpy(step.F, (N, N))

@@ -690,7 +690,7 @@ class DeviceSCFStep(object):
     """
 
     def __init__(self, basis, x_func, c_func, ldft, mdft, nocc, symmetry=1, device=0, rank=0, nranks=1,
-                 dens_thr=1e-12):
+                 dens_thr=1e-12, kfrac=0.0, device_tei=False):
         import torch
         self.torch = torch
         self.basis = basis
@@ -699,6 +699,8 @@ class DeviceSCFStep(object):
         torch.cuda.set_device(self.dev)
         self.ctx = Context(device, stream=torch.cuda.current_stream(self.dev).cuda_stream)
         self.ctx.set_shard(rank, nranks)
+        if device_tei:  # in-element tables (with the exchange-ordered ones when K is wanted) built on this context's device
+            basis.compute_tei(float(kfrac) != 0.0, device=True, ctx=self.ctx)
         basis.upload(ldft, mdft, ctx=self.ctx)
         L = lib()
         L.hfg_fock_compact_size.restype = ctypes.c_int64
@@ -724,6 +726,15 @@ class DeviceSCFStep(object):
         self.blockbuf = torch.zeros(nb, **f64)
         self.H0 = None
         self.Sinvh = None
+        # hybrid functionals: F += kfrac K[Pa] (main.cpp:820-877); K is dense, its shards (output shells j % n == rank) sum
+        self.kfrac = float(kfrac)
+        self.have_C = False
+        if self.kfrac != 0.0:
+            self.K = torch.zeros(N * N, **f64)
+            self.Pa = torch.zeros(N * N, **f64)
+            L.hfg_exchange_occ_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_void_p]
+            L.hfg_exchange_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 
     def _ptr(self, t):
         return ctypes.c_void_p(t.data_ptr())
@@ -735,8 +746,22 @@ class DeviceSCFStep(object):
         self.Sinvh = t.from_numpy(np.asfortranarray(Sinvh).ravel(order="F").copy()).to(self.dev)
         self.ctx.fix_sinvh(self.Sinvh.data_ptr())  # constant until the next set_matrices
 
-    def set_density(self, P):
+    def set_density(self, P, C=None):
+        """total density P = 2 C_occ C_occ^T; C (N x >= nocc, optional): the orbitals it was formed from, which the exact
+        exchange takes as the factors of P/2 (as inside the SCF loop, where the driver has just formed P from them)"""
         self.P.copy_(self.torch.from_numpy(np.asfortranarray(P).ravel(order="F").copy()))
+        self.have_C = C is not None
+        if C is not None:
+            self.C[:self.N * self.nocc].copy_(self.torch.from_numpy(np.asfortranarray(C[:, :self.nocc]).ravel(order="F").copy()))
+
+    def exchange(self):
+        """K[Pa], Pa = P/2 (closed shell; basis.exchange(Pa) of main.cpp:822) into self.K"""
+        self.torch.mul(self.P, 0.5, out=self.Pa)
+        if self.have_C:
+            _check(lib().hfg_exchange_occ_dev(self.ctx.h, self.basis.h, self._ptr(self.Pa), self._ptr(self.C),
+                                              ctypes.c_int64(self.nocc), self._ptr(self.K)))
+        else:
+            _check(lib().hfg_exchange_dev(self.ctx.h, self.basis.h, self._ptr(self.Pa), self._ptr(self.K)))
 
     def fock_partial(self):
         _check(lib().hfg_fock_compact_dev(self.ctx.h, self.basis.h, self.x_func, self.c_func, self._ptr(self.P),
@@ -770,6 +795,11 @@ class DeviceSCFStep(object):
             allreduce(self.Fc)
             allreduce(self.scal)
         self.fock_finish()
+        if self.kfrac != 0.0:
+            self.exchange()
+            if allreduce is not None:
+                allreduce(self.K)
+            self.F.add_(self.K, alpha=self.kfrac)  # K of a block-diagonal density is block diagonal: no mask needed
         self.eig_partial()
         if exchange_blocks is not None:
             exchange_blocks(self.blockbuf, len(self.blocks))
@@ -777,6 +807,7 @@ class DeviceSCFStep(object):
             allreduce(self.blockbuf)
         self.eig_finish()
         self.density()
+        self.have_C = True  # self.C now holds the orbitals self.P was formed from
 
     def numpy(self, t, shape):
         return t.cpu().numpy().reshape(shape, order="F")

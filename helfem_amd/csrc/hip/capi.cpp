@@ -669,6 +669,12 @@ int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, double *dK) {
   HFG_TRY exchange_dev(ctx, b, dP, dK);
   HFG_CATCH
 }
+int hfg_exchange_occ_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, const double *dC, int64_t nocc, double *dK) {
+  HFG_TRY
+  if (nocc < 1 || !dC) throw std::logic_error("hfg_exchange_occ_dev: occupied orbitals missing\n");
+  exchange_dev(ctx, b, dP, dK, false, dC, (int)nocc);
+  HFG_CATCH
+}
 int hfg_rs_exchange_dev(hfg_ctx *ctx, hfg_basis *b, const double *dP, double *dK) {
   HFG_TRY exchange_dev(ctx, b, dP, dK, true);
   HFG_CATCH

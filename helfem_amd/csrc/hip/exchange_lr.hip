@@ -1433,6 +1433,15 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     for (const GemmTask &q : tasks) ncols_tot += (double)q.N;
     const bool rect_tiles = rect_env >= 0 ? rect_env != 0 : (ncols_tot < 1500.0 * (double)tasks.size());
     static const bool wl_off = getenv("HELFEM_EXL_WL") && atoi(getenv("HELFEM_EXL_WL")) == 0;  // checker: plain task-list grid
+    // bench.py: HIP events around this launch alone ("exl_element_gemm") and its USEFUL work in GFLOP, 2 p^2 pairs (ntt p^2)
+    // per task without any padding, accumulated in the `ms` field of "exl_element_gemm_gflop"
+    ProfScope pgemm(ctx, "exl_element_gemm");
+    if (ctx->profiling) {
+      double gf = 0.0;
+      for (const GemmTask &q : tasks) gf += 2.0 * (double)pp * (double)q.N * (double)Kt * 1e-9;
+      ctx->prof["exl_element_gemm_gflop"].ms += gf;
+      ctx->prof["exl_element_gemm_gflop"].launches += 1;
+    }
     if (!wl_off) {
       // all tiles of a task on one XCD (its element table is then fetched from HBM once, not by all eight L2s)
       const int BNt = rect_tiles ? 64 : 128;

@@ -225,6 +225,10 @@ int hfg_gemm(hfg_ctx *ctx, int transA, int transB, int64_t m, int64_t n, int64_t
 int hfg_coulomb_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dJ);
 int hfg_exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
 int hfg_rs_exchange_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, double *dK);
+/* TwoDBasis::exchange(Pa) as the SCF driver calls it (src/diatomic/main.cpp:822, src/atomic/main.cpp:767): the caller has
+ * just formed dP = C_occ C_occ^T with scf::form_density from the nocc occupied orbitals dC (N x nocc, column-major, ld N)
+ * and hands them over as the factors of dP, which saves the pivoted factorisation of dP and its verification. */
+int hfg_exchange_occ_dev(hfg_ctx *ctx, hfg_basis *basis, const double *dP, const double *dC, int64_t nocc, double *dK);
 /* dScal: 3 doubles in HBM receiving Exc, Nel, Ekin */
 int hfg_xc_fock_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, const double *dP, double *dH,
                     double *dScal, double dens_thr);
