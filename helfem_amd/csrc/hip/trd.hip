@@ -29,8 +29,8 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
-bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
-                               double *const *tau);  // trdp.hip
+void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
+                               double *const *tau, std::vector<char> &done);  // trdp.hip
 
 constexpr int TB_MAXB = 8;
 constexpr int TB_NB = 16;   // panel width (measured: 16 beats 8 and 32 at n ~ 1400 x 3 blocks; 32 again after the DPP work: 11.7 vs 7.6 us per column)
@@ -1184,16 +1184,43 @@ void trd_release(hfg_ctx *ctx) {
   }
 }
 
+static thread_local bool g_in_chain_fallback = false;  // the chain below is running on what the persistent path left
 /// A[blk] (n x n, ld n, full symmetric storage) -> d, e, tau and the Householder vectors below the subdiagonal
 void tridiagonalize_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
                           double *const *tau) {
   if (nblk > TB_MAXB) throw std::logic_error("tridiagonalize_batch: too many blocks");
   // one cooperative launch with the matrices resident in the register file when the batch fits the chip (trdp.hip);
   // the chain of launches below otherwise
-  if (tridiagonalize_persistent(ctx, nblk, ns, A, d, e, tau)) {
-    auto itp = g_trd.find(ctx);
-    if (itp != g_trd.end()) itp->second->last_ns.clear();
-    return;
+  if (!g_in_chain_fallback) {
+    std::vector<char> done;
+    tridiagonalize_persistent(ctx, nblk, ns, A, d, e, tau, done);
+    int ndone = 0;
+    for (char c : done) ndone += c ? 1 : 0;
+    if (ndone > 0) {
+      auto itp = g_trd.find(ctx);
+      if (itp != g_trd.end()) itp->second->last_ns.clear();
+      if (ndone == nblk) return;
+      // the matrices the persistent path left (order beyond its register tiles, a refused launch) go through the chain
+      std::vector<int> ns2;
+      std::vector<double *> A2, d2, e2, t2;
+      for (int i = 0; i < nblk; i++)
+        if (!done[i]) {
+          ns2.push_back(ns[i]);
+          A2.push_back(A[i]);
+          d2.push_back(d[i]);
+          e2.push_back(e[i]);
+          t2.push_back(tau[i]);
+        }
+      g_in_chain_fallback = true;
+      try {
+        tridiagonalize_batch(ctx, (int)ns2.size(), ns2.data(), A2.data(), d2.data(), e2.data(), t2.data());
+      } catch (...) {
+        g_in_chain_fallback = false;
+        throw;
+      }
+      g_in_chain_fallback = false;
+      return;
+    }
   }
   TrdWork *wp;
   auto it = g_trd.find(ctx);

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 namespace hfg {
@@ -462,8 +463,12 @@ void trdp_check_status(hfg_ctx *ctx) {
   if (it == g_trdp.end() || !it->second->pending) return;
   TrdpWork &w = *it->second;
   w.pending = false;
-  if (*w.h_status == 1)
-    throw std::runtime_error("persistent tridiagonalisation: an exchange between workgroups ran into its time limit");
+  bool bad = false;
+  for (int q = 0; q < 16; q++) {
+    bad = bad || w.h_status[q] == 1;
+    w.h_status[q] = -1;
+  }
+  if (bad) throw std::runtime_error("persistent tridiagonalisation: an exchange between workgroups ran into its time limit");
   // HELFEM_TRDP_STAMPS=1 (measurement builds of the kernel): phase durations of the last launch, printed once per launch
   if (w.stamps.p && !w.last_ns.empty()) {
     const int n0 = w.last_ns[0];
@@ -508,28 +513,32 @@ static trdp_kernel_t trdp_pick(int R, int U, bool stamps) {
   if (R == r && U == u) return stamps ? trdp_kernel<r, u, true>() : trdp_kernel<r, u, false>();
   TP_CASE(1, 6) TP_CASE(2, 6) TP_CASE(3, 6) TP_CASE(4, 6) TP_CASE(6, 6)
   TP_CASE(2, 12) TP_CASE(3, 12) TP_CASE(4, 12) TP_CASE(5, 12) TP_CASE(6, 12)
+  TP_CASE(2, 17) TP_CASE(3, 17) TP_CASE(4, 17)
 #undef TP_CASE
   return nullptr;
 }
 static const int tp_rows_choices[] = {1, 2, 3, 4, 5, 6};
+/// column chunks per thread for matrices up to this order (0: beyond the register tiles)
+static int tp_columns_for(int nmax) {
+  if (nmax <= 6 * TP_NCG) return 6;
+  if (nmax <= 12 * TP_NCG) return 12;
+  if (nmax <= 17 * TP_NCG) return 17;
+  return 0;
+}
 
-/// Persistent path of tridiagonalize_batch: returns false (nothing launched, nothing touched) when the batch does not
-/// fit -- order beyond the register tiles, more workgroups than CUs, the runtime refusing the cooperative launch -- or
-/// when HELFEM_TRD selects another variant.  Same outputs as the chain: d, e, tau, reflectors below the subdiagonal.
-bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
-                               double *const *tau) {
+/// Persistent path of tridiagonalize_batch.  The matrices are dealt into GROUPS that each fit the chip's register file
+/// (one cooperative launch per group, one after the other on the stream: the three blocks 1380/1470/1380 of the bench
+/// workload are one group, the blocks 2100/2001/2001 of the LiF sizing two -- {2100} and {2001, 2001}).  done[i] says
+/// which matrices were factorised; the caller runs its chain of launches on the others (order beyond the register
+/// tiles, the runtime refusing a cooperative launch, HELFEM_TRD selecting another variant: nothing is touched then).
+/// Same outputs as the chain: d, e, tau, reflectors below the subdiagonal.
+void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
+                               double *const *tau, std::vector<char> &done) {
+  done.assign(nblk, 0);
   static const char *mode = getenv("HELFEM_TRD");
-  if (mode && strcmp(mode, "persistent") != 0) return false;
-  if (nblk < 1 || nblk > TP_MAXB) return false;
-  int nmax = 0, nmin = 1 << 30;
-  for (int i = 0; i < nblk; i++) {
-    nmax = std::max(nmax, ns[i]);
-    nmin = std::min(nmin, ns[i]);
-  }
+  if (mode && strcmp(mode, "persistent") != 0) return;
+  if (nblk < 1 || nblk > TP_MAXB) return;
   static const int min_order = getenv("HELFEM_TRDP_MIN") ? atoi(getenv("HELFEM_TRDP_MIN")) : 256;
-  if (nmin < 3 || nmax < min_order) return false;
-  const int U = nmax <= 6 * TP_NCG ? 6 : (nmax <= 12 * TP_NCG ? 12 : 0);
-  if (U == 0) return false;
   TrdpWork *wp;
   auto it = g_trdp.find(ctx);
   if (it == g_trdp.end()) {
@@ -537,92 +546,152 @@ bool tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     g_trdp[ctx] = wp;
     HFG_HIP_CHECK(hipDeviceGetAttribute(&wp->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
     HFG_HIP_CHECK(hipHostMalloc((void **)&wp->h_status, 64, hipHostMallocDefault));
-    *wp->h_status = -1;
+    for (int i = 0; i < 16; i++) wp->h_status[i] = -1;
   } else
     wp = it->second;
   TrdpWork &w = *wp;
   if (w.pending) {
-    // the previous launch's status was copied back on this stream; by now that copy has long completed in any loop
-    // that consumed the eigenvalues, but it is only READ here when the event says so
+    // the previous launches' status words were copied back on this stream; they are only READ when the stream says so
     if (hipStreamQuery(ctx->stream) == hipSuccess) trdp_check_status(ctx);
   }
   static const int forceR = getenv("HELFEM_TRDP_R") ? atoi(getenv("HELFEM_TRDP_R")) : 0;
-  int R = 0, grid = 0;
-  for (int r : tp_rows_choices) {
-    if (forceR && r != forceR) continue;
-    if (!trdp_pick(r, U, false)) continue;
-    int g = 0;
-    for (int i = 0; i < nblk; i++) g += (ns[i] + TP_NRG * r - 1) / (TP_NRG * r);
-    if (g <= w.ncu) {
-      R = r;
-      grid = g;
-      break;
-    }
-  }
-  if (R == 0) return false;
   static const bool want_stamps = getenv("HELFEM_TRDP_STAMPS") && atoi(getenv("HELFEM_TRDP_STAMPS")) != 0;
-  trdp_kernel_t kern = trdp_pick(R, U, want_stamps);
-  if (!kern) return false;
-  const int M = TP_NRG * R, NP = TP_NCG * U;
-  TrdpDesc D{};
-  D.nblk = nblk;
-  size_t words = 16;
-  std::vector<size_t> off(nblk);
-  int wg = 0;
-  for (int i = 0; i < nblk; i++) {
-    const int G = (ns[i] + M - 1) / M;
-    D.wg0[i] = wg;
-    wg += G;
-    D.n[i] = ns[i];
-    D.G[i] = G;
-    D.A[i] = A[i];
-    D.d[i] = d[i];
-    D.e[i] = e[i];
-    D.tau[i] = tau[i];
-    off[i] = words;
-    words += (size_t)TP_SLOTS * ((size_t)2 * NP + 64 + TP_MAXG);
-    if (G > TP_MAXG) return false;  // the landing area of the dot words
-  }
-  for (int i = nblk; i <= TP_MAXB; i++) D.wg0[i] = wg;
-  words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
-  w.ring.resize(words);
-  for (int i = 0; i < nblk; i++) D.xb[i] = w.ring.p + off[i];
-  D.status = (int *)w.ring.p;
-  D.stamps = nullptr;
-  if (want_stamps) {
-    w.stamps.resize((size_t)8 * (nmax + 2));
-    HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, (size_t)8 * (nmax + 2) * 8, ctx->stream));
-    D.stamps = w.stamps.p;
-  }
-  static const long long limit_ms = getenv("HELFEM_TRDP_LIMIT_MS") ? atoll(getenv("HELFEM_TRDP_LIMIT_MS")) : 200;
-  D.spin_limit = limit_ms * 100000ll;  // 100 MHz wall clock
-  hipStream_t s = ctx->stream;
-  upload_cached(w.desc, w.h_desc, std::vector<TrdpDesc>(1, D), s);
-  HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, words * sizeof(unsigned long long), s));
-  const TrdpDesc *dptr = w.desc.p;
-  void *args[] = {(void *)&dptr};
-  hipError_t err;
-  {
-    ProfScope pk(ctx, "k_trdp");  // HIP events around this launch alone on the launch stream (bench.py: roofline)
-    err = hipLaunchCooperativeKernel((const void *)kern, dim3(grid), dim3(TP_NT), args, 0, s);
-  }
-  if (err != hipSuccess) {
-    (void)hipGetLastError();  // refused (grid not co-resident on this device): the chain runs instead
-    static bool told = false;
-    if (!told) {
-      fprintf(stderr, "helfem_amd: cooperative launch of the persistent tridiagonalisation refused (%s): grid %d; using the launch chain\n",
-              hipGetErrorString(err), grid);
-      told = true;
+  // ---- plan: largest matrices first; a matrix joins the current group while the group still fits ----
+  struct Group {
+    std::vector<int> idx;
+    int R = 0, U = 0, grid = 0;
+  };
+  auto fit = [&](const std::vector<int> &idx, Group &g) -> bool {
+    int nmax = 0;
+    for (int i : idx) nmax = std::max(nmax, ns[i]);
+    const int U = tp_columns_for(nmax);
+    if (U == 0) return false;
+    for (int r : tp_rows_choices) {
+      if (forceR && r != forceR) continue;
+      if (!trdp_pick(r, U, false)) continue;
+      int grid = 0;
+      bool ok = true;
+      for (int i : idx) {
+        const int G = (ns[i] + TP_NRG * r - 1) / (TP_NRG * r);
+        ok = ok && G <= TP_MAXG;
+        grid += G;
+      }
+      if (ok && grid <= w.ncu) {
+        g.idx = idx;
+        g.R = r;
+        g.U = U;
+        g.grid = grid;
+        return true;
+      }
     }
     return false;
+  };
+  std::vector<int> order;
+  for (int i = 0; i < nblk; i++)
+    if (ns[i] >= 3 && ns[i] >= min_order) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ns[x] > ns[y]; });
+  std::vector<Group> groups;
+  {
+    std::vector<int> cur;
+    Group g;
+    for (int i : order) {
+      std::vector<int> trial = cur;
+      trial.push_back(i);
+      Group t;
+      if (fit(trial, t)) {
+        cur = trial;
+        g = t;
+      } else {
+        if (!cur.empty()) groups.push_back(g);
+        cur.clear();
+        Group one;
+        if (fit(std::vector<int>(1, i), one)) {
+          cur.assign(1, i);
+          g = one;
+        }  // else: this matrix stays with the chain
+      }
+    }
+    if (!cur.empty()) groups.push_back(g);
   }
-  HFG_HIP_CHECK(hipMemcpyAsync(w.h_status, w.ring.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  w.pending = true;
-  w.last_ns.assign(ns, ns + nblk);
-  w.last_R = R;
-  w.last_U = U;
-  w.last_grid = grid;
-  return true;
+  if (groups.empty()) return;
+  // ---- descriptors of all groups (identical from one SCF iteration to the next: uploaded once) ----
+  size_t ring_words = 0;
+  std::vector<TrdpDesc> descs(groups.size());
+  std::vector<size_t> ring_of(groups.size());
+  int nmax_all = 0;
+  for (size_t q = 0; q < groups.size(); q++) {
+    const Group &g = groups[q];
+    const int M = TP_NRG * g.R, NP = TP_NCG * g.U;
+    TrdpDesc &D = descs[q];
+    D = TrdpDesc{};
+    D.nblk = (int)g.idx.size();
+    size_t words = 16;
+    int wg = 0;
+    for (int b = 0; b < D.nblk; b++) {
+      const int i = g.idx[b];
+      const int G = (ns[i] + M - 1) / M;
+      D.wg0[b] = wg;
+      wg += G;
+      D.n[b] = ns[i];
+      D.G[b] = G;
+      D.A[b] = A[i];
+      D.d[b] = d[i];
+      D.e[b] = e[i];
+      D.tau[b] = tau[i];
+      D.xb[b] = (unsigned long long *)words;  // offset for now, the base is added below
+      words += (size_t)TP_SLOTS * ((size_t)2 * NP + 64 + TP_MAXG);
+      nmax_all = std::max(nmax_all, ns[i]);
+    }
+    for (int b = D.nblk; b <= TP_MAXB; b++) D.wg0[b] = wg;
+    words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
+    ring_of[q] = words;
+    ring_words = std::max(ring_words, words);
+  }
+  w.ring.resize(ring_words);  // the groups run one after the other on the stream and share the ring
+  if (want_stamps) w.stamps.resize((size_t)8 * (nmax_all + 2));
+  static const long long limit_ms = getenv("HELFEM_TRDP_LIMIT_MS") ? atoll(getenv("HELFEM_TRDP_LIMIT_MS")) : 200;
+  for (size_t q = 0; q < groups.size(); q++) {
+    TrdpDesc &D = descs[q];
+    for (int b = 0; b < D.nblk; b++) D.xb[b] = w.ring.p + (size_t)D.xb[b];
+    D.status = (int *)w.ring.p;
+    D.stamps = want_stamps ? w.stamps.p : nullptr;
+    D.spin_limit = limit_ms * 100000ll;  // 100 MHz wall clock
+  }
+  hipStream_t s = ctx->stream;
+  upload_cached(w.desc, w.h_desc, descs, s);
+  w.last_ns.clear();
+  for (size_t q = 0; q < groups.size(); q++) {
+    const Group &g = groups[q];
+    trdp_kernel_t kern = trdp_pick(g.R, g.U, want_stamps);
+    if (want_stamps) HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, w.stamps.n * 8, s));
+    HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, ring_of[q] * sizeof(unsigned long long), s));
+    const TrdpDesc *dptr = w.desc.p + q;
+    void *args[] = {(void *)&dptr};
+    hipError_t err;
+    {
+      ProfScope pk(ctx, "k_trdp");  // HIP events around this launch alone on the launch stream (bench.py: roofline)
+      err = hipLaunchCooperativeKernel((const void *)kern, dim3(g.grid), dim3(TP_NT), args, 0, s);
+    }
+    if (err != hipSuccess) {
+      (void)hipGetLastError();  // refused (grid not co-resident on this device): the chain takes these matrices
+      static bool told = false;
+      if (!told) {
+        fprintf(stderr, "helfem_amd: cooperative launch of the persistent tridiagonalisation refused (%s): grid %d; using the launch chain\n",
+                hipGetErrorString(err), g.grid);
+        told = true;
+      }
+      continue;
+    }
+    HFG_HIP_CHECK(hipMemcpyAsync(w.h_status + q, w.ring.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    w.pending = true;
+    for (int i : g.idx) done[i] = 1;
+    if (w.last_ns.empty()) {
+      for (int i : g.idx) w.last_ns.push_back(ns[i]);
+      w.last_R = g.R;
+      w.last_U = g.U;
+      w.last_grid = g.grid;
+    }
+  }
 }
 
 /// replay of the last batch's launch on scratch copies is not possible (the kernel consumes its input); the bench

@@ -76,3 +76,5 @@ if __name__ == "__main__":
     check_blocks([1380, 1470, 1380])
     check_blocks([700, 650])
     check_blocks([300] * 8)
+    check_blocks([2100, 2001, 2001], reps=2)  # two groups: {2100} and {2001, 2001}
+    check_blocks([1700, 300, 2500], reps=1)   # 2500 is beyond the register tiles: that block takes the launch chain
