@@ -134,8 +134,7 @@ __host__ __device__ inline Dual eps_cam_lda0_x(Dual rho) {
   return 0.5 * eps_lda_x(rho) + 0.25 * eps_lda_x_sr(rho, HFG_CAM_LDA0_OMEGA, 2);
 }
 
-__host__ __device__ inline Dual eps_lda_c_vwn(Dual rho) {
-  const double A = 0.0310907, b = 3.72744, c = 12.9352, x0 = -0.10498;
+__host__ __device__ inline Dual eps_vwn_fit(Dual rho, double A, double b, double c, double x0) {
   Dual rs = dcbrt(3.0 / (4.0 * HFG_PI) / rho);
   Dual x = dsqrt(rs);
   Dual X = x * x + b * x + c;
@@ -145,6 +144,51 @@ __host__ __device__ inline Dual eps_lda_c_vwn(Dual rho) {
   Dual xm = x - x0;
   return A * (dlog(x * x / X) + (2.0 * b / Q) * at -
               (b * x0 / X0) * (dlog(xm * xm / X) + (2.0 * (b + 2.0 * x0) / Q) * at));
+}
+// VWN5 (libxc lda_c_vwn = 7: fit to the Ceperley-Alder data) and the RPA fit of the same paper (lda_c_vwn_rpa = 8, the
+// "VWN" inside B3LYP as libxc and Gaussian define it); Vosko, Wilk, Nusair, Can. J. Phys. 58, 1200 (1980), paramagnetic sets
+__host__ __device__ inline Dual eps_lda_c_vwn(Dual rho) { return eps_vwn_fit(rho, 0.0310907, 3.72744, 12.9352, -0.10498); }
+__host__ __device__ inline Dual eps_lda_c_vwn_rpa(Dual rho) { return eps_vwn_fit(rho, 0.0310907, 13.0720, 42.7198, -0.409286); }
+
+// Becke 88 exchange (libxc gga_x_b88 = 106; Becke, Phys. Rev. A 38, 3098 (1988)), per spin channel s:
+//   e_s = -Cx rho_s^{4/3} - beta rho_s^{4/3} x^2 / (1 + 6 beta x asinh x),  x = |grad rho_s| / rho_s^{4/3},  beta = 0.0042
+// written in t = x^2: x asinh x is smooth in t (no square-root singularity where the gradient vanishes)
+__host__ __device__ inline Dual d_x_asinh_x(Dual t) {
+  const double sq = sqrt(t.v), as = asinh(sq);
+  const double df = (sq > 1e-8 ? as / (2.0 * sq) : 0.5) + 0.5 / sqrt(1.0 + t.v);
+  return mk(sq * as, t.dr * df, t.ds * df);
+}
+__host__ __device__ inline Dual eps_gga_x_b88(Dual rho, Dual sigma) {
+  const double beta = 0.0042, Cx = 0.9305257363491000;  // (3/2) (3/(4 pi))^{1/3}
+  Dual rs = 0.5 * rho;  // one spin channel of the unpolarised density, gradient invariant sigma/4
+  Dual r43 = rs * dcbrt(rs);
+  Dual t = (0.25 * sigma) / (r43 * r43);
+  Dual es = (-1.0 * r43) * (Cx + beta * t / (1.0 + (6.0 * beta) * d_x_asinh_x(t)));
+  return 2.0 * es / rho;
+}
+
+// Lee-Yang-Parr correlation (libxc gga_c_lyp = 131; Lee, Yang, Parr, Phys. Rev. B 37, 785 (1988)) in the gradient-only
+// form of Miehlich, Savin, Stoll, Preuss, Chem. Phys. Lett. 157, 200 (1989).  Closed shell (their eq 2 at rho_a = rho_b):
+//   E = -a rho/(1 + d rho^{-1/3}) - a b omega [C_F rho^{14/3} - rho^2 sigma (1/24 + 7 delta/72)],
+//   omega = exp(-c rho^{-1/3}) rho^{-11/3} / (1 + d rho^{-1/3}),  delta = c rho^{-1/3} + d rho^{-1/3}/(1 + d rho^{-1/3})
+#define HFG_LYP_A 0.04918
+#define HFG_LYP_B 0.132
+#define HFG_LYP_C 0.2533
+#define HFG_LYP_D 0.349
+__host__ __device__ inline Dual eps_gga_c_lyp(Dual rho, Dual sigma) {
+  const double CF = 0.3 * 9.570780000627305;  // (3/10) (3 pi^2)^{2/3}
+  Dual rm13 = 1.0 / dcbrt(rho);
+  Dual den = 1.0 + HFG_LYP_D * rm13;
+  Dual delta = HFG_LYP_C * rm13 + HFG_LYP_D * rm13 / den;
+  Dual rm23 = rm13 * rm13;
+  Dual rm83 = rm23 * rm23 * rm23 * rm23;
+  return (-HFG_LYP_A) / den -
+         (HFG_LYP_A * HFG_LYP_B) * dexp(-HFG_LYP_C * rm13) / den * (CF - rm83 * sigma * (1.0 / 24.0 + (7.0 / 72.0) * delta));
+}
+// hyb_gga_xc_b3lyp (libxc 402; Stephens, Devlin, Chabalowski, Frisch, J. Phys. Chem. 98, 11623 (1994)), DFT part:
+// 0.08 lda_x + 0.72 gga_x_b88 + 0.19 lda_c_vwn_rpa + 0.81 gga_c_lyp; 0.20 exact exchange
+__host__ __device__ inline Dual eps_b3lyp(Dual r, Dual s) {
+  return 0.08 * eps_lda_x(r) + 0.72 * eps_gga_x_b88(r, s) + 0.19 * eps_lda_c_vwn_rpa(r) + 0.81 * eps_gga_c_lyp(r, s);
 }
 
 __host__ __device__ inline Dual eps_pw92(Dual rs, bool mod) {
@@ -187,13 +231,15 @@ __host__ __device__ inline Dual eps_gga_c_pbe(Dual rho, Dual sigma) {
   return ec + H;
 }
 
-__host__ __device__ inline bool is_gga(int id) { return id == 101 || id == 130 || id == 406 || id == 202 || id == 231; }
+__host__ __device__ inline bool is_gga(int id) {
+  return id == 101 || id == 130 || id == 406 || id == 202 || id == 231 || id == 106 || id == 131 || id == 402;
+}
 __host__ __device__ inline bool is_supported(int id) {
-  return id == 1 || id == 7 || id == 12 || id == 13 || id == 101 || id == 130 || id == 406 || id == 202 || id == 231 ||
-         id == 546 || id == 641 || id == 178;
+  return id == 1 || id == 7 || id == 8 || id == 12 || id == 13 || id == 101 || id == 130 || id == 406 || id == 202 || id == 231 ||
+         id == 546 || id == 641 || id == 178 || id == 106 || id == 131 || id == 402;
 }
 
-__host__ __device__ inline bool is_exchange(int id) { return id == 1 || id == 101 || id == 546 || id == 641 || id == 202; }
+__host__ __device__ inline bool is_exchange(int id) { return id == 1 || id == 101 || id == 546 || id == 641 || id == 202 || id == 106; }
 
 /// adds functional id's exc (per particle), vrho, vsigma at one point; rho >= threshold assumed.
 /// live: the density of one spin channel, rho/2, reaches the threshold.  Exchange is a sum over the spin channels and
@@ -207,6 +253,7 @@ __host__ __device__ inline void eval_add(int id, double rho, double sigma, bool 
     if (is_exchange(id)) return;
     if (id == 178) id = 13;   // the hybrids keep their correlation part
     if (id == 406) id = 130;
+    if (id == 402) id = -402;  // 0.19 lda_c_vwn_rpa + 0.81 gga_c_lyp
   }
   switch (id) {
     case 1: e = c_xcpar.x_alpha * eps_lda_x(r); break;
@@ -219,6 +266,11 @@ __host__ __device__ inline void eval_add(int id, double rho, double sigma, bool 
     case 101: e = eps_gga_x_pbe(r, s); break;
     case 130: e = eps_gga_c_pbe(r, s); break;
     case 406: e = 0.75 * eps_gga_x_pbe(r, s) + eps_gga_c_pbe(r, s); break;  // hyb_gga_xc_pbeh (PBE0), DFT part
+    case 8: e = eps_lda_c_vwn_rpa(r); break;
+    case 106: e = eps_gga_x_b88(r, s); break;
+    case 131: e = eps_gga_c_lyp(r, s); break;
+    case 402: e = eps_b3lyp(r, s); break;
+    case -402: e = 0.19 * eps_lda_c_vwn_rpa(r) + 0.81 * eps_gga_c_lyp(r, s); break;
     default: return;
   }
   Dual en = r * e;  // energy per volume
@@ -430,6 +482,38 @@ __host__ __device__ inline T pol_eps_pbe_c(T n, T rs, T z, T sig, bool ext = fal
   return ec + gamma * phi3 * tlog1p(B * f1 / (1.0 + Aa * f1));
 }
 
+// lda_c_vwn_rpa, spin-polarised: libxc interpolates the paramagnetic and the ferromagnetic RPA fits with f(zeta) alone
+__host__ __device__ inline T3 pol_eps_vwn_rpa(T3 rs, T3 z) {
+  T3 x = tsqrt(rs);
+  T3 eP = pol_vwn_fit(x, 0.0310907, 13.0720, 42.7198, -0.409286);
+  T3 eF = pol_vwn_fit(x, 0.01554535, 20.1231, 101.578, -0.743294);
+  return eP + (eF - eP) * pol_fzeta(z);
+}
+// gga_c_lyp for a spin-polarised density, Miehlich et al. eq 2 (energy per particle):
+//   n e = -a 4 ra rb / (n (1 + d n^{-1/3}))
+//         - a b omega { ra rb [2^{11/3} C_F (ra^{8/3} + rb^{8/3}) + (47/18 - 7 delta/18) s_t - (5/2 - delta/18)(s_aa + s_bb)
+//                              - (delta - 11)/9 (ra s_aa + rb s_bb)/n] - (2/3) n^2 s_t + ((2/3) n^2 - ra^2) s_bb + ((2/3) n^2 - rb^2) s_aa }
+// (vanishes identically for a fully polarised density: no self-correlation)
+template <class T>
+__host__ __device__ inline T pol_eps_lyp(T ra, T rb, T saa, T sab, T sbb) {
+  const double CF = 0.3 * 9.570780000627305, c11 = 12.699208415745595;  // 2^{11/3}
+  T n = ra + rb;
+  T rm13 = 1.0 / tcbrt(n);
+  T den = 1.0 + HFG_LYP_D * rm13;
+  T delta = HFG_LYP_C * rm13 + HFG_LYP_D * rm13 / den;
+  T rm23 = rm13 * rm13;
+  T rm113 = rm23 * rm23 * rm23 * rm23 * rm23 * rm13;  // n^{-11/3}
+  T omega = texp((-HFG_LYP_C) * rm13) / den * rm113;
+  T st = saa + 2.0 * sab + sbb;
+  T rab = ra * rb, n2 = n * n;
+  T ra83 = ra * ra * tpow23(ra), rb83 = rb * rb * tpow23(rb);
+  T t1 = (c11 * CF) * (ra83 + rb83) + (47.0 / 18.0 - (7.0 / 18.0) * delta) * st - (2.5 - delta / 18.0) * (saa + sbb) -
+         ((delta - 11.0) / 9.0) * (ra * saa + rb * sbb) / n;
+  T E = (-4.0 * HFG_LYP_A) * rab / (n * den) -
+        (HFG_LYP_A * HFG_LYP_B) * omega * (rab * t1 - (2.0 / 3.0) * n2 * st + ((2.0 / 3.0) * n2 - ra * ra) * sbb + ((2.0 / 3.0) * n2 - rb * rb) * saa);
+  return E / n;
+}
+
 /// adds functional id's exc (per particle of ra+rb), vrho[2], vsigma[3] (aa, ab, bb); ra + rb >= threshold assumed,
 /// ra, rb already raised to the threshold; live_a, live_b: the channel's own density reached the threshold (a channel
 /// below it is left out of the exchange sum, as libxc >= 5 does)
@@ -449,12 +533,39 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
     eval_add_pol(130, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
     return;
   }
+  if (id == 402) {  // hyb_gga_xc_b3lyp, DFT part
+    const int ids[4] = {1, 106, 8, 131};
+    const double wts[4] = {0.08, 0.72, 0.19, 0.81};
+    for (int q = 0; q < 4; q++) {
+      double e = 0.0, a = 0.0, b = 0.0, x = 0.0, y = 0.0, z = 0.0;
+      eval_add_pol(ids[q], ra, rb, saa, sab, sbb, live_a, live_b, e, a, b, x, y, z);
+      exc += wts[q] * e;
+      va += wts[q] * a;
+      vb += wts[q] * b;
+      vsaa += wts[q] * x;
+      vsab += wts[q] * y;
+      vsbb += wts[q] * z;
+    }
+    return;
+  }
+  if (id == 131) {  // gga_c_lyp: depends on the three gradient invariants separately
+    T7 A = t7var(ra, 0), B = t7var(rb, 1), Saa = t7var(saa, 2), Sab = t7var(sab, 3), Sbb = t7var(sbb, 4);
+    T7 e = pol_eps_lyp(A, B, Saa, Sab, Sbb);
+    T7 en = (A + B) * e;
+    exc += e.v;
+    va += en.d[0];
+    vb += en.d[1];
+    vsaa += en.d[2];
+    vsab += en.d[3];
+    vsbb += en.d[4];
+    return;
+  }
   if (id == 178) {  // hyb_lda_xc_cam_lda0, DFT part: spin-scaled exchange mixture + lda_c_pw_mod
     eval_add_pol(-178, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
     eval_add_pol(13, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
     return;
   }
-  if (id == 1 || id == 101 || id == 546 || id == 641 || id == -178) {
+  if (id == 1 || id == 101 || id == 546 || id == 641 || id == -178 || id == 106) {
     Dual a = mk(2.0 * ra, 1.0, 0.0), b = mk(2.0 * rb, 1.0, 0.0);
     Dual sa = mk(4.0 * saa, 0.0, 1.0), sb = mk(4.0 * sbb, 0.0, 1.0);
     Dual ea, eb;
@@ -463,6 +574,7 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
       case 546: ea = eps_lda_x_sr(a, 0.3, 2); eb = eps_lda_x_sr(b, 0.3, 2); break;
       case 641: ea = eps_lda_x_sr(a, 0.3, 1); eb = eps_lda_x_sr(b, 0.3, 1); break;
       case -178: ea = eps_cam_lda0_x(a); eb = eps_cam_lda0_x(b); break;
+      case 106: ea = eps_gga_x_b88(a, sa); eb = eps_gga_x_b88(b, sb); break;
       default: ea = eps_gga_x_pbe(a, sa); eb = eps_gga_x_pbe(b, sb); break;
     }
     Dual na = a * ea, nb = b * eb;  // energy per volume of the doubled densities
@@ -482,6 +594,7 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
   T3 e;
   switch (id) {
     case 7: e = pol_eps_vwn(rs, z); break;
+    case 8: e = pol_eps_vwn_rpa(rs, z); break;
     case 12: e = pol_eps_pw(rs, z, false); break;
     case 13: e = pol_eps_pw(rs, z, true); break;
     case 130: e = pol_eps_pbe_c(n, rs, z, st, true); break;

@@ -246,7 +246,7 @@ int orc_scf_diatomic(int Z1, int Z2, double Rbond, const int *lmmax, int nlm, in
   o.zexp = zexp;
   o.lpad = lpad;
   parse_xc_func(o.x_func, o.c_func, method);
-  o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
+  o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : (o.x_func == 402 ? 0.20 : 0.0));
   o.iguess = g_orc_iguess;
   o.readocc = g_orc_readocc;
   o.occs = g_orc_occs;
@@ -462,7 +462,7 @@ int orc_scf_atomic(int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int 
   o.igrid = igrid;
   o.zexp = zexp;
   parse_xc_func(o.x_func, o.c_func, method);
-  o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : 0.0);
+  o.kfrac = (o.x_func == -1) ? 1.0 : (o.x_func == 406 ? 0.25 : (o.x_func == 402 ? 0.20 : 0.0));
   if (o.x_func == 178) {  // hyb_lda_xc_cam_lda0: omega = 1/3, alpha = 1/2, beta = -1/4, erfc kernel
     o.kfrac = 0.5;
     o.kshort = -0.25;

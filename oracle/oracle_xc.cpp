@@ -92,9 +92,8 @@ void cam_lda0_x(double rho, double &exc, double &vrho) {
   vrho = 0.5 * v1 + 0.25 * v2;
 }
 
-// ---- VWN5 paramagnetic correlation ----
-void lda_c_vwn(double rho, double &exc, double &vrho) {
-  const double A = 0.0310907, b = 3.72744, c = 12.9352, x0 = -0.10498;
+// ---- VWN paramagnetic correlation: the Ceperley-Alder fit (VWN5, lda_c_vwn) and the RPA fit (lda_c_vwn_rpa) ----
+void lda_c_vwn_par(double rho, double A, double b, double c, double x0, double &exc, double &vrho) {
   double rs = cbrt(3.0 / (4.0 * PI * rho));
   double x = sqrt(rs);
   double X = x * x + b * x + c;
@@ -108,6 +107,31 @@ void lda_c_vwn(double rho, double &exc, double &vrho) {
                      b * x0 / X0 * (2.0 / (x - x0) - (2.0 * x + b) / X - 4.0 * (2.0 * x0 + b) / den));
   // rho d exc/d rho = -(rs/3) d exc/d rs = -(x/6) d exc/dx
   vrho = exc - x / 6.0 * dedx;
+}
+void lda_c_vwn(double rho, double &exc, double &vrho) { lda_c_vwn_par(rho, 0.0310907, 3.72744, 12.9352, -0.10498, exc, vrho); }
+void lda_c_vwn_rpa(double rho, double &exc, double &vrho) { lda_c_vwn_par(rho, 0.0310907, 13.0720, 42.7198, -0.409286, exc, vrho); }
+
+// ---- Becke 88 exchange (Phys. Rev. A 38, 3098): hand-derived.  Per spin channel (density r = rho/2, gradient invariant
+// s = sigma/4):  e_s = -r^{4/3} [Cx + beta g(x)],  g = x^2/(1 + 6 beta x asinh x),  x = sqrt(s)/r^{4/3};
+// unpolarised energy per volume 2 e_s; d/d rho and d/d sigma through x^2 = s r^{-8/3}
+void gga_x_b88(double rho, double sigma, double &exc, double &vrho, double &vsigma) {
+  const double beta = 0.0042, Cx = 1.5 * cbrt(3.0 / (4.0 * PI));
+  const double r = 0.5 * rho, sg = 0.25 * sigma;
+  const double r13 = cbrt(r), r43 = r * r13;
+  const double t = sg / (r43 * r43);  // x^2
+  const double x = sqrt(t), as = asinh(x);
+  const double D = 1.0 + 6.0 * beta * x * as;
+  const double g = t / D;
+  // dg/dt = 1/D - t/D^2 * 6 beta d(x asinh x)/dt,  d(x asinh x)/dt = asinh(x)/(2x) + 1/(2 sqrt(1+t))
+  const double dh = (x > 1e-8 ? as / (2.0 * x) : 0.5) + 0.5 / sqrt(1.0 + t);
+  const double dg = 1.0 / D - t / (D * D) * 6.0 * beta * dh;
+  const double es = -r43 * (Cx + beta * g);  // per volume, one channel
+  // d es/d r = -(4/3) r^{1/3} (Cx + beta g) - r^{4/3} beta dg dt/dr,  dt/dr = -(8/3) t/r
+  const double des_dr = -(4.0 / 3.0) * r13 * (Cx + beta * g) + r43 * beta * dg * (8.0 / 3.0) * t / r;
+  const double des_ds = -r43 * beta * dg / (r43 * r43);  // dt/ds = r^{-8/3}
+  exc = 2.0 * es / rho;
+  vrho = des_dr;           // d(2 es)/d rho = 2 des/dr * (1/2)
+  vsigma = 0.5 * des_ds;   // d(2 es)/d sigma = 2 des/ds * (1/4)
 }
 
 // ---- PW92 paramagnetic correlation; mod=true uses the higher-precision constants of pw_mod ----
@@ -182,7 +206,12 @@ void gga_c_pbe(double rho, double sigma, double &exc, double &vrho, double &vsig
 }
 }  // namespace
 
-bool xc_is_gga(int id) { return id == 101 || id == 130 || id == 406 || id == 202 || id == 231; }  // needs the gradient
+// Lee-Yang-Parr correlation, defined behind the differentiation type below
+void gga_c_lyp(double rho, double sigma, double &exc, double &vrho, double &vsigma);
+
+bool xc_is_gga(int id) {  // needs the gradient
+  return id == 101 || id == 130 || id == 406 || id == 202 || id == 231 || id == 106 || id == 131 || id == 402;
+}
 
 void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho,
                     double *vsigma, double thr) {
@@ -199,9 +228,10 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
     const bool live = 0.5 * r >= thr;
     int idl = id;
     if (!live) {
-      if (id == 1 || id == 101 || id == 546 || id == 641) continue;
+      if (id == 1 || id == 101 || id == 546 || id == 641 || id == 106) continue;
       if (id == 178) idl = 13;  // the hybrids keep their correlation part
       if (id == 406) idl = 130;
+      if (id == 402) idl = -402;
     }
     switch (idl) {
       case 1:
@@ -224,6 +254,23 @@ void xc_unpolarized(int id, size_t N, const double *rho, const double *sigma, do
       }
       case 101: gga_x_pbe(r, sigma[i], e, v, vs); break;
       case 130: gga_c_pbe(r, sigma[i], e, v, vs); break;
+      case 8: lda_c_vwn_rpa(r, e, v); break;
+      case 106: gga_x_b88(r, sigma[i], e, v, vs); break;
+      case 131: gga_c_lyp(r, sigma[i], e, v, vs); break;
+      case 402:     // hyb_gga_xc_b3lyp, DFT part: 0.08 lda_x + 0.72 gga_x_b88 + 0.19 lda_c_vwn_rpa + 0.81 gga_c_lyp
+      case -402: {  // ... its correlation part alone (exchange channel below the threshold)
+        double e1 = 0, v1 = 0, e2 = 0, v2 = 0, vs2 = 0, e3, v3, e4, v4, vs4;
+        if (idl == 402) {
+          lda_x(r, e1, v1);
+          gga_x_b88(r, sigma[i], e2, v2, vs2);
+        }
+        lda_c_vwn_rpa(r, e3, v3);
+        gga_c_lyp(r, sigma[i], e4, v4, vs4);
+        e = 0.08 * e1 + 0.72 * e2 + 0.19 * e3 + 0.81 * e4;
+        v = 0.08 * v1 + 0.72 * v2 + 0.19 * v3 + 0.81 * v4;
+        vs = 0.72 * vs2 + 0.81 * vs4;
+        break;
+      }
       case 406: {  // hyb_gga_xc_pbeh (PBE0), DFT part
         double e2, v2, vs2;
         gga_x_pbe(r, sigma[i], e, v, vs);
@@ -372,7 +419,41 @@ D3 eps_pbe_c(D3 rho, D3 rs, D3 z, D3 sig) {
   D3 At2 = A * t2;
   return ec + gamma * phi3 * Dlog1p(B * t2 * (1.0 + BB * At2) / (1.0 + At2 + BB * At2 * At2));
 }
+// lda_c_vwn_rpa, spin-polarised: the paramagnetic and ferromagnetic RPA fits interpolated with f(zeta) alone (libxc)
+D3 eps_vwn_rpa(D3 rs, D3 z) {
+  D3 x = Dsqrt(rs);
+  D3 eP = vwn_fit(x, 0.0310907, 13.0720, 42.7198, -0.409286);
+  D3 eF = vwn_fit(x, 0.01554535, 20.1231, 101.578, -0.743294);
+  return eP + (eF - eP) * fzeta(z);
+}
+
+// Lee-Yang-Parr correlation energy per VOLUME in the form of Miehlich, Savin, Stoll, Preuss (Chem. Phys. Lett. 157, 200
+// (1989), eq 2) as a function of (rho_a, rho_b, sigma_aa, sigma_ab, sigma_bb)
+D3 lyp_energy(D3 ra, D3 rb, D3 saa, D3 sab, D3 sbb) {
+  const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349, CF = 0.3 * pow(3.0 * PI * PI, 2.0 / 3.0);
+  D3 n = ra + rb;
+  D3 rm13 = 1.0 / Dcbrt(n);
+  D3 den = 1.0 + d * rm13;
+  D3 delta = c * rm13 + d * rm13 / den;
+  D3 n113 = n * n * n * Dpow23(n);  // n^{11/3}
+  D3 omega = Dexp(-c * rm13) / (den * n113);
+  D3 st = saa + 2.0 * sab + sbb;
+  D3 ra83 = ra * ra * Dpow23(ra), rb83 = rb * rb * Dpow23(rb);
+  D3 brace = ra * rb * (pow(2.0, 11.0 / 3.0) * CF * (ra83 + rb83) + (47.0 / 18.0 - 7.0 / 18.0 * delta) * st -
+                        (2.5 - delta / 18.0) * (saa + sbb) - (delta - 11.0) / 9.0 * (ra * saa + rb * sbb) / n) -
+             2.0 / 3.0 * n * n * st + (2.0 / 3.0 * n * n - ra * ra) * sbb + (2.0 / 3.0 * n * n - rb * rb) * saa;
+  return -a * 4.0 / den * ra * rb / n - a * b * omega * brace;
+}
 }  // namespace
+
+// spin-unpolarised LYP from the general form at rho_a = rho_b = rho/2, sigma_aa = sigma_ab = sigma_bb = sigma/4 (the
+// kernels use the closed-shell reduction of the formula instead: two different algebraic routes)
+void gga_c_lyp(double rho, double sigma, double &exc, double &vrho, double &vsigma) {
+  D3 E = lyp_energy(var(0.5 * rho, 0), var(0.5 * rho, 1), var(0.25 * sigma, 2), var(0.25 * sigma, 3), var(0.25 * sigma, 4));
+  exc = E.v / rho;
+  vrho = 0.5 * (E.d[0] + E.d[1]);
+  vsigma = 0.25 * (E.d[2] + E.d[3] + E.d[4]);
+}
 
 void xc_polarized(int id, size_t N, const double *rho, const double *sigma, double *exc, double *vrho, double *vsigma,
                   double thr) {
@@ -383,6 +464,23 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
     for (size_t i = 0; i < N; i++) exc[i] += e[i];
     for (size_t i = 0; i < 2 * N; i++) vrho[i] += v[i];
     if (vsigma) std::fill(vsigma, vsigma + 3 * N, 0.0);
+    return;
+  }
+  if (id == 402) {  // hyb_gga_xc_b3lyp, DFT part
+    const int ids[4] = {1, 106, 8, 131};
+    const double wts[4] = {0.08, 0.72, 0.19, 0.81};
+    std::fill(exc, exc + N, 0.0);
+    std::fill(vrho, vrho + 2 * N, 0.0);
+    std::fill(vsigma, vsigma + 3 * N, 0.0);
+    Vec e(N), v(2 * N), vs(3 * N);
+    for (int q = 0; q < 4; q++) {
+      std::fill(vs.begin(), vs.end(), 0.0);
+      xc_polarized(ids[q], N, rho, sigma, e.data(), v.data(), vs.data(), thr);
+      for (size_t i = 0; i < N; i++) exc[i] += wts[q] * e[i];
+      for (size_t i = 0; i < 2 * N; i++) vrho[i] += wts[q] * v[i];
+      if (xc_is_gga(ids[q]))
+        for (size_t i = 0; i < 3 * N; i++) vsigma[i] += wts[q] * vs[i];
+    }
     return;
   }
   if (id == 406) {  // hyb_gga_xc_pbeh (PBE0), DFT part: 0.75 gga_x_pbe + gga_c_pbe
@@ -416,6 +514,7 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
       case 546:
       case 641:
       case -178:
+      case 106:
       case 101: {  // spin-scaled exchange
         double ea, va, vsa = 0, eb, vb, vsb = 0;
         if (id == 1) {
@@ -431,6 +530,9 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
         } else if (id == -178) {
           cam_lda0_x(2.0 * ra, ea, va);
           cam_lda0_x(2.0 * rb, eb, vb);
+        } else if (id == 106) {
+          gga_x_b88(2.0 * ra, 4.0 * saa, ea, va, vsa);
+          gga_x_b88(2.0 * rb, 4.0 * sbb, eb, vb, vsb);
         } else {
           gga_x_pbe(2.0 * ra, 4.0 * saa, ea, va, vsa);
           gga_x_pbe(2.0 * rb, 4.0 * sbb, eb, vb, vsb);
@@ -446,7 +548,18 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
         }
         break;
       }
+      case 131: {  // LYP: the three gradient invariants enter separately
+        D3 E = lyp_energy(var(ra, 0), var(rb, 1), var(saa, 2), var(sab, 3), var(sbb, 4));
+        exc[i] = E.v / rt;
+        vrho[2 * i] = E.d[0];
+        vrho[2 * i + 1] = E.d[1];
+        vsigma[3 * i] = E.d[2];
+        vsigma[3 * i + 1] = E.d[3];
+        vsigma[3 * i + 2] = E.d[4];
+        break;
+      }
       case 7:
+      case 8:
       case 12:
       case 13:
       case 130: {
@@ -454,7 +567,7 @@ void xc_polarized(int id, size_t N, const double *rho, const double *sigma, doub
         D3 n = a + b;
         D3 rs = Dcbrt((3.0 / (4.0 * PI)) / n);
         D3 z = (a - b) / n;
-        D3 e = (id == 7) ? eps_vwn(rs, z) : (id == 12) ? eps_pw(rs, z, false) : (id == 13) ? eps_pw(rs, z, true) : eps_pbe_c(n, rs, z, st);
+        D3 e = (id == 7) ? eps_vwn(rs, z) : (id == 8) ? eps_vwn_rpa(rs, z) : (id == 12) ? eps_pw(rs, z, false) : (id == 13) ? eps_pw(rs, z, true) : eps_pbe_c(n, rs, z, st);
         D3 en = n * e;
         exc[i] = e.v;
         vrho[2 * i] = en.d[0];
@@ -648,6 +761,10 @@ static int find_func(const std::string &name) {
   if (!strcasecmp(name.c_str(), "gga_x_pbe")) return 101;
   if (!strcasecmp(name.c_str(), "gga_c_pbe")) return 130;
   if (!strcasecmp(name.c_str(), "hyb_gga_xc_pbeh")) return 406;
+  if (!strcasecmp(name.c_str(), "lda_c_vwn_rpa")) return 8;
+  if (!strcasecmp(name.c_str(), "gga_x_b88")) return 106;
+  if (!strcasecmp(name.c_str(), "gga_c_lyp")) return 131;
+  if (!strcasecmp(name.c_str(), "hyb_gga_xc_b3lyp")) return 402;
   if (!strcasecmp(name.c_str(), "mgga_x_tpss")) return 202;
   if (!strcasecmp(name.c_str(), "mgga_c_tpss")) return 231;
   std::ostringstream oss;

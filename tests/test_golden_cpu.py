@@ -235,18 +235,19 @@ def test_oracle_xc_functionals_consistency():
     import oracle_lib as orc
     rho = np.array([1e-6, 1e-3, 0.05, 0.3, 2.0, 40.0])
     sig = np.array([1e-14, 1e-7, 1e-3, 0.2, 5.0, 3000.0])
-    for fid in (1, 7, 12, 101, 130):
+    for fid in (1, 7, 8, 12, 101, 130, 106, 131, 402):
         e, vr, vs = orc.xc_unpolarized(fid, rho, sig)
         h = 1e-5
         ep, _, _ = orc.xc_unpolarized(fid, rho * (1 + h), sig)
         em, _, _ = orc.xc_unpolarized(fid, rho * (1 - h), sig)
         num = (rho * (1 + h) * ep - rho * (1 - h) * em) / (2 * h * rho)
         assert np.all(np.abs(num - vr) < 1e-7 * (1 + np.abs(vr))), fid
-        if fid in (101, 130):
+        if fid in (101, 130, 106, 131, 402):
             ep, _, _ = orc.xc_unpolarized(fid, rho, sig * (1 + h))
             em, _, _ = orc.xc_unpolarized(fid, rho, sig * (1 - h))
             num = rho * (ep - em) / (2 * h * sig)
-            assert np.all(np.abs(num - vs) < 1e-6 * (np.abs(vs) + 1e-12)), fid
+            noise = 8 * np.finfo(float).eps * np.abs(rho * e) / (2 * h * sig)  # rounding of the difference quotient itself
+            assert np.all(np.abs(num - vs) < 1e-6 * (np.abs(vs) + 1e-12) + noise), fid
     # below the density threshold everything is zero (xc_func_set_dens_threshold, dftgrid.cpp:393)
     e, vr, vs = orc.xc_unpolarized(101, np.array([1e-13]), np.array([1.0]), 1e-12)
     assert e[0] == 0 and vr[0] == 0 and vs[0] == 0
@@ -382,7 +383,28 @@ ATOMIC_LITERATURE = [
     ("He_PBE0", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh"), -2.895178, 2e-6),
     ("He_TPSS", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="mgga_x_tpss-mgga_c_tpss"), -2.9097, 1e-4),
     ("Be_TPSS", dict(Z=4, lmax=0, mmax=0, nelem=5, nnodes=15, method="mgga_x_tpss-mgga_c_tpss"), -14.6717, 2e-4),
+    # B-LYP and B3LYP (libxc's definition: VWN RPA fit): basis-set-limit totals quoted to four decimals in the literature
+    # [external]: He -2.9071 / -2.9152, Ne -128.9730 / -128.9810; the checker gives -2.907067, -2.915219, -128.973015, -128.980973
+    ("He_BLYP", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=12, method="gga_x_b88-gga_c_lyp"), -2.9071, 1e-4),
+    ("He_B3LYP", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=12, method="hyb_gga_xc_b3lyp"), -2.9152, 1e-4),
+    ("Ne_BLYP", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=12, method="gga_x_b88-gga_c_lyp"), -128.9730, 2e-4),
 ]
+
+
+def test_becke88_exchange_energy_of_the_hydrogen_atom():
+    """Becke, Phys. Rev. A 38, 3098 (1988), Table I: exchange energy of the exact hydrogen density, LDA -0.2680, B88 -0.3098
+    (exact -0.3125); one-dimensional radial quadrature of the checker's spin-polarised functional (one spin channel)"""
+    r = np.linspace(1e-6, 40.0, 200001)
+    rho = np.exp(-2.0 * r) / np.pi
+    g = 2.0 * rho  # |grad rho|
+    pr = np.stack([rho, 0 * rho], 1)
+    ps = np.stack([g * g, 0 * g, 0 * g], 1)
+    out = {}
+    for fid in (1, 106):
+        e, _, _ = orc.xc_polarized(fid, pr, ps, 1e-300)
+        f = 4 * np.pi * r * r * rho * e
+        out[fid] = float(np.sum(0.5 * (f[1:] + f[:-1]) * np.diff(r)))
+    assert abs(out[1] - (-0.2680)) < 1e-4 and abs(out[106] - (-0.3098)) < 1e-4, out
 
 
 @pytest.mark.parametrize("name,kw,lit,tol", ATOMIC_LITERATURE, ids=[c[0] for c in ATOMIC_LITERATURE])
@@ -421,7 +443,49 @@ def test_atomic_grid_electron_count_and_exchange_energy():
 # ---------------------------------------------------------------------------------------------------
 # spin-polarised functionals and unrestricted runs
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("fid", [1, 7, 12, 101, 130])
+def test_b88_lyp_b3lyp_known_limits():
+    """gga_x_b88 reduces to lda_x at vanishing gradient and lowers the energy with it; gga_c_lyp (Miehlich form through
+    the checker's differentiation type) equals the closed-shell reduction of the same formula written out independently
+    here, has the Colle-Salvetti uniform-gas value at sigma = 0 and vanishes for a fully polarised density (no
+    self-correlation); hyb_gga_xc_b3lyp is 0.08 lda_x + 0.72 gga_x_b88 + 0.19 lda_c_vwn_rpa + 0.81 gga_c_lyp"""
+    import oracle_lib as orc
+    rho = np.array([1e-4, 0.02, 0.3, 1.7, 25.0])
+    sig = np.array([1e-9, 1e-4, 0.05, 2.0, 900.0])
+    e0, v0, _ = orc.xc_unpolarized(1, rho, 0 * sig)
+    eb, vb, vsb = orc.xc_unpolarized(106, rho, 1e-300 + 0 * sig)
+    assert np.max(np.abs(eb - e0)) < 1e-14 and np.max(np.abs(vb - v0)) < 1e-13
+    eb2, _, vs2 = orc.xc_unpolarized(106, rho, sig)
+    assert np.all(eb2 < e0) and np.all(vs2 < 0)
+    # small-gradient expansion: e = e_LDA - beta (rho/2)^{4/3} x^2 * 2/rho, x^2 = (sigma/4)/(rho/2)^{8/3}
+    s_small = 1e-5 * rho ** (8.0 / 3.0)
+    es, _, _ = orc.xc_unpolarized(106, rho, s_small)
+    x2 = (0.25 * s_small) / (0.5 * rho) ** (8.0 / 3.0)
+    assert np.max(np.abs((es - e0) - (-0.0042 * (0.5 * rho) ** (4.0 / 3.0) * x2 * 2.0 / rho)) / np.abs(es - e0)) < 1e-5
+    # LYP, closed shell, written out: E/rho = -a/(1 + d r) - a b exp(-c r)/(1 + d r) [C_F - rho^{-8/3} sigma (1/24 + 7 delta/72)], r = rho^{-1/3}
+    a, b, c, d = 0.04918, 0.132, 0.2533, 0.349
+    CF = 0.3 * (3 * np.pi ** 2) ** (2.0 / 3.0)
+    r = rho ** (-1.0 / 3.0)
+    delta = c * r + d * r / (1 + d * r)
+    closed = -a / (1 + d * r) - a * b * np.exp(-c * r) / (1 + d * r) * (CF - rho ** (-8.0 / 3.0) * sig * (1.0 / 24 + 7.0 * delta / 72))
+    el, vl, vsl = orc.xc_unpolarized(131, rho, sig)
+    assert np.max(np.abs(el - closed) / np.abs(closed)) < 1e-13
+    # fully polarised: zero (threshold 0 so that the empty channel stays empty)
+    pr = np.stack([rho, 0 * rho], axis=1)
+    ps = np.stack([sig, 0 * sig, 0 * sig], axis=1)
+    ep, vp, vsp = orc.xc_polarized(131, pr, ps, 0.0)
+    assert np.max(np.abs(ep)) < 1e-16
+    # composition of B3LYP
+    ex, vx, _ = orc.xc_unpolarized(1, rho, sig)
+    ev, vv, _ = orc.xc_unpolarized(8, rho, sig)
+    e3, v3, vs3 = orc.xc_unpolarized(402, rho, sig)
+    assert np.max(np.abs(e3 - (0.08 * ex + 0.72 * eb2 + 0.19 * ev + 0.81 * el))) < 1e-15
+    assert np.max(np.abs(vs3 - (0.72 * vs2 + 0.81 * vsl))) < 1e-15 * np.max(np.abs(vs3)) + 1e-18
+    # VWN: the RPA fit lies below the Ceperley-Alder fit (RPA overcorrelates) at every density
+    e5, _, _ = orc.xc_unpolarized(7, rho, sig)
+    assert np.all(ev < e5)
+
+
+@pytest.mark.parametrize("fid", [1, 7, 8, 12, 101, 130, 106, 131, 402])
 def test_polarized_functionals_reduce_to_unpolarized_and_match_finite_differences(fid):
     rng = np.random.RandomState(fid)
     n = 40

@@ -214,7 +214,7 @@ def test_exchange_shards_sum_to_full(case, hf, nranks):
 
 
 @pytest.mark.parametrize("funcs", [(1, 7), (1, 0), (101, 130), (101, 0), (0, 130), (1, 12), (406, 0), (202, 231), (202, 0),
-                                   (0, 231), (202, 130)])
+                                   (0, 231), (202, 130), (106, 131), (106, 0), (0, 131), (402, 0), (1, 8)])
 def test_xc_parity(case, hf, funcs):
     import common
     name, gb, ob, ldft, mdft = case
@@ -530,7 +530,7 @@ def test_atomic_exchange_parity(acase):
         assert common.relerr(K, Ko) < 1e-12, (name, tag, common.relerr(K, Ko))
 
 
-@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (101, 0), (0, 130), (1, 12), (202, 231)])
+@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (101, 0), (0, 130), (1, 12), (202, 231), (106, 131), (402, 0)])
 def test_atomic_xc_parity(acase, hf, funcs):
     import common
     name, gb, ob, ldft, mdft = acase
@@ -589,7 +589,7 @@ def test_xc_polarized_mgga_parity(case, hf, funcs):
             assert common.relerr(Hb, Hbo) < 1e-4, (name, funcs, common.relerr(Hb, Hbo))
 
 
-@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (1, 12), (101, 0), (0, 130), (406, 0)])
+@pytest.mark.parametrize("funcs", [(1, 7), (101, 130), (1, 12), (101, 0), (0, 130), (406, 0), (106, 131), (0, 131), (402, 0), (1, 8)])
 def test_xc_polarized_parity(case, hf, funcs):
     import common
     name, gb, ob, ldft, mdft = case
@@ -643,6 +643,9 @@ OPEN_SHELL_CASES = [
     ("H_PBE", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=15, method="gga_x_pbe-gga_c_pbe", M=2), -0.499990, 2e-6),
     ("Li_UHF", "atomic", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=2), -7.432751, 2e-6),
     ("N_LSD", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=12, method="lda_x-lda_c_vwn", M=4), -54.136799, 5e-6),
+    # spin-polarised B-LYP / B3LYP: hydrogen (LYP has no self-correlation: E = T + V + J + E_x^B88) and nitrogen 4S against the checker
+    ("H_BLYP", "atomic", dict(Z=1, lmax=0, mmax=0, nelem=5, nnodes=12, method="gga_x_b88-gga_c_lyp", M=2), None, None),
+    ("N_B3LYP", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=12, method="hyb_gga_xc_b3lyp", M=4), None, None),
     # restricted open shell (constrained-UHF form of ROHF, scf::ROHF_update): M < 0 selects it; ROHF limits
     ("Li_ROHF", "atomic", dict(Z=3, lmax=0, mmax=0, nelem=5, nnodes=15, method="HF", M=-2), -7.4327269, 1e-6),
     ("N_ROHF", "atomic", dict(Z=7, lmax=1, mmax=1, nelem=5, nnodes=12, method="HF", M=-4), -54.400934, 2e-6),
@@ -717,6 +720,10 @@ ATOMIC_SCF_CASES = [
     ("Ne_LDA", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=15, method="lda_x-lda_c_vwn"), -128.233481, 2e-6),
     # global hybrid: J + 0.25 K + XC in one Fock build (hyb_gga_xc_pbeh = PBE0)
     ("He_PBE0", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="hyb_gga_xc_pbeh"), -2.895178, 2e-6),
+    # B-LYP and B3LYP (0.20 exact exchange; libxc's definition with the VWN RPA fit): literature totals to four decimals
+    ("He_BLYP", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=12, method="gga_x_b88-gga_c_lyp"), -2.9071, 1e-4),
+    ("He_B3LYP", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=12, method="hyb_gga_xc_b3lyp"), -2.9152, 1e-4),
+    ("Ne_B3LYP", dict(Z=10, lmax=1, mmax=1, nelem=5, nnodes=12, method="hyb_gga_xc_b3lyp"), -128.9810, 3e-4),
     # meta-GGA (tau): TPSS, total energies of Staroverov et al., PRB 69, 075102, Table (4 decimals)
     ("He_TPSS", dict(Z=2, lmax=0, mmax=0, nelem=5, nnodes=15, method="mgga_x_tpss-mgga_c_tpss"), -2.9097, 1e-4),
     ("Ne_TPSS", dict(Z=10, lmax=1, mmax=1, nelem=4, nnodes=12, method="mgga_x_tpss-mgga_c_tpss"), -128.9811, 2e-4),
