@@ -509,45 +509,22 @@ __host__ __device__ inline T pol_eps_lyp(T ra, T rb, T saa, T sab, T sbb) {
   T ra83 = ra * ra * tpow23(ra), rb83 = rb * rb * tpow23(rb);
   T t1 = (c11 * CF) * (ra83 + rb83) + (47.0 / 18.0 - (7.0 / 18.0) * delta) * st - (2.5 - delta / 18.0) * (saa + sbb) -
          ((delta - 11.0) / 9.0) * (ra * saa + rb * sbb) / n;
+  // the last three terms of the published brace, -(2/3) n^2 s_t + ((2/3) n^2 - ra^2) s_bb + ((2/3) n^2 - rb^2) s_aa, collapse to
+  // -(4/3) n^2 s_ab - ra^2 s_bb - rb^2 s_aa: summed as published they cancel to 1e-8 of their size in strongly polarised
+  // regions (the checker keeps the published arrangement)
   T E = (-4.0 * HFG_LYP_A) * rab / (n * den) -
-        (HFG_LYP_A * HFG_LYP_B) * omega * (rab * t1 - (2.0 / 3.0) * n2 * st + ((2.0 / 3.0) * n2 - ra * ra) * sbb + ((2.0 / 3.0) * n2 - rb * rb) * saa);
+        (HFG_LYP_A * HFG_LYP_B) * omega * (rab * t1 - (4.0 / 3.0) * n2 * sab - ra * ra * sbb - rb * rb * saa);
+  (void)st;
   return E / n;
 }
 
 /// adds functional id's exc (per particle of ra+rb), vrho[2], vsigma[3] (aa, ab, bb); ra + rb >= threshold assumed,
 /// ra, rb already raised to the threshold; live_a, live_b: the channel's own density reached the threshold (a channel
 /// below it is left out of the exchange sum, as libxc >= 5 does)
-__host__ __device__ inline void eval_add_pol(int id, double ra, double rb, double saa, double sab, double sbb, bool live_a,
+__host__ __device__ inline void eval_add_pol_basic(int id, double ra, double rb, double saa, double sab, double sbb, bool live_a,
                                              bool live_b, double &exc, double &va, double &vb, double &vsaa, double &vsab,
                                              double &vsbb) {
   const double rt = ra + rb;
-  if (id == 406) {  // hyb_gga_xc_pbeh (PBE0), DFT part: 0.75 gga_x_pbe + gga_c_pbe
-    double e = 0.0, a = 0.0, b = 0.0, saa2 = 0.0, sab2 = 0.0, sbb2 = 0.0;
-    eval_add_pol(101, ra, rb, saa, sab, sbb, live_a, live_b, e, a, b, saa2, sab2, sbb2);
-    exc += 0.75 * e;
-    va += 0.75 * a;
-    vb += 0.75 * b;
-    vsaa += 0.75 * saa2;
-    vsab += 0.75 * sab2;
-    vsbb += 0.75 * sbb2;
-    eval_add_pol(130, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
-    return;
-  }
-  if (id == 402) {  // hyb_gga_xc_b3lyp, DFT part
-    const int ids[4] = {1, 106, 8, 131};
-    const double wts[4] = {0.08, 0.72, 0.19, 0.81};
-    for (int q = 0; q < 4; q++) {
-      double e = 0.0, a = 0.0, b = 0.0, x = 0.0, y = 0.0, z = 0.0;
-      eval_add_pol(ids[q], ra, rb, saa, sab, sbb, live_a, live_b, e, a, b, x, y, z);
-      exc += wts[q] * e;
-      va += wts[q] * a;
-      vb += wts[q] * b;
-      vsaa += wts[q] * x;
-      vsab += wts[q] * y;
-      vsbb += wts[q] * z;
-    }
-    return;
-  }
   if (id == 131) {  // gga_c_lyp: depends on the three gradient invariants separately
     T7 A = t7var(ra, 0), B = t7var(rb, 1), Saa = t7var(saa, 2), Sab = t7var(sab, 3), Sbb = t7var(sbb, 4);
     T7 e = pol_eps_lyp(A, B, Saa, Sab, Sbb);
@@ -558,11 +535,6 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
     vsaa += en.d[2];
     vsab += en.d[3];
     vsbb += en.d[4];
-    return;
-  }
-  if (id == 178) {  // hyb_lda_xc_cam_lda0, DFT part: spin-scaled exchange mixture + lda_c_pw_mod
-    eval_add_pol(-178, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
-    eval_add_pol(13, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
     return;
   }
   if (id == 1 || id == 101 || id == 546 || id == 641 || id == -178 || id == 106) {
@@ -607,6 +579,37 @@ __host__ __device__ inline void eval_add_pol(int id, double ra, double rb, doubl
   vsaa += en.s;
   vsab += 2.0 * en.s;
   vsbb += en.s;
+}
+
+/// eval_add_pol_basic plus the composite functionals (no recursion: a recursive device function needs a dynamic stack)
+__host__ __device__ inline void eval_add_pol(int id, double ra, double rb, double saa, double sab, double sbb, bool live_a,
+                                             bool live_b, double &exc, double &va, double &vb, double &vsaa, double &vsab,
+                                             double &vsbb) {
+#define HFG_ADD_SCALED(ID, W)                                                                          \
+  {                                                                                                    \
+    double e_ = 0.0, a_ = 0.0, b_ = 0.0, x_ = 0.0, y_ = 0.0, z_ = 0.0;                                 \
+    eval_add_pol_basic(ID, ra, rb, saa, sab, sbb, live_a, live_b, e_, a_, b_, x_, y_, z_);             \
+    exc += (W)*e_;                                                                                     \
+    va += (W)*a_;                                                                                      \
+    vb += (W)*b_;                                                                                      \
+    vsaa += (W)*x_;                                                                                    \
+    vsab += (W)*y_;                                                                                    \
+    vsbb += (W)*z_;                                                                                    \
+  }
+  if (id == 406) {  // hyb_gga_xc_pbeh (PBE0), DFT part: 0.75 gga_x_pbe + gga_c_pbe
+    HFG_ADD_SCALED(101, 0.75)
+    HFG_ADD_SCALED(130, 1.0)
+  } else if (id == 178) {  // hyb_lda_xc_cam_lda0, DFT part: spin-scaled exchange mixture + lda_c_pw_mod
+    HFG_ADD_SCALED(-178, 1.0)
+    HFG_ADD_SCALED(13, 1.0)
+  } else if (id == 402) {  // hyb_gga_xc_b3lyp, DFT part
+    HFG_ADD_SCALED(1, 0.08)
+    HFG_ADD_SCALED(106, 0.72)
+    HFG_ADD_SCALED(8, 0.19)
+    HFG_ADD_SCALED(131, 0.81)
+  } else
+    eval_add_pol_basic(id, ra, rb, saa, sab, sbb, live_a, live_b, exc, va, vb, vsaa, vsab, vsbb);
+#undef HFG_ADD_SCALED
 }
 
 // ---------------------------------------------------------------------------------------------------------
