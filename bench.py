@@ -40,6 +40,18 @@ WORKLOADS = {
 TRD_KERNEL = "k_trdb_gemv" if os.environ.get("HELFEM_TRD") == "twokernel" else "k_trdf"
 
 
+def kernel_sources_sha():
+    """fingerprint of the HIP sources the profiled kernels come from: tools/pmc_traffic.py stores it with the PMC traffic
+    it reduces, and the bench line drops a committed `traffic` figure that was measured on other kernel sources"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "helfem_amd", "csrc", "hip")
+    for f in ("trdp.hip", "trd.hip", "gemm.hip", "exchange_lr.hip", "fock.hip", "wave.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_basis(hf, w):
     lval, mval = hf.lm_to_l_m(w["lmmax"])
     Rh = 0.5 * w["Rbond"]
@@ -407,7 +419,10 @@ def main():
                 import glob
                 traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]
                 with open(traffic_file) as fh:
-                    for kname, rec in json.load(fh).items():  # "void hfg::k_trdf<1024>" (template) or "hfg::k_trdb_gemv"
+                    tj = json.load(fh)
+                meta = tj.pop("_meta", {})
+                if meta.get("kernel_sources_sha256", kernel_sources_sha()) == kernel_sources_sha():  # stale figures are dropped
+                    for kname, rec in tj.items():  # "void hfg::k_trdp<5, 12, false>" (template) or "hfg::k_trdb_gemv"
                         if ("hfg::" + trd_kernel) in kname:
                             traffic = rec.get("traffic_bytes_per_launch")
         except Exception:
@@ -463,7 +478,10 @@ def main():
                 if cand:
                     ktraffic_file = cand[-1]
                     with open(ktraffic_file) as fh:
-                        for kname, rec in json.load(fh).items():
+                        tj = json.load(fh)
+                    meta = tj.pop("_meta", {})
+                    if meta.get("kernel_sources_sha256", kernel_sources_sha()) == kernel_sources_sha():
+                        for kname, rec in tj.items():
                             if "k_dgemm_tasklist_wl" in kname:
                                 ktraffic = rec.get("traffic_bytes_per_launch")
             except Exception:

@@ -111,13 +111,14 @@ class Parser {
   }
   const std::string &str(const std::string &name) const { return opts_[index_.at(name)].value; }
   bool given(const std::string &name) const { return opts_[index_.at(name)].given; }
-  int integer(const std::string &name) const {
-    const std::string &v = str(name);
+  /// checked conversion of one item of an option's value (the whole value, or one entry of a comma-separated list)
+  static int to_int(const std::string &name, const std::string &v) {
     char *end = nullptr;
     long r = strtol(v.c_str(), &end, 10);
     if (end == v.c_str() || *end) throw std::runtime_error("option value is invalid: --" + name + "=" + v);
     return (int)r;
   }
+  int integer(const std::string &name) const { return to_int(name, str(name)); }
   double real(const std::string &name) const {
     const std::string &v = str(name);
     char *end = nullptr;

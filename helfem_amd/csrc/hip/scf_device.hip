@@ -690,7 +690,7 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
   // DIIS error by symmetry blocks when every matrix in it is block diagonal (not with the CUHF constraint, whose lambda
   // comes from natural orbitals of the whole density); HELFEM_DIIS_BLOCKS=0 keeps the four dense N^3 products (checker)
   static const bool blocks_off = getenv("HELFEM_DIIS_BLOCKS") && atoi(getenv("HELFEM_DIIS_BLOCKS")) == 0;
-  const bool blocked_err = symm != 0 && dsym.size() > 1 && !rohf && !blocks_off;
+  bool blocked_err = symm != 0 && dsym.size() > 1 && !rohf && !blocks_off;
   if (blocked_err) d.blocked_error_setup(nspin, ptr, idx);
   helfem::DiisMixer mixer(true, opt.diiseps, opt.diisthr, true, verbose, (size_t)order);
   const double spinfac = restr ? 2.0 : 1.0;
@@ -802,6 +802,29 @@ helfem::scf::Result scf_device_loop(hfg_ctx *ctx, hfg_basis *hb, const helfem::s
       }
     }
     slots.push_back(slot);
+    if (blocked_err && it == 1 && opt.have_guess) {
+      // Orbitals that did not come from this loop's block eigensolve (a checkpoint made with another symmetry setting, a
+      // projection from another basis) may mix the symmetry blocks: P then has off-block parts, and so has the DIIS error,
+      // which the per-block form would drop (the reference's uDIIS works on the full matrices).  Compare the squared norm
+      // of the dense error of this first density with that of its diagonal blocks; unless they agree, the run keeps the
+      // dense products.
+      const double *Fs0[2] = {d.Fa.p, nspin == 2 ? d.Fb.p : nullptr}, *Ps0[2] = {d.Pa.p, nspin == 2 ? d.Pb.p : nullptr};
+      double *Es0[2] = {d.histE[slot].p, d.histE[slot].p + d.be.etot};
+      d.blocked_error(Fs0, Ps0, Es0);
+      d.multidot(std::vector<const double *>(1, d.histE[slot].p), d.histE[slot].p, nspin * d.be.etot, 6);
+      double dense2 = 0.0;
+      for (int sp = 0; sp < nspin; sp++) {
+        d.diis_error(sp ? d.Fb.p : d.Fa.p, sp ? d.Pb.p : d.Pa.p, d.Err.p);
+        d.multidot(std::vector<const double *>(1, d.Err.p), d.Err.p, NN, 7);
+        d.fetch(8);
+        dense2 += d.hres[7];
+      }
+      const double blocked2 = d.hres[6];
+      if (std::fabs(dense2 - blocked2) > 1e-10 * std::max(dense2, 1e-300)) {
+        blocked_err = false;
+        if (verbose) printf("The guess orbitals mix the symmetry blocks: DIIS error from the full matrices in this run\n");
+      }
+    }
     if (blocked_err) {
       const double *Fs[2] = {d.Fa.p, nspin == 2 ? d.Fb.p : nullptr}, *Ps[2] = {d.Pa.p, nspin == 2 ? d.Pb.p : nullptr};
       double *Es[2] = {d.histE[slot].p, d.histE[slot].p + d.be.etot};  // the spins' blocks one after the other

@@ -37,6 +37,8 @@ struct H5 {
   htri_t (*Lexists)(hid_t, const char *, hid_t) = nullptr;
   herr_t (*Ldelete)(hid_t, const char *, hid_t) = nullptr;
   herr_t (*Eset_auto2)(hid_t, void *, void *) = nullptr;
+  herr_t (*Eget_auto2)(hid_t, void **, void **) = nullptr;
+  herr_t (*get_libversion)(unsigned *, unsigned *, unsigned *) = nullptr;
   hid_t native_double = -1, native_int = -1, native_hbool = -1;
 };
 
@@ -89,7 +91,19 @@ H5 &h5() {
     HFG_H5(Lexists, "H5Lexists");
     HFG_H5(Ldelete, "H5Ldelete");
     HFG_H5(Eset_auto2, "H5Eset_auto2");
+    HFG_H5(Eget_auto2, "H5Eget_auto2");
+    HFG_H5(get_libversion, "H5get_libversion");
 #undef HFG_H5
+    // the prototypes above assume the 64-bit hid_t of HDF5 >= 1.10; an older library would take and return handles of the
+    // wrong width.  H5get_libversion needs no initialised library.
+    if (ok) {
+      unsigned maj = 0, min = 0, rel = 0;
+      if (api.get_libversion(&maj, &min, &rel) < 0 || maj < 1 || (maj == 1 && min < 10)) {
+        ok = false;
+        api.why += api.name + ": HDF5 " + std::to_string(maj) + "." + std::to_string(min) + "." + std::to_string(rel) +
+                   " is older than 1.10 (32-bit handles); ";
+      }
+    }
     if (ok && api.open() >= 0) {
       // the H5T_NATIVE_* macros are globals that H5open() fills in
       hid_t *d = (hid_t *)sym("H5T_NATIVE_DOUBLE_g"), *i = (hid_t *)sym("H5T_NATIVE_INT_g"), *b = (hid_t *)sym("H5T_NATIVE_HBOOL_g");
@@ -97,7 +111,6 @@ H5 &h5() {
         api.native_double = *d;
         api.native_int = *i;
         api.native_hbool = *b;
-        api.Eset_auto2(0, nullptr, nullptr);  // errors are reported through exceptions here, not printed by the library
       } else
         ok = false;
     } else
@@ -118,6 +131,22 @@ const H5 &need() {
   return a;
 }
 
+// Calls that may fail as a matter of course (a file or an entry that is not there) are made with the library's automatic
+// error printing switched off and the caller's handler restored afterwards: the process may host other HDF5 users
+// (h5py in the same interpreter), whose error reporting is theirs.  Failures come back as exceptions here.
+struct Quiet {
+  const H5 &a;
+  void *func = nullptr, *data = nullptr;
+  bool saved = false;
+  explicit Quiet(const H5 &api) : a(api) {
+    saved = a.Eget_auto2(0, &func, &data) >= 0;
+    if (saved) a.Eset_auto2(0, nullptr, nullptr);
+  }
+  ~Quiet() {
+    if (saved) a.Eset_auto2(0, func, data);
+  }
+};
+
 constexpr unsigned F_ACC_RDONLY = 0u, F_ACC_TRUNC = 2u;
 constexpr int S_SCALAR = 0;
 
@@ -125,7 +154,10 @@ struct Dataset {  // RAII: an open dataset and its dataspace
   const H5 &a;
   hid_t d = -1, s = -1;
   Dataset(const H5 &api, hid_t file, const std::string &name) : a(api) {
-    d = a.Dopen2(file, name.c_str(), 0);
+    {
+      Quiet q(a);
+      d = a.Dopen2(file, name.c_str(), 0);
+    }
     if (d < 0) throw std::runtime_error("The entry " + name + " does not exist in the checkpoint file!\n");
     s = a.Dget_space(d);
   }
@@ -150,7 +182,10 @@ bool hdf5_available(std::string *why) {
 
 Checkpoint::Checkpoint(const std::string &fname, bool write) : write_(write) {
   const H5 &a = need();
-  file_ = write ? a.Fcreate(fname.c_str(), F_ACC_TRUNC, 0, 0) : a.Fopen(fname.c_str(), F_ACC_RDONLY, 0);
+  {
+    Quiet q(a);
+    file_ = write ? a.Fcreate(fname.c_str(), F_ACC_TRUNC, 0, 0) : a.Fopen(fname.c_str(), F_ACC_RDONLY, 0);
+  }
   if (file_ < 0) throw std::runtime_error("Trying to open nonexistent or unwritable checkpoint file \"" + fname + "\"!\n");
 }
 
@@ -158,7 +193,10 @@ Checkpoint::~Checkpoint() {
   if (file_ >= 0) h5().Fclose(file_);
 }
 
-bool Checkpoint::exist(const std::string &name) const { return need().Lexists(file_, name.c_str(), 0) > 0; }
+bool Checkpoint::exist(const std::string &name) const {
+  Quiet q(need());
+  return need().Lexists(file_, name.c_str(), 0) > 0;
+}
 
 void Checkpoint::remove(const std::string &name) {
   if (!write_) throw std::runtime_error("Cannot write to checkpoint file that was opened for reading only!\n");

@@ -90,6 +90,8 @@ def test_required_and_unknown_options(hf):
 @pytest.mark.parametrize("extra,msg", [(["--Ez", "0.01"], "fields are not supported"), (["--finitenuc", "1"], "Finite nuclear"),
                                        (["--readocc", "3"], "occs.dat"), (["--primbas", "3"], "LIP primitive basis"),
                                        (["--iguess", "2"], "SAP"),
+                                       (["--iguess", "0", "--load", "x.chk"], "projection of the stored Fock matrix"),
+                                       (["--lmax", "6,x", "--mmax", "-1"], "option value is invalid: --lmax=x"),
                                        (["--method", "hyb_lda_xc_cam_lda0"], "Range separated functionals are not supported"),
                                        (["--M", "2"], "Requested multiplicity 2 with 2 electrons"),
                                        (["--method", "no_such_functional"], "")])

@@ -44,7 +44,12 @@ def main():
         res[name] = {"launches_fetch_pass": nf, "launches_write_pass": nw,
                      "fetch_bytes_per_launch_corrected_x2": fetch_b, "write_bytes_per_launch": write_b,
                      "traffic_bytes_per_launch": fetch_b + write_b}
-    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res_out = dict(res)
+    res_out["_meta"] = {"kernel_sources_sha256": bench.kernel_sources_sha(),
+                        "note": "bench.py reports `traffic` from this file only while the kernel sources still hash to this value"}
+    json.dump(res_out, open(out, "w"), indent=1, sort_keys=True)
     for k, v in res.items():
         print("%-60s %12.0f B fetch  %12.0f B write  (%d launches)" % (k[:60], v["fetch_bytes_per_launch_corrected_x2"],
                                                                        v["write_bytes_per_launch"], v["launches_fetch_pass"]))
