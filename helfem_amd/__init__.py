@@ -690,7 +690,7 @@ class DeviceSCFStep(object):
     """
 
     def __init__(self, basis, x_func, c_func, ldft, mdft, nocc, symmetry=1, device=0, rank=0, nranks=1,
-                 dens_thr=1e-12, kfrac=0.0, device_tei=False):
+                 dens_thr=1e-12, kfrac=0.0, device_tei=False, fock_shard="auto"):
         import torch
         self.torch = torch
         self.basis = basis
@@ -699,6 +699,12 @@ class DeviceSCFStep(object):
         torch.cuda.set_device(self.dev)
         self.ctx = Context(device, stream=torch.cuda.current_stream(self.dev).cuda_stream)
         self.ctx.set_shard(rank, nranks)
+        self.rank, self.nranks = int(rank), int(nranks)
+        # J + XC: "always" shards the build over the ranks ((L,|M|) channels, radial points) and all-reduces the compact
+        # buffer; "never" lets every rank build all of it.  "auto" = never: after sum factorisation the whole J + XC build
+        # takes 1.1 ms at Nbf = 4230 and 2.9 ms at 6102, less than an all-reduce of its 33 / 69 MB compact buffer over
+        # xGMI.  The exchange build (tens of ms) and the eigensolve's blocks are always sharded.
+        self.fock_shard = os.environ.get("HELFEM_FOCK_SHARD", fock_shard)  # the environment wins (tests, A/B runs)
         if device_tei:  # in-element tables (with the exchange-ordered ones when K is wanted) built on this context's device
             basis.compute_tei(float(kfrac) != 0.0, device=True, ctx=self.ctx)
         basis.upload(ldft, mdft, ctx=self.ctx)
@@ -790,8 +796,13 @@ class DeviceSCFStep(object):
         exchange_blocks(buffer, nblk) completes the per-block eigenvector slots on every rank (parallel.
         broadcast_block_slots_: one broadcast per block from its owner; None: the sum all-reduce, which the zero
         padding of the slots owned elsewhere also makes correct)"""
+        shard_fock = self.nranks > 1 and self.fock_shard == "always"
+        if self.nranks > 1 and not shard_fock:
+            self.ctx.set_shard(0, 1)  # every rank builds the whole J + XC: no collective
         self.fock_partial()
-        if allreduce is not None:
+        if self.nranks > 1 and not shard_fock:
+            self.ctx.set_shard(self.rank, self.nranks)
+        if allreduce is not None and (shard_fock or self.nranks == 1):
             allreduce(self.Fc)
             allreduce(self.scal)
         self.fock_finish()

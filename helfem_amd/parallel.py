@@ -4,8 +4,11 @@ The hot path shards naturally:
   * Coulomb: (L,|M|) channels are independent (basis.cpp:1414)      -> rank r owns channels ilm % nranks == r
   * XC: radial quadrature points are independent (dftgrid.cpp:779)  -> rank r owns points Q % nranks == r
   * eigensolve: symmetry blocks are independent (scf_helpers.cpp:148) -> rank r owns blocks ib % nranks == r
+  * exact exchange: output shells are independent (basis.cpp:1578)   -> rank r owns shells jang % nranks == r
 Each rank produces partial Fock contributions in a zero-padded buffer; one sum all-reduce of the *compact*
-(block-banded) Fock buffer completes them on every rank.  The eigenvector blocks have ONE owner each, so they are not
+(block-banded) J + XC buffer, and one of the dense exchange matrix of hybrid runs, completes them on every rank.
+DeviceSCFStep(fock_shard="auto") does not shard J + XC at all: after sum factorisation that build (1-3 ms) is cheaper than
+the all-reduce of its buffer, so every rank builds it whole; the exchange build and the eigensolve's blocks stay sharded.  The eigenvector blocks have ONE owner each, so they are not
 summed: every block slot is broadcast from its owner (all broadcasts in flight together) -- half the bytes of a sum
 all-reduce of the zero-padded buffer and no additions; ranks beyond the number of blocks own nothing and only receive.
 No other data-path collective exists.  The same functions run on CPU tensors with the gloo backend,

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(nranks, out):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HELFEM_NUM_THREADS="4")
+def _run(nranks, out, fock_shard="auto"):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HELFEM_NUM_THREADS="4", HELFEM_FOCK_SHARD=fock_shard)
     worker = os.path.join(ROOT, "tests", "multirank_worker.py")
     if nranks == 1:
         cmd = [sys.executable, worker, out]
@@ -27,8 +27,10 @@ def _run(nranks, out):
 def test_two_three_and_four_ranks_reproduce_one(native_libs, tmp_path):
     """4 ranks, 3 symmetry blocks: the fourth rank owns no block, it only receives the owners' broadcasts"""
     ref = _run(1, str(tmp_path / "r1.json"))
-    for n in (2, 3, 4):
-        got = _run(n, str(tmp_path / ("r%d.json" % n)))
+    # default policy (J + XC built whole on every rank, blocks of the eigensolve sharded) at 2, 3, 4 ranks; the sharded
+    # J + XC build with its all-reduce of the compact buffer at 2 and 3
+    for n, shard in ((2, "auto"), (3, "auto"), (4, "auto"), (2, "always"), (3, "always")):
+        got = _run(n, str(tmp_path / ("r%d%s.json" % (n, shard))), shard)
         for a, b in zip(ref, got):
             assert abs(a["exc"] - b["exc"]) < 1e-10 * abs(a["exc"])
             assert np.max(np.abs(np.array(a["E"]) - np.array(b["E"]))) < 1e-9

@@ -43,6 +43,15 @@ def _worker(rank, world, port, out):
     buf = torch.from_numpy(np.concatenate([(J + H).ravel(order="F"), [Exc, Nel]]))
     parallel.allreduce_sum_(buf)
     F_part = buf[:-2].numpy().reshape((N, N), order="F")
+    # ---- hybrid step: the exchange build shards over OUTPUT shells (jang % world == rank, basis.cpp:1578); the partial
+    # matrices have disjoint supports and sum to K ----
+    ob.compute_tei(True)
+    A = len(gb.lval)
+    mine = [(j, k) for j in parallel.owned_units(A, rank, world) for k in range(A)]
+    Kp = ob.exchange_blocks(0.5 * P, mine) if mine else np.zeros((N, N))
+    kbuf = torch.from_numpy(np.asfortranarray(Kp).ravel(order="F").copy())
+    parallel.allreduce_sum_(kbuf)
+    K_sum = kbuf.numpy().reshape((N, N), order="F")
     # ---- eigensolve: block ib on rank ib % world, zero-padded slots, ONE all-reduce, global sort ----
     S = gb.overlap()
     H0 = gb.kinetic() + gb.nuclear()
@@ -73,7 +82,7 @@ def _worker(rank, world, port, out):
     E = Eall[order]
     t = parallel.max_over_ranks(float(rank))
     if rank == 0:
-        np.savez(out, F_part=F_part, Exc=buf[-2].item(), Nel=buf[-1].item(), E=E, C=C, F=F, tmax=t)
+        np.savez(out, F_part=F_part, Exc=buf[-2].item(), Nel=buf[-1].item(), E=E, C=C, F=F, tmax=t, K_sum=K_sum)
     import torch.distributed as dist
     dist.destroy_process_group()
 
@@ -98,6 +107,9 @@ def test_sharded_step_matches_unsharded(tmp_path, native_libs, world):
     assert np.max(np.abs(res["F_part"] - (J + H))) < 1e-12 * np.max(np.abs(J + H))
     assert abs(res["Exc"] - Exc) < 1e-12 * max(1.0, abs(Exc)) and abs(res["Nel"] - Nel) < 1e-12 * max(1.0, abs(Nel))
     assert res["tmax"] == world - 1.0  # MAX over ranks of the rank id
+    ob.compute_tei(True)
+    K = ob.exchange(0.5 * P)
+    assert np.max(np.abs(res["K_sum"] - K)) <= 1e-14 * np.max(np.abs(K))  # the shards of the exchange build sum to K
     S = gb.overlap()
     X = orc.form_Sinvh(S, False, blocks)
     Eo, Co = orc.eig_gsym_sub(res["F"], X, blocks)
