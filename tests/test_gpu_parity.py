@@ -347,6 +347,17 @@ def test_tei_tables_against_the_independent_fixture(hf):
     assert __import__("common").relerr(gd.exchange(P), gh.exchange(P)) < 1e-12
 
 
+def test_device_tei_tables_at_the_bench_element_order(hf):
+    """hfg_compute_tei_dev at the headline workload's element order (15-node LIPs, 75-point quadrature, channels up to
+    L = 40) against tests/golden/diatomic_tei_p15.npz: seeded samples of the independent NumPy / mpmath restatement"""
+    import test_tei_golden_cpu as tg
+    g = np.load(tg.P15)
+    gd = tg.p15_basis(hf, g)
+    gd.compute_tei(False, device=True)
+    dev = tg.p15_errors(gd.prim_table, g, "exact")
+    assert max(v for k, v in dev.items() if not k.endswith("[0]")) < 2e-11, dev
+
+
 @pytest.mark.parametrize("env", [dict(HELFEM_TRD="twokernel"), dict(HELFEM_BT="column"),
                                  dict(HELFEM_TRD="unblocked", HELFEM_BT="column"), dict(HELFEM_TRDF_SYM="1"),
                                  dict(HELFEM_TRDF_SYM="0"), dict(HELFEM_TRDF_NTH="512", HELFEM_TRDF_SYM="1"),

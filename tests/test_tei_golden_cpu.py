@@ -157,3 +157,76 @@ def test_host_tables_match_the_fixture(gold):
 
 # measured 2e-12: the reference library's inaccuracy in Q_L^M near the nucleus barely enters the in-element tables
 REF_TEI_TOL = 1e-10
+
+
+# ---- one-electron matrices (TwoDBasis::overlap / kinetic / nuclear, basis.cpp:677-817) -------------------------------------
+def test_one_electron_matrices_against_the_independent_fixture(native_libs):
+    """S, T, V of the product's host code against tests/golden/diatomic_onebody.npz (oracle/diatomic_onebody.py: NumPy, no
+    product code, angular couplings from the cos(theta) recurrence instead of Gaunt tables)"""
+    import helfem_amd as hf
+    g = np.load(os.path.join(ROOT, "tests", "golden", "diatomic_onebody.npz"))
+    gb = hf.TwoDBasis(int(g["case/Z1"]), int(g["case/Z2"]), 0.5 * float(g["case/Rbond"]), int(g["case/nnodes"]), int(g["case/nquad"]),
+                      g["bval"], [int(x) for x in g["lval"]], [int(x) for x in g["mval"]], 10)
+    for name, got in (("S", gb.overlap()), ("T", gb.kinetic()), ("V", gb.nuclear())):
+        ref = g[name]
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) < 5e-15 * np.max(np.abs(ref)), name
+
+
+def test_independent_one_electron_restatement_reproduces_h2plus():
+    """the restatement itself against a known answer: ground state of H2+ at R = 2 a0, E_el = -1.1026342144949 Eh
+    [external literature, e.g. Madsen & Peek 1971]; sigma shells up to l = 8, 4 x 10 nodes: basis limit to 2e-10"""
+    import scipy.linalg as sl
+    import diatomic_onebody as ob
+    import diatomic_tei as dt
+    lval, mval = dt.lm_to_l_m([8])
+    bval = dt.get_grid_exp(float(np.arccosh(40.0)), 4, 1.0)
+    S, T, V = ob.one_electron(1, 1, 1.0, bval, 10, 50, lval, mval)
+    assert abs(sl.eigh(T + V, S, eigvals_only=True)[0] - (-1.1026342144949)) < 5e-10
+
+
+# ---- the bench workload's element order: 15-node LIPs, 75-point quadrature, channels up to L = 40 ---------------------------
+P15 = os.path.join(ROOT, "tests", "golden", "diatomic_tei_p15.npz")
+
+
+def p15_errors(get, g, which):
+    """largest relative deviation (per table, relative to the table's largest sampled entry) of the sampled entries and of
+    the disjoint tables; the disjoint Q tables of element 0 are reported apart (see table_errors)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_tei_golden_p15 as mk
+    lm = [tuple(int(v) for v in x) for x in g["lm_map"]]
+    worst = {}
+    for (L, M) in [tuple(int(v) for v in x) for x in g["channels"]]:
+        ilm = lm.index((L, M))
+        for iel in range(len(g["bval"]) - 1):
+            for tag in ("P0", "P2", "Q0", "Q2"):
+                ref = g["%s/%s/%d/%d" % (which, tag, ilm, iel)]
+                a = get(tag, ilm, iel)
+                key = tag + "[0]" if (tag[0] == "Q" and iel == 0) else tag
+                worst[key] = max(worst.get(key, 0.0), float(np.max(np.abs(a - ref)) / np.max(np.abs(ref))))
+            for tag, (k, l) in (("00", (0, 0)), ("02", (0, 2)), ("20", (2, 0)), ("22", (2, 2))):
+                ref = g["%s/tei%s/%d/%d" % (which, tag, ilm, iel)]
+                t = get("tei" + tag, ilm, iel)
+                ii, jj = mk.sample_indices(t.shape[0], 1000 * ilm + 10 * iel + k + l // 2)
+                worst["tei" + tag] = max(worst.get("tei" + tag, 0.0), float(np.max(np.abs(t[ii, jj] - ref)) / np.max(np.abs(ref))))
+                nrm = float(g["%s/tei%s_norm/%d/%d" % (which, tag, ilm, iel)])
+                worst["norm" + tag] = max(worst.get("norm" + tag, 0.0), abs(float(np.linalg.norm(t)) - nrm) / nrm)
+    return worst
+
+
+def p15_basis(hf, g, **kw):
+    return hf.TwoDBasis(int(g["case/Z1"]), int(g["case/Z2"]), 0.5 * float(g["case/Rbond"]), int(g["case/nnodes"]), int(g["case/nquad"]),
+                        g["bval"], [int(x) for x in g["lval"]], [int(x) for x in g["mval"]], int(g["case/lpad"]), **kw)
+
+
+def test_host_tables_at_the_bench_element_order(native_libs):
+    """p = 15, nquad = 75, L up to 40: the high-order quadrature of the headline workload against the independent samples"""
+    import helfem_amd as hf
+    g = np.load(P15)
+    gb = p15_basis(hf, g)
+    assert gb.lm_map() == [tuple(int(v) for v in x) for x in g["lm_map"]]
+    gb.compute_tei(False)
+    exact = p15_errors(gb.prim_table, g, "exact")
+    assert max(v for k, v in exact.items() if not k.endswith("[0]")) < 2e-11, exact
+    ref = p15_errors(gb.prim_table, g, "ref")
+    assert max(v for k, v in ref.items() if not k.endswith("[0]")) < 1e-6, ref  # the reference Legendre library's own accuracy
