@@ -17,11 +17,11 @@ one_workload () {   # $1 = workload, $2 = suffix of the output names
   $PY bench.py --workload $W --steps 5 --warmup 1 > $OUT/bench$S.json 2> $OUT/bench$S.err
   cat $OUT/bench$S.json
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats$S -o stats -- $PY $REPO/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats$S.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats$S -o stats -- $PY $REPO/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats$S.log 2>&1 || echo "(rocprofv3 exit status $? -- its reports are written before the profiled process exits)"
   echo "stats $W done"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch$S -o fetch -- $PY $REPO/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_fetch$S.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch$S -o fetch -- $PY $REPO/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_fetch$S.log 2>&1 || echo "(rocprofv3 exit status $?)"
   echo "fetch $W done"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write$S -o write -- $PY $REPO/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write$S.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write$S -o write -- $PY $REPO/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_write$S.log 2>&1 || echo "(rocprofv3 exit status $?)"
   echo "write $W done"
   cd $REPO
   $PY tools/pmc_traffic.py $OUT/pmc_fetch$S $OUT/pmc_write$S $OUT/pmc_traffic$S.json k_trd k_coulomb_tei k_backtransform k_dgemm k_exl > $OUT/pmc_traffic$S.txt
