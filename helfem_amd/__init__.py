@@ -23,7 +23,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libhelfem_amd.so")
+_LIB_PATH = os.environ.get("HELFEM_AMD_LIB") or os.path.join(_HERE, "lib", "libhelfem_amd.so")  # HELFEM_AMD_LIB: A/B builds (tools/ab_build.py)
 _lib = None
 
 c_double_p = ctypes.POINTER(ctypes.c_double)

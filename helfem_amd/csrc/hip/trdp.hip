@@ -60,6 +60,7 @@ struct TrdpDesc {
   int *status;                      // 1: a spin ran into its limit (poisoned to -1 before the launch)
   unsigned long long *stamps;       // measurement only (nullptr in the product path): 4 wall-clock stamps per column
   long long spin_limit;             // wall-clock ticks (100 MHz)
+  long long win_off;                // measurement only: offset (words) of the all-workgroup stamp window in stamps
 };
 
 __device__ __forceinline__ unsigned long long tp_load(const gu64 *p) {
@@ -81,6 +82,24 @@ __device__ __forceinline__ double tp_wsum(double v) {
 // row z: everything the threads of a workgroup tell each other goes through LDS, and words of the exchange that are
 // written twice (poison, then data) are written by the SAME thread both times, so no barrier has to order them.
 #define TP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// A/B switches (tools/ab_build.py builds variant libraries with -D...; compile time, because a run-time switch inside the
+// loop costs registers).  Defaults = the measured best.
+#ifndef TP_Z_BY_ROW
+#define TP_Z_BY_ROW 0  // 1: the owner of row j+2 publishes the whole row (staged through LDS) instead of every workgroup its entries of column j+2
+#endif
+#ifndef TP_FLAG_FIRST
+#define TP_FLAG_FIRST 0  // 1: a thread that misses a word of y watches its producer's dot word before it re-reads the word
+#endif
+
+// stamps of EVERY workgroup for a window of columns (measurement kernel only): wg x TP_WIN_N columns x 4 stamps behind the
+// per-column stamps of the observed workgroup
+constexpr int TP_WIN_0 = 400, TP_WIN_N = 64;
+#define TP_WIN_STAMP(idx)                                                                                              \
+  if constexpr (STAMPS) {                                                                                              \
+    if (tid == 0 && (unsigned)(j1 - TP_WIN_0) < (unsigned)TP_WIN_N)                                                      \
+      ((gu64 *)D.stamps)[D.win_off + ((size_t)blockIdx.x * TP_WIN_N + (j1 - TP_WIN_0)) * 4 + (idx)] = wall_clock64(); \
+  }
 
 template <int R, int U, bool STAMPS>
 __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp) {
@@ -117,6 +136,13 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = tid & (TP_NCG - 1), rg = tid >> 7;
   const int row0 = k * M + rg * R;  // first row of this thread
+  if constexpr (STAMPS) {
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      ((gu64 *)D.stamps)[D.win_off + (size_t)TP_MAXG * TP_WIN_N * 4 + blockIdx.x] = xcc & 15u;
+    }
+  }
   if (k * M >= n) return;
 
   // ---- registers: a[i][u] = A(row0 + i, cg + 128 u); the lower triangle is the input (LAPACK uplo = 'L') ----
@@ -131,8 +157,17 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       if (r < n && c < n) v = (r >= c) ? A[(size_t)c * n + r] : A[(size_t)r * n + c];
       a[i][u] = v;
     }
-    // a few column chunks at a time: with every load of the tile in flight their 64-bit addresses alone cost 2 R U registers
+    // a few column chunks at a time: with every load of the tile in flight their 64-bit addresses alone cost 2 R U registers.
+    // Inline assembly ON PURPOSE: the compiler's wait-count bookkeeping does not see it, believes the tile still in flight
+    // on entry to the main loop and puts an s_waitcnt vmcnt(0) in front of the first use of a tile register there -- at the
+    // top of every pass, in front of the register update.  That wait retires the first attempt's loads and the publishing
+    // wave's write-through stores before the update instead of in front of the poll behind it, and measures 4 % FASTER than
+    // the precise bookkeeping the builtin gives (-DTP_BUILTIN_WAIT: 5.69 against 5.47 ms at 1380/1470/1380).
+#ifdef TP_BUILTIN_WAIT
+    if ((u & 3) == 3 || u == U - 1) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#else
     if ((u & 3) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   }
   for (int r = tid; r < NL; r += TP_NT) {
     X[r] = 0.0;
@@ -182,9 +217,32 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       }
     }
     // =============== row j+2 for exchange j+1, one exchange AHEAD of the products ===============
-    // The registers now hold A^(j) (every update up to column j-1).  The owner of row j+2 publishes it RAW; the
-    // consumers apply the update of column j themselves (z = raw - v_j[j+2] w_j - w_j[j+2] v_j: they know v_j and w_j
-    // in full by then), so this row never sits on the critical path of a column.
+    // The registers now hold A^(j) (every update up to column j-1).  Row j+2 is published RAW; the consumers apply the
+    // update of column j themselves (z = raw - v_j[j+2] w_j - w_j[j+2] v_j: they know v_j and w_j in full by then), so
+    // this row never sits on the critical path of a column.  It is published as COLUMN j+2 of the symmetric tile, every
+    // workgroup the entries of its own rows (2 R stores in four threads): with the owner of row j+2 publishing the whole
+    // row, that workgroup -- the first one that still owns rows -- was the last to publish its y in nine columns of ten
+    // (all-workgroup stamps, tools/trdp_window.py) and every other one waited for it.
+#if !TP_Z_BY_ROW
+    if (j < n - 3 && cg == (j2 & (TP_NCG - 1))) {
+      // the tile is symmetric (up to the rounding of the two orders of its update): row j+2 is column j+2, and of that every
+      // workgroup holds the entries of its own rows in the four threads (one per row group) of column group (j+2) % 128
+      const int uz = j2 / TP_NCG;
+      double zv[R];
+#pragma unroll
+      for (int i = 0; i < R; i++) zv[i] = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (u == uz) {
+#pragma unroll
+          for (int i = 0; i < R; i++) zv[i] = a[i][u];
+        }
+      gu64 *zcol = xb + (size_t)(j1 & (TP_SLOTS - 1)) * slotw + ZOFF;
+#pragma unroll
+      for (int i = 0; i < R; i++)
+        if (row0 + i < n) tp_store(zcol + row0 + i, tp_bits(zv[i]));
+    }
+#else
     if (j < n - 3 && k == j2 / M) {
       // staged through LDS so that ALL threads store (three words each, the same thread that poisoned the word): the
       // workgroup that owns the row is also the one every other workgroup ends up waiting for
@@ -205,6 +263,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       for (int h = 0; h < EPT; h++)
         if (tid + TP_NT * h < NP) tp_store(zrow + tid + TP_NT * h, tp_bits(ZS[tid + TP_NT * h]));
     }
+#endif
     double pc1 = 0.0, pc2 = 0.0, ps = 0.0;  // partial sums for the next column
     if (j >= 0) {
       // =============== exchange j: wait for y (rows >= j+1), raw z (columns >= j+1), dots ===============
@@ -221,6 +280,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       if constexpr (STAMPS) {
         if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 3] = wall_clock64();
       }
+      TP_WIN_STAMP(3)
       // (the first attempt was issued at the end of the previous pass, behind the partial sums: its round trip, 0.45 us,
       // runs under the scalars of this column, the register update and the row z)
       {
@@ -252,7 +312,11 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
 #pragma unroll
           for (int h = 0; h < EPT; h++) {
             const int r = min(j1 + tid + TP_NT * h, n - 1);
+#if TP_FLAG_FIRST
             if (yb[h] == TP_SENT && tp_load(sb + DOFF + r / M) != TP_SENT) yb[h] = tp_load(sb + r);
+#else
+            if (yb[h] == TP_SENT) yb[h] = tp_load(sb + r);
+#endif
             if (zb[h] == TP_SENT) zb[h] = tp_load(sb + ZOFF + r);
           }
           if (dd == TP_SENT) dd = tp_load(sb + DOFF + kd);
@@ -278,6 +342,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       if constexpr (STAMPS) {
         if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 0] = wall_clock64();
       }
+      TP_WIN_STAMP(0)
       // ---- scalars, redundantly in every wave (fixed orders: bitwise the same in every workgroup) ----
       double dsum = (dots[lane] + dots[lane + 64]) + (dots[lane + 128] + dots[lane + 192]);
       dsum = wave_sum(dsum);
@@ -289,8 +354,10 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       const double w0 = ts * (q0 - beta * zz0) + aa;
       // ---- element-wise: v_j, w_j, x_{j+1} (rolled: the register tile needs the room) ----
       const int own0 = k * M;
-#pragma unroll 1
-      for (int r = j1 + tid; r < n; r += TP_NT) {
+#pragma unroll
+      for (int h = 0; h < EPT; h++) {  // (unrolled: the LDS round trips of the EPT elements overlap; 2 % of the column)
+        const int r = j1 + tid + TP_NT * h;
+        if (r >= n) continue;
         const double vpo = VP[r], wpo = WP[r];
         const double z = ZL[r] - vz * wpo - wz * vpo;  // row j+1 with the update of column j-1 applied
         const double q = YL[r] - vpo * c1 - wpo * c2;
@@ -321,6 +388,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
     if constexpr (STAMPS) {
       if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 1] = wall_clock64();
     }
+    TP_WIN_STAMP(1)
     if (j == n - 3) break;  // the last column has no successor to prepare
 
     // =============== publish exchange j+1: rows of the product with x_{j+1} ===============
@@ -369,12 +437,22 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
     if constexpr (STAMPS) {
       if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 2] = wall_clock64();
     }
+    TP_WIN_STAMP(2)
     // the row of exchange j+3 is published (raw, see above) at the top of pass j+2 by the owner of row j+4: that
     // workgroup poisons the words now
+#if !TP_Z_BY_ROW
+    if (j + 4 < n && cg == ((j + 4) & (TP_NCG - 1))) {  // the threads that will store these words at the top of pass j+2
+      gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
+#pragma unroll
+      for (int i = 0; i < R; i++)
+        if (row0 + i < n) tp_store(sb3 + ZOFF + row0 + i, TP_SENT);
+    }
+#else
     if (j + 4 < n && (j + 4) / M == k) {
       gu64 *sb3 = xb + (size_t)((j + 3) & (TP_SLOTS - 1)) * slotw;
       for (int c = tid; c < NP; c += TP_NT) tp_store(sb3 + ZOFF + c, TP_SENT);
     }
+#endif
     // =============== off the critical path: z of exchange j+1 (published at the top of this pass), partial sums and
     // scalars of column j+1 ===============
 #pragma unroll
@@ -444,7 +522,7 @@ struct TrdpWork {
   bool pending = false;
   int ncu = 0;
   std::vector<int> last_ns;
-  int last_R = 0, last_U = 0, last_grid = 0;
+  int last_R = 0, last_U = 0, last_grid = 0, last_nmax = 0;
 };
 static std::map<hfg_ctx *, TrdpWork *> g_trdp;
 
@@ -497,6 +575,21 @@ void trdp_check_status(hfg_ctx *ctx) {
                 (double)(st[(size_t)i * 8 + 1] - st[(size_t)i * 8]) * 0.01, (double)(st[(size_t)i * 8 + 2] - st[(size_t)i * 8 + 1]) * 0.01, (double)(st[(size_t)i * 8 + 5] - st[(size_t)i * 8 + 3]) * 0.01,
                 st[(size_t)i * 8 + 4] & 0xffff, (st[(size_t)i * 8 + 4] >> 16) & 0xffff, (st[(size_t)i * 8 + 4] >> 32) & 0xffff);
     }
+    if (getenv("HELFEM_TRDP_STAMPS_FILE")) {
+      // all workgroups, columns TP_WIN_0 .. TP_WIN_0 + TP_WIN_N: raw 100 MHz stamps (landed, element-wise done, published, poll start)
+      std::vector<unsigned long long> win((size_t)TP_MAXG * TP_WIN_N * 4 + TP_MAXG);
+      HFG_HIP_CHECK(hipMemcpy(win.data(), w.stamps.p + (size_t)8 * (w.last_nmax + 2), win.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(getenv("HELFEM_TRDP_STAMPS_FILE"), "w")) {
+        fprintf(f, "# grid %d R %d U %d first column %d columns %d; per line: workgroup column landed elementwise_done published poll_start\n", w.last_grid, w.last_R,
+                w.last_U, TP_WIN_0, TP_WIN_N);
+        for (int g = 0; g < w.last_grid; g++)
+          for (int c = 0; c < TP_WIN_N; c++) {
+            const unsigned long long *q = &win[((size_t)g * TP_WIN_N + c) * 4];
+            fprintf(f, "%d %d %llu %llu %llu %llu %llu\n", g, TP_WIN_0 + c, q[0], q[1], q[2], q[3], win[(size_t)TP_MAXG * TP_WIN_N * 4 + g]);
+          }
+        fclose(f);
+      }
+    }
     if (cnt)
       fprintf(stderr, "k_trdp stamps (n = %d, R = %d, U = %d, grid %d; us per column over %d columns): column %.3f = sums+scalars+update %.3f | poll %.3f | scalars+element-wise %.3f | product+publish %.3f\n",
               n0, w.last_R, w.last_U, w.last_grid, cnt, total / cnt * 0.01, post / cnt * 0.01, wait / cnt * 0.01, elem / cnt * 0.01, pub / cnt * 0.01);
@@ -513,6 +606,7 @@ static trdp_kernel_t trdp_pick(int R, int U, bool stamps) {
   if (R == r && U == u) return stamps ? trdp_kernel<r, u, true>() : trdp_kernel<r, u, false>();
   TP_CASE(1, 6) TP_CASE(2, 6) TP_CASE(3, 6) TP_CASE(4, 6) TP_CASE(6, 6)
   TP_CASE(2, 12) TP_CASE(3, 12) TP_CASE(4, 12) TP_CASE(5, 12) TP_CASE(6, 12)
+  TP_CASE(2, 16) TP_CASE(3, 16) TP_CASE(4, 16)
   TP_CASE(2, 17) TP_CASE(3, 17) TP_CASE(4, 17)
 #undef TP_CASE
   return nullptr;
@@ -520,8 +614,11 @@ static trdp_kernel_t trdp_pick(int R, int U, bool stamps) {
 static const int tp_rows_choices[] = {1, 2, 3, 4, 5, 6};
 /// column chunks per thread for matrices up to this order (0: beyond the register tiles)
 static int tp_columns_for(int nmax) {
+  static const int force = getenv("HELFEM_TRDP_U") ? atoi(getenv("HELFEM_TRDP_U")) : 0;  // measurement: a wider tile than needed
+  if (force && nmax <= force * TP_NCG) return force;
   if (nmax <= 6 * TP_NCG) return 6;
   if (nmax <= 12 * TP_NCG) return 12;
+  if (nmax <= 16 * TP_NCG) return 16;  // (4, 16) holds its tile without spilling, (4, 17) does not quite: LiF's 2001-blocks
   if (nmax <= 17 * TP_NCG) return 17;
   return 0;
 }
@@ -648,13 +745,15 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     ring_words = std::max(ring_words, words);
   }
   w.ring.resize(ring_words);  // the groups run one after the other on the stream and share the ring
-  if (want_stamps) w.stamps.resize((size_t)8 * (nmax_all + 2));
+  const size_t win_off = (size_t)8 * (nmax_all + 2);
+  if (want_stamps) w.stamps.resize(win_off + (size_t)TP_MAXG * TP_WIN_N * 4 + TP_MAXG);
   static const long long limit_ms = getenv("HELFEM_TRDP_LIMIT_MS") ? atoll(getenv("HELFEM_TRDP_LIMIT_MS")) : 200;
   for (size_t q = 0; q < groups.size(); q++) {
     TrdpDesc &D = descs[q];
     for (int b = 0; b < D.nblk; b++) D.xb[b] = w.ring.p + (size_t)D.xb[b];
     D.status = (int *)w.ring.p;
     D.stamps = want_stamps ? w.stamps.p : nullptr;
+    D.win_off = (long long)win_off;
     D.spin_limit = limit_ms * 100000ll;  // 100 MHz wall clock
   }
   hipStream_t s = ctx->stream;
@@ -690,6 +789,7 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
       w.last_R = g.R;
       w.last_U = g.U;
       w.last_grid = g.grid;
+      w.last_nmax = nmax_all;
     }
   }
 }
