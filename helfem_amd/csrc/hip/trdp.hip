@@ -48,6 +48,7 @@ constexpr int TP_NCG = 128;              // column groups: thread (rg, cg) holds
 constexpr int TP_NRG = TP_NT / TP_NCG;   // row groups
 constexpr int TP_NW = TP_NT / 64;
 constexpr int TP_SLOTS = 4;
+constexpr int TP_MAXLAUNCH = 64;         // launches (groups x phases) of one batch
 constexpr int TP_MAXG = 256;             // workgroups per matrix (landing area of the dot words)
 constexpr unsigned long long TP_SENT = ~0ull;
 
@@ -55,6 +56,8 @@ struct TrdpDesc {
   int nblk;
   int wg0[TP_MAXB + 1];  // first workgroup of every matrix
   int n[TP_MAXB], G[TP_MAXB];
+  int lda[TP_MAXB];    // leading dimension of A (a launch may work on the trailing part of a larger matrix)
+  int jstop[TP_MAXB];  // columns this launch reduces before it writes the trailing matrix back and ends (>= n - 2: all)
   double *A[TP_MAXB], *d[TP_MAXB], *e[TP_MAXB], *tau[TP_MAXB];
   unsigned long long *xb[TP_MAXB];  // exchange ring: TP_SLOTS x (y: NP + 64 | z: NP | dots: TP_MAXG) words
   int *status;                      // 1: a spin ran into its limit (poisoned to -1 before the launch)
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   int blk = 0;
   while (blk + 1 < D.nblk && (int)blockIdx.x >= D.wg0[blk + 1]) blk++;
   const int k = (int)blockIdx.x - D.wg0[blk];
-  const int n = D.n[blk], G = D.G[blk];
+  const int n = D.n[blk], G = D.G[blk], lda = D.lda[blk], jstop = D.jstop[blk];
   gdouble *A = (gdouble *)D.A[blk];
   gdouble *dw = (gdouble *)D.d[blk], *ew = (gdouble *)D.e[blk], *tauw = (gdouble *)D.tau[blk];
   gu64 *xb = (gu64 *)D.xb[blk];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
     for (int i = 0; i < R; i++) {
       const int r = row0 + i;
       double v = 0.0;
-      if (r < n && c < n) v = (r >= c) ? A[(size_t)c * n + r] : A[(size_t)r * n + c];
+      if (r < n && c < n) v = (r >= c) ? A[(size_t)c * lda + r] : A[(size_t)r * lda + c];
       a[i][u] = v;
     }
     // a few column chunks at a time: with every load of the tile in flight their 64-bit addresses alone cost 2 R U registers.
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
   unsigned long long zb[EPT], yb[EPT], dd = TP_SENT;  // words of the NEXT exchange, first fetched at the end of a pass
 #pragma unroll
   for (int h = 0; h < EPT; h++) zb[h] = yb[h] = TP_SENT;
+  const int jlast = min(n - 3, jstop - 1);  // last column this launch reduces
   int j = -1;
   for (;; j++) {
     const int j1 = j + 1, j2 = j + 2;
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
           pc1 += wn * xn;
           pc2 += vn * xn;
           if (r > j2) ps += xn * xn;
-          if ((unsigned)(r - own0) < (unsigned)M) A[(size_t)j * n + r] = vn;  // reflector for the back-transformation (LAPACK layout)
+          if ((unsigned)(r - own0) < (unsigned)M) A[(size_t)j * lda + r] = vn;  // reflector for the back-transformation (LAPACK layout)
         }
         X[r] = xn;
         VP[r] = vn;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       if (blk == 0 && k == G - 1 && tid == 0) ((gu64 *)D.stamps)[(size_t)j1 * 8 + 1] = wall_clock64();
     }
     TP_WIN_STAMP(1)
-    if (j == n - 3) break;  // the last column has no successor to prepare
+    if (j == jlast) break;  // the last column of the matrix (no successor to prepare) or of this phase
 
     // =============== publish exchange j+1: rows of the product with x_{j+1} ===============
     // (registers still lack the update of column j; X is zero on reduced columns)
@@ -491,6 +495,33 @@ __global__ __launch_bounds__(TP_NT) void k_trdp(const TrdpDesc *__restrict__ dp)
       }
     }
   }
+  if (jlast != n - 3) {
+    // ---- end of a phase (tridiagonalize_persistent): column j is reduced, v_j and w_j are in LDS; with their update the
+    // registers hold the trailing matrix A^(j+1), whose lower triangle goes back to memory: the next launch takes it up
+    // as a matrix of order n - j - 1, with the tile shape that fits THAT order ----
+    // (the indices go through a value the compiler cannot see through: the 2 U address registers of these stores are
+    // then computed HERE and not hoisted above the main loop, where they cost the 5 x 12 tile 33 registers)
+    int opq;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+    const int cgo = cg + opq, row0o = row0 + opq;
+    double vr[R], wr[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      vr[i] = VP[row0o + i];
+      wr[i] = WP[row0o + i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int c = cgo + TP_NCG * u;
+      const double vc = VP[c], wc = WP[c];
+#pragma unroll
+      for (int i = 0; i < R; i++) {
+        const int r = row0o + i;
+        if (c > j && r >= c && r < n) A[(size_t)c * lda + r] = fma(-wr[i], vc, fma(-vr[i], wc, a[i][u]));
+      }
+    }
+    return;
+  }
   // ---- last column done: e[n-2] is the one element of x_{n-2}; d[n-1] from the registers of the last row, which lack the
   // update of column n-3 ----
   const int rl = n - 1;
@@ -542,7 +573,7 @@ void trdp_check_status(hfg_ctx *ctx) {
   TrdpWork &w = *it->second;
   w.pending = false;
   bool bad = false;
-  for (int q = 0; q < 16; q++) {
+  for (int q = 0; q < TP_MAXLAUNCH; q++) {
     bad = bad || w.h_status[q] == 1;
     w.h_status[q] = -1;
   }
@@ -601,34 +632,51 @@ template <int R, int U, bool STAMPS>
 static trdp_kernel_t trdp_kernel() {
   return k_trdp<R, U, STAMPS>;
 }
+/// the tile shapes compiled (rows per thread x column chunks per thread); the stamping variants only where they are used
 static trdp_kernel_t trdp_pick(int R, int U, bool stamps) {
 #define TP_CASE(r, u) \
+  if (R == r && U == u) return trdp_kernel<r, u, false>();
+#define TP_CASE_S(r, u) \
   if (R == r && U == u) return stamps ? trdp_kernel<r, u, true>() : trdp_kernel<r, u, false>();
-  TP_CASE(1, 6) TP_CASE(2, 6) TP_CASE(3, 6) TP_CASE(4, 6) TP_CASE(6, 6)
-  TP_CASE(2, 12) TP_CASE(3, 12) TP_CASE(4, 12) TP_CASE(5, 12) TP_CASE(6, 12)
-  TP_CASE(2, 16) TP_CASE(3, 16) TP_CASE(4, 16)
-  TP_CASE(2, 17) TP_CASE(3, 17) TP_CASE(4, 17)
+#ifdef TP_QUICK  // compile experiments
+  TP_CASE_S(5, 12) TP_CASE(3, 8) TP_CASE(2, 4)
+#else
+  TP_CASE(1, 2) TP_CASE(2, 2) TP_CASE(3, 2) TP_CASE(4, 2)
+  TP_CASE(1, 4) TP_CASE(2, 4) TP_CASE(3, 4) TP_CASE(4, 4) TP_CASE(5, 4) TP_CASE(6, 4)
+  TP_CASE(1, 6) TP_CASE_S(2, 6) TP_CASE(3, 6) TP_CASE(4, 6) TP_CASE(5, 6) TP_CASE(6, 6)
+  TP_CASE(1, 8) TP_CASE(2, 8) TP_CASE_S(3, 8) TP_CASE(4, 8) TP_CASE(5, 8) TP_CASE(6, 8)
+  TP_CASE(1, 10) TP_CASE(2, 10) TP_CASE(3, 10) TP_CASE(4, 10) TP_CASE(5, 10) TP_CASE(6, 10)
+  TP_CASE(1, 12) TP_CASE_S(2, 12) TP_CASE(3, 12) TP_CASE(4, 12) TP_CASE_S(5, 12) TP_CASE(6, 12)
+  TP_CASE(1, 14) TP_CASE(2, 14) TP_CASE(3, 14) TP_CASE(4, 14)
+  TP_CASE(2, 16) TP_CASE(3, 16) TP_CASE_S(4, 16)
+  TP_CASE(2, 17) TP_CASE_S(3, 17) TP_CASE(4, 17)
+#endif
 #undef TP_CASE
+#undef TP_CASE_S
   return nullptr;
 }
 static const int tp_rows_choices[] = {1, 2, 3, 4, 5, 6};
+static const int tp_widths[] = {2, 4, 6, 8, 10, 12, 14, 16, 17};
 /// column chunks per thread for matrices up to this order (0: beyond the register tiles)
 static int tp_columns_for(int nmax) {
   static const int force = getenv("HELFEM_TRDP_U") ? atoi(getenv("HELFEM_TRDP_U")) : 0;  // measurement: a wider tile than needed
   if (force && nmax <= force * TP_NCG) return force;
-  if (nmax <= 6 * TP_NCG) return 6;
-  if (nmax <= 12 * TP_NCG) return 12;
-  if (nmax <= 16 * TP_NCG) return 16;  // (4, 16) holds its tile without spilling, (4, 17) does not quite: LiF's 2001-blocks
-  if (nmax <= 17 * TP_NCG) return 17;
+  for (int u : tp_widths)
+    if (nmax <= u * TP_NCG) return u;
   return 0;
 }
 
 /// Persistent path of tridiagonalize_batch.  The matrices are dealt into GROUPS that each fit the chip's register file
-/// (one cooperative launch per group, one after the other on the stream: the three blocks 1380/1470/1380 of the bench
-/// workload are one group, the blocks 2100/2001/2001 of the LiF sizing two -- {2100} and {2001, 2001}).  done[i] says
-/// which matrices were factorised; the caller runs its chain of launches on the others (order beyond the register
-/// tiles, the runtime refusing a cooperative launch, HELFEM_TRD selecting another variant: nothing is touched then).
-/// Same outputs as the chain: d, e, tau, reflectors below the subdiagonal.
+/// (the three blocks 1380/1470/1380 of the bench workload are one group, the blocks 2100/2001/2001 of the LiF sizing two
+/// -- {2100} and {2001, 2001}), and a group is reduced in PHASES, one cooperative launch each, one after the other on the
+/// stream: a launch reduces the leading columns until the largest trailing matrix fits the next narrower tile, writes
+/// the trailing matrices back, and the next launch takes them up as matrices of their own -- fewer column chunks AND fewer
+/// rows per thread, all workgroups busy again.  (The time of a column follows the tile width the kernel is compiled
+/// for: 2.55 / 3.21 / 3.41 us per column for the same 700-row matrices with 6 / 12 / 16 chunks; a phase boundary costs a
+/// launch and one pass over the trailing matrix, some 20 us.)  done[i] says which matrices were factorised; the caller
+/// runs its chain of launches on the others (order beyond the register tiles, the runtime refusing a cooperative
+/// launch, HELFEM_TRD selecting another variant: nothing is touched then).  Same outputs as the chain: d, e, tau,
+/// reflectors below the subdiagonal.
 void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
                                double *const *tau, std::vector<char> &done) {
   done.assign(nblk, 0);
@@ -642,8 +690,8 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     wp = new TrdpWork();
     g_trdp[ctx] = wp;
     HFG_HIP_CHECK(hipDeviceGetAttribute(&wp->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    HFG_HIP_CHECK(hipHostMalloc((void **)&wp->h_status, 64, hipHostMallocDefault));
-    for (int i = 0; i < 16; i++) wp->h_status[i] = -1;
+    HFG_HIP_CHECK(hipHostMalloc((void **)&wp->h_status, TP_MAXLAUNCH * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < TP_MAXLAUNCH; i++) wp->h_status[i] = -1;
   } else
     wp = it->second;
   TrdpWork &w = *wp;
@@ -653,14 +701,15 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   }
   static const int forceR = getenv("HELFEM_TRDP_R") ? atoi(getenv("HELFEM_TRDP_R")) : 0;
   static const bool want_stamps = getenv("HELFEM_TRDP_STAMPS") && atoi(getenv("HELFEM_TRDP_STAMPS")) != 0;
+  static const bool phases = !(getenv("HELFEM_TRDP_PHASES") && atoi(getenv("HELFEM_TRDP_PHASES")) == 0);
+  static const int min_step = getenv("HELFEM_TRDP_STEP") ? std::max(1, atoi(getenv("HELFEM_TRDP_STEP"))) : 96;
   // ---- plan: largest matrices first; a matrix joins the current group while the group still fits ----
-  struct Group {
-    std::vector<int> idx;
+  struct Shape {
     int R = 0, U = 0, grid = 0;
   };
-  auto fit = [&](const std::vector<int> &idx, Group &g) -> bool {
+  auto fit = [&](const std::vector<int> &orders, Shape &g) -> bool {
     int nmax = 0;
-    for (int i : idx) nmax = std::max(nmax, ns[i]);
+    for (int o : orders) nmax = std::max(nmax, o);
     const int U = tp_columns_for(nmax);
     if (U == 0) return false;
     for (int r : tp_rows_choices) {
@@ -668,13 +717,12 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
       if (!trdp_pick(r, U, false)) continue;
       int grid = 0;
       bool ok = true;
-      for (int i : idx) {
-        const int G = (ns[i] + TP_NRG * r - 1) / (TP_NRG * r);
+      for (int o : orders) {
+        const int G = (o + TP_NRG * r - 1) / (TP_NRG * r);
         ok = ok && G <= TP_MAXG;
         grid += G;
       }
       if (ok && grid <= w.ncu) {
-        g.idx = idx;
         g.R = r;
         g.U = U;
         g.grid = grid;
@@ -687,69 +735,108 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   for (int i = 0; i < nblk; i++)
     if (ns[i] >= 3 && ns[i] >= min_order) order.push_back(i);
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ns[x] > ns[y]; });
-  std::vector<Group> groups;
+  std::vector<std::vector<int>> groups;
   {
-    std::vector<int> cur;
-    Group g;
+    std::vector<int> cur, cur_orders;
     for (int i : order) {
-      std::vector<int> trial = cur;
-      trial.push_back(i);
-      Group t;
+      std::vector<int> trial = cur_orders;
+      trial.push_back(ns[i]);
+      Shape t;
       if (fit(trial, t)) {
-        cur = trial;
-        g = t;
+        cur.push_back(i);
+        cur_orders = trial;
       } else {
-        if (!cur.empty()) groups.push_back(g);
+        if (!cur.empty()) groups.push_back(cur);
         cur.clear();
-        Group one;
-        if (fit(std::vector<int>(1, i), one)) {
+        cur_orders.clear();
+        if (fit(std::vector<int>(1, ns[i]), t)) {
           cur.assign(1, i);
-          g = one;
+          cur_orders.assign(1, ns[i]);
         }  // else: this matrix stays with the chain
       }
     }
-    if (!cur.empty()) groups.push_back(g);
+    if (!cur.empty()) groups.push_back(cur);
   }
   if (groups.empty()) return;
-  // ---- descriptors of all groups (identical from one SCF iteration to the next: uploaded once) ----
+  // ---- launches: per group one per phase (descriptors identical from one SCF iteration to the next: uploaded once) ----
+  struct Launch {
+    Shape sh;
+    size_t ring_words;
+    std::vector<int> idx;  // matrices in it
+    int nmax;
+  };
+  std::vector<Launch> launches;
+  std::vector<TrdpDesc> descs;
   size_t ring_words = 0;
-  std::vector<TrdpDesc> descs(groups.size());
-  std::vector<size_t> ring_of(groups.size());
   int nmax_all = 0;
-  for (size_t q = 0; q < groups.size(); q++) {
-    const Group &g = groups[q];
-    const int M = TP_NRG * g.R, NP = TP_NCG * g.U;
-    TrdpDesc &D = descs[q];
-    D = TrdpDesc{};
-    D.nblk = (int)g.idx.size();
-    size_t words = 16;
-    int wg = 0;
-    for (int b = 0; b < D.nblk; b++) {
-      const int i = g.idx[b];
-      const int G = (ns[i] + M - 1) / M;
-      D.wg0[b] = wg;
-      wg += G;
-      D.n[b] = ns[i];
-      D.G[b] = G;
-      D.A[b] = A[i];
-      D.d[b] = d[i];
-      D.e[b] = e[i];
-      D.tau[b] = tau[i];
-      D.xb[b] = (unsigned long long *)words;  // offset for now, the base is added below
-      words += (size_t)TP_SLOTS * ((size_t)2 * NP + 64 + TP_MAXG);
-      nmax_all = std::max(nmax_all, ns[i]);
+  for (const std::vector<int> &grp : groups) {
+    std::vector<int> act = grp, rem, off;
+    for (int i : grp) {
+      rem.push_back(ns[i]);
+      off.push_back(0);
     }
-    for (int b = D.nblk; b <= TP_MAXB; b++) D.wg0[b] = wg;
-    words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
-    ring_of[q] = words;
-    ring_words = std::max(ring_words, words);
+    while (!act.empty()) {
+      Launch L;
+      if (!fit(rem, L.sh)) return;  // cannot happen: a trailing matrix is smaller than the matrix that fitted
+      int nmax = 0;
+      for (int o : rem) nmax = std::max(nmax, o);
+      // columns of this phase: until the largest trailing matrix fits the next narrower tile (at least min_step columns)
+      int step = 0x3fffffff;
+      if (phases && !want_stamps)
+        for (int q = (int)(sizeof(tp_widths) / sizeof(int)) - 1; q >= 0; q--)
+          if (tp_widths[q] < L.sh.U && nmax - tp_widths[q] * TP_NCG >= min_step) {
+            step = nmax - tp_widths[q] * TP_NCG;
+            break;
+          }
+      const int M = TP_NRG * L.sh.R, NP = TP_NCG * L.sh.U;
+      TrdpDesc D = TrdpDesc{};
+      D.nblk = (int)act.size();
+      size_t words = 16;
+      int wg = 0;
+      std::vector<int> act2, rem2, off2;
+      for (int b = 0; b < D.nblk; b++) {
+        const int i = act[b];
+        const int G = (rem[b] + M - 1) / M;
+        const size_t o = (size_t)off[b];
+        D.wg0[b] = wg;
+        wg += G;
+        D.n[b] = rem[b];
+        D.G[b] = G;
+        D.lda[b] = ns[i];
+        D.A[b] = A[i] + o * (size_t)ns[i] + o;
+        D.d[b] = d[i] + o;
+        D.e[b] = e[i] + o;
+        D.tau[b] = tau[i] + o;
+        D.xb[b] = (unsigned long long *)words;  // offset for now, the base is added below
+        words += (size_t)TP_SLOTS * ((size_t)2 * NP + 64 + TP_MAXG);
+        if (rem[b] - step >= 3) {
+          D.jstop[b] = step;
+          act2.push_back(i);
+          rem2.push_back(rem[b] - step);
+          off2.push_back(off[b] + step);
+        } else
+          D.jstop[b] = 0x3fffffff;  // runs to its end in this launch
+        L.idx.push_back(i);
+      }
+      for (int b = D.nblk; b <= TP_MAXB; b++) D.wg0[b] = wg;
+      words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
+      L.ring_words = words;
+      L.nmax = nmax;
+      ring_words = std::max(ring_words, words);
+      nmax_all = std::max(nmax_all, nmax);
+      launches.push_back(L);
+      descs.push_back(D);
+      act = act2;
+      rem = rem2;
+      off = off2;
+    }
   }
-  w.ring.resize(ring_words);  // the groups run one after the other on the stream and share the ring
+  if ((int)launches.size() > TP_MAXLAUNCH) return;
+  w.ring.resize(ring_words);  // the launches run one after the other on the stream and share the ring
   const size_t win_off = (size_t)8 * (nmax_all + 2);
   if (want_stamps) w.stamps.resize(win_off + (size_t)TP_MAXG * TP_WIN_N * 4 + TP_MAXG);
   static const long long limit_ms = getenv("HELFEM_TRDP_LIMIT_MS") ? atoll(getenv("HELFEM_TRDP_LIMIT_MS")) : 200;
-  for (size_t q = 0; q < groups.size(); q++) {
-    TrdpDesc &D = descs[q];
+  for (TrdpDesc &D : descs) {
     for (int b = 0; b < D.nblk; b++) D.xb[b] = w.ring.p + (size_t)D.xb[b];
     D.status = (int *)w.ring.p;
     D.stamps = want_stamps ? w.stamps.p : nullptr;
@@ -759,39 +846,49 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   hipStream_t s = ctx->stream;
   upload_cached(w.desc, w.h_desc, descs, s);
   w.last_ns.clear();
-  for (size_t q = 0; q < groups.size(); q++) {
-    const Group &g = groups[q];
-    trdp_kernel_t kern = trdp_pick(g.R, g.U, want_stamps);
-    if (want_stamps) HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, w.stamps.n * 8, s));
-    HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, ring_of[q] * sizeof(unsigned long long), s));
+  std::vector<char> touched(nblk, 0), failed(nblk, 0);
+  for (size_t q = 0; q < launches.size(); q++) {
+    const Launch &L = launches[q];
+    bool skip = false;
+    for (int i : L.idx) skip = skip || failed[i];
+    if (skip) continue;
+    trdp_kernel_t kern = trdp_pick(L.sh.R, L.sh.U, want_stamps);
+    if (want_stamps && q == 0) HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, w.stamps.n * 8, s));
+    HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, L.ring_words * sizeof(unsigned long long), s));
     const TrdpDesc *dptr = w.desc.p + q;
     void *args[] = {(void *)&dptr};
     hipError_t err;
     {
       ProfScope pk(ctx, "k_trdp");  // HIP events around this launch alone on the launch stream (bench.py: roofline)
-      err = hipLaunchCooperativeKernel((const void *)kern, dim3(g.grid), dim3(TP_NT), args, 0, s);
+      err = hipLaunchCooperativeKernel((const void *)kern, dim3(L.sh.grid), dim3(TP_NT), args, 0, s);
     }
     if (err != hipSuccess) {
-      (void)hipGetLastError();  // refused (grid not co-resident on this device): the chain takes these matrices
+      (void)hipGetLastError();  // refused (grid not co-resident on this device)
+      bool first = true;
+      for (int i : L.idx) first = first && !touched[i];
+      if (!first)  // a later phase: the matrices are half reduced, there is nothing to fall back to
+        throw std::runtime_error(std::string("persistent tridiagonalisation: cooperative launch refused in a later phase: ") + hipGetErrorString(err));
       static bool told = false;
       if (!told) {
         fprintf(stderr, "helfem_amd: cooperative launch of the persistent tridiagonalisation refused (%s): grid %d; using the launch chain\n",
-                hipGetErrorString(err), g.grid);
+                hipGetErrorString(err), L.sh.grid);
         told = true;
       }
+      for (int i : L.idx) failed[i] = 1;  // the chain takes these matrices
       continue;
     }
     HFG_HIP_CHECK(hipMemcpyAsync(w.h_status + q, w.ring.p, sizeof(int), hipMemcpyDeviceToHost, s));
     w.pending = true;
-    for (int i : g.idx) done[i] = 1;
+    for (int i : L.idx) touched[i] = 1;
     if (w.last_ns.empty()) {
-      for (int i : g.idx) w.last_ns.push_back(ns[i]);
-      w.last_R = g.R;
-      w.last_U = g.U;
-      w.last_grid = g.grid;
+      for (int i : L.idx) w.last_ns.push_back(ns[i]);
+      w.last_R = L.sh.R;
+      w.last_U = L.sh.U;
+      w.last_grid = L.sh.grid;
       w.last_nmax = nmax_all;
     }
   }
+  for (int i = 0; i < nblk; i++) done[i] = touched[i] && !failed[i];
 }
 
 /// replay of the last batch's launch on scratch copies is not possible (the kernel consumes its input); the bench
