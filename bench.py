@@ -385,12 +385,19 @@ def main():
     # (rank 0 only: it always owns symmetry block 0; ranks beyond the number of blocks never ran the factorisation)
     ctx_gemv = (0.0, 0)
     trd_kernel = TRD_KERNEL
+    trdp_shapes = {}
     if rank == 0:
         if fams["k_trdp"]["calls"] > 0:
             # persistent tridiagonalisation: ONE cooperative launch per eigensolve, timed by HIP events around each of
             # the launches of the timed region itself on the launch stream (nothing to replay: the kernel consumes its input)
             trd_kernel = "k_trdp"
             ctx_gemv = (fams["k_trdp"]["ms_per_step"] * args.steps, fams["k_trdp"]["calls"])
+            # its launches by tile shape ("k_trdp<R, U>": one launch per phase of the eigensolve, see hip/trdp.hip)
+            trdp_shapes = {}
+            for nm in ctx.profile_names():
+                if nm.startswith("k_trdp<"):
+                    ms_s, calls_s = ctx.profile_get(nm)
+                    trdp_shapes[nm] = {"us_per_launch": 1e3 * ms_s / max(1, calls_s), "launches_per_step": calls_s / float(args.steps)}
         else:
             for _ in range(3):
                 ctx_gemv = ctx.measure_kernel(TRD_KERNEL)
@@ -422,9 +429,21 @@ def main():
                     tj = json.load(fh)
                 meta = tj.pop("_meta", {})
                 if meta.get("kernel_sources_sha256", kernel_sources_sha()) == kernel_sources_sha():  # stale figures are dropped
-                    for kname, rec in tj.items():  # "void hfg::k_trdp<5, 12, false>" (template) or "hfg::k_trdb_gemv"
-                        if ("hfg::" + trd_kernel) in kname:
-                            traffic = rec.get("traffic_bytes_per_launch")
+                    if trdp_shapes:
+                        # all launches of one eigensolve (one per phase, each its own template instance
+                        # "void hfg::k_trdp<R, U, false>"), averaged per launch like `achieved`
+                        tot, cnt = 0.0, 0.0
+                        for nm, rec_s in trdp_shapes.items():
+                            key = "void hfg::" + nm[:-1] + ", false>"
+                            if key in tj and tj[key].get("traffic_bytes_per_launch") is not None:
+                                tot += tj[key]["traffic_bytes_per_launch"] * rec_s["launches_per_step"]
+                                cnt += rec_s["launches_per_step"]
+                        if cnt == sum(r["launches_per_step"] for r in trdp_shapes.values()) and cnt > 0:
+                            traffic = tot / cnt
+                    else:
+                        for kname, rec in tj.items():  # "hfg::k_trdf<1024>" or "hfg::k_trdb_gemv"
+                            if ("hfg::" + trd_kernel) in kname:
+                                traffic = rec.get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
         out = {
@@ -452,9 +471,12 @@ def main():
                                             "measured in this run)" % os.path.basename(traffic_file)) if traffic is not None else None,
                          "kernel": "hfg::" + trd_kernel, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_ms * 1e3, "launches_per_step": launches_per_step,
-                         "note": ("one cooperative launch per eigensolve, the trailing matrices resident in the register file: "
-                                  "the algorithmic bytes (one triangle of the trailing matrix per Householder column, SURVEY 8d) "
-                                  "never cross HBM; bound by one exchange between workgroups per column (DESIGN.md 3.4)")
+                         "launches_by_tile_shape": trdp_shapes,
+                         "note": ("persistent cooperative launches, one per phase of an eigensolve (a phase ends when the "
+                                  "trailing matrices fit the next narrower register tile), the trailing matrices resident in "
+                                  "the register file: the algorithmic bytes (one triangle of the trailing matrix per Householder "
+                                  "column, SURVEY 8d) never cross HBM; achieved = algorithmic bytes of an eigensolve / time of its "
+                                  "launches; bound by one exchange between workgroups per column (DESIGN.md 3.4)")
                          if trd_kernel == "k_trdp" else
                          "latency-bound: one dependent launch per Householder column (see DESIGN.md 3.4)"},
             "stages_ms": {k: round(v["ms_per_step"], 4) for k, v in fams.items()},

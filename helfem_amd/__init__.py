@@ -96,6 +96,7 @@ def lib():
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
         L.hfg_profile_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, c_double_p, c_i64_p]
         L.hfg_measure_kernel.argtypes = [ctypes.c_void_p, ctypes.c_char_p, c_double_p, c_i64_p]
+        L.hfg_profile_names.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         _lib = L
     return _lib
 
@@ -167,6 +168,11 @@ class Context(object):
         n = ctypes.c_int64()
         _check(lib().hfg_measure_kernel(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def profile_names(self):
+        buf = ctypes.create_string_buffer(1 << 16)
+        _check(lib().hfg_profile_names(self.h, buf, len(buf)))
+        return [x for x in buf.value.decode().split("\n") if x]
 
     def profile_get(self, name):
         ms = ctypes.c_double()

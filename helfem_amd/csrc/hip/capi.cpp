@@ -977,6 +977,19 @@ int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launche
   HFG_CATCH
 }
 
+int hfg_profile_names(hfg_ctx *ctx, char *buf, size_t cap) {
+  HFG_TRY
+  ctx->prof_collect();
+  std::string all;
+  for (const auto &kv : ctx->prof) {
+    if (!all.empty()) all += "\n";
+    all += kv.first;
+  }
+  if (cap == 0 || all.size() + 1 > cap) throw std::logic_error("hfg_profile_names: buffer too small");
+  memcpy(buf, all.c_str(), all.size() + 1);
+  HFG_CATCH
+}
+
 int hfg_measure_kernel(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches) {
   HFG_TRY
   if (std::string(name) == "k_trdb_gemv" || std::string(name) == "k_trdf") trd_measure_gemv(ctx, ms, launches);

@@ -859,7 +859,12 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     void *args[] = {(void *)&dptr};
     hipError_t err;
     {
-      ProfScope pk(ctx, "k_trdp");  // HIP events around this launch alone on the launch stream (bench.py: roofline)
+      // HIP events around this launch alone on the launch stream (bench.py: roofline), for the family and per tile shape
+      static std::map<std::pair<int, int>, std::string> shape_names;
+      std::string &nm = shape_names[std::make_pair(L.sh.R, L.sh.U)];
+      if (nm.empty()) nm = "k_trdp<" + std::to_string(L.sh.R) + ", " + std::to_string(L.sh.U) + ">";
+      ProfScope pk(ctx, "k_trdp");
+      ProfScope ps(ctx, nm.c_str());
       err = hipLaunchCooperativeKernel((const void *)kern, dim3(L.sh.grid), dim3(TP_NT), args, 0, s);
     }
     if (err != hipSuccess) {

@@ -371,6 +371,9 @@ int hfg_chk_read_diatomic_basis(hfg_chk *chk, int lpad, hfg_basis **basis);
 int hfg_profile_enable(hfg_ctx *ctx, int on);
 int hfg_profile_reset(hfg_ctx *ctx);
 int hfg_profile_get(hfg_ctx *ctx, const char *name, double *ms, int64_t *launches);
+/* the names seen since the last reset, separated by '\n' (besides the families above: one name per tile shape of the
+ * persistent tridiagonalisation, "k_trdp<R, U>", and "k_trdp" for all its launches) */
+int hfg_profile_names(hfg_ctx *ctx, char *buf, size_t cap);
 
 /* Atomic SCF, restricted closed shell or unrestricted (driver loop of src/atomic/main.cpp:760-1005); out as for hfg_scf_diatomic */
 int hfg_scf_atomic(hfg_ctx *ctx, int Z, int Q, int lmax, int mmax, int nelem, int nnodes, int nquad, double Rmax,
