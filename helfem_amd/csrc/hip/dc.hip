@@ -20,6 +20,7 @@
 //           zhat_j^2 = prod_i (lam_i - d_j) / (rho prod_{i != j} (d_i - d_j));  U_ji = zhat_j / (d_j - lam_i)
 //           (columns normalised); Q <- [Q_nd U | Q_deflated] sorted by eigenvalue.
 #include "common.h"
+#include <cstring>
 #include "wave.h"
 
 namespace hfg {
@@ -718,6 +719,7 @@ __global__ void k_dc_copyback(DCBatch b, const DCNode *__restrict__ nodes, int n
 }
 
 // ---- batched FP64 MFMA GEMM over device-side task descriptors (C = A B, column-major) ----------------------------
+void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);  // gemm.hip
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_dgemm_tasks(const GemmTask *__restrict__ tasks) {
@@ -933,8 +935,16 @@ void tridiag_dc_batch(hfg_ctx *ctx, int nblk, const int *ns, double *const *d, d
     hipLaunchKernelGGL(k_dc_zhat, dim3((mx + 3) / 4, nn), dim3(256), 0, s, b, w.nodes.p, node0, w.kcount.p, w.rho_eff.p);
     hipLaunchKernelGGL(k_dc_U, dim3((mx + 3) / 4, nn), dim3(256), 0, s, b, w.nodes.p, node0, w.kcount.p);
     hipLaunchKernelGGL(k_dc_gather, dim3((mx + 255) / 256, mx, nn), dim3(256), 0, s, b, w.nodes.p, node0, w.kcount.p);
-    int tiles = ((mx + 63) / 64) * ((mx + 63) / 64);
-    hipLaunchKernelGGL(k_dgemm_tasks, dim3(tiles, nn), dim3(256), 0, s, w.tasks.p);
+    // Q <- Q U of every node of the level: the tile engine of gemm.hip (16-byte staging loads, conflict-free LDS rows, two
+    // workgroups per CU).  The small kernel below, which this call replaced, spent 68 % of its LDS cycles in bank
+    // conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r03_gemm_sq_counters_bench_step.txt): its B tile is
+    // read along k and stored transposed.  HELFEM_DC_GEMM=small keeps it as the checker.
+    static const bool small_gemm = getenv("HELFEM_DC_GEMM") && !strcmp(getenv("HELFEM_DC_GEMM"), "small");
+    if (small_gemm) {
+      int tiles = ((mx + 63) / 64) * ((mx + 63) / 64);
+      hipLaunchKernelGGL(k_dgemm_tasks, dim3(tiles, nn), dim3(256), 0, s, w.tasks.p);
+    } else
+      gemm_tasklist64_dev(ctx, w.tasks.p, nn, mx, mx);
     size_t shr = (size_t)mx * sizeof(double);
     if (shr > 64 * 1024)
       HFG_HIP_CHECK(hipFuncSetAttribute((const void *)k_dc_rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shr));

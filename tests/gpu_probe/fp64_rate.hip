@@ -126,6 +126,54 @@ __global__ __launch_bounds__(256) void k_mfma16_var(double *out, unsigned long l
   }
 }
 
+// Round 3: the two 16x16x4 loops above do NOT measure the instruction -- hipcc keeps their accumulators in VGPRs across the
+// loop and copies all 128 registers into AGPRs and back around the 16 MFMAs of every iteration (256 v_accvgpr moves per
+// 16 MFMAs in the ISA), which is where their 36 / 31.5 TFLOP/s came from.  These loops issue the instruction through inline
+// assembly with the accumulators pinned in VGPRs: 16 independent accumulators (a dependent MFMA is 16 instructions = more
+// than the 16 passes of the pipeline away), the same operand pair everywhere or 4 x 4 distinct operand registers.
+__global__ __launch_bounds__(256) void k_mfma16_asm(double *out, unsigned long long *clk, int iters) {
+  double4_t acc[16];
+  for (int i = 0; i < 16; i++) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+  unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+  }
+  unsigned long long c1 = clock64(), w1 = wall_clock64();
+  double s = 0.0;
+  for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = c1 - c0;
+    clk[1] = w1 - w0;
+  }
+}
+__global__ __launch_bounds__(256) void k_mfma16_asm_var(double *out, unsigned long long *clk, int iters) {
+  double4_t acc[16];
+  double a[4], b[4];
+  for (int i = 0; i < 16; i++) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < 4; i++) {
+    a[i] = threadIdx.x * 1e-3 + i;
+    b[i] = 1.0 + threadIdx.x * 1e-4 * (i + 1);
+  }
+  unsigned long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[4 * i + j]) : "v"(a[i]), "v"(b[j]));
+  }
+  unsigned long long c1 = clock64(), w1 = wall_clock64();
+  double s = 0.0;
+  for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = c1 - c0;
+    clk[1] = w1 - w0;
+  }
+}
+
 template <typename K>
 static void run(const char *name, K kern, double flops_per_wave_iter, int iters) {
   double *d;
@@ -161,5 +209,7 @@ int main() {
   run("v_mfma_f64_4x4x4_4b x32", k_mfma4, 32 * 4 * 4 * 4 * 4 * 2.0, 20000);
   run("4x4x4_4b, 8x8 operands", k_mfma4_var, 64 * 512.0, 10000);
   run("16x16x4, 4x4 operands", k_mfma16_var, 16 * 2048.0, 10000);
+  run("16x16x4 asm, pinned acc", k_mfma16_asm, 16 * 2048.0, 10000);
+  run("16x16x4 asm, 4x4 operands", k_mfma16_asm_var, 16 * 2048.0, 10000);
   return 0;
 }
