@@ -388,6 +388,23 @@ class AtomicTwoDBasis(TwoDBasis):
         _check(lib().hfg_basis_dims(self.h, *[ctypes.byref(x) for x in dims]))
         self._Nbf, self._Ndummy, self._Nrad, self._Nang, self._Nel = [x.value for x in dims]
 
+    ATOMIC_TABLES = {"prim_tei": 0, "prim_ktei": 4, "disjoint_L": 8, "disjoint_m1L": 10, "disjoint_iL": 12, "disjoint_kL": 13,
+                     "rs_tei": 14, "rs_ktei": 15}
+
+    def atomic_table(self, name, L, iel, kel=None):
+        """one table of compute_tei / compute_yukawa / compute_erfc in the reference's shape (erfc: element pair iel, kel)"""
+        which = self.ATOMIC_TABLES[name]
+        idx = int(iel) if kel is None else int(iel) * self._Nel + int(kel)
+        r, c = ctypes.c_int64(), ctypes.c_int64()
+        ctxh = self.ctx.h if self.ctx is not None else None
+        f = lib().hfg_basis_get_prim
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                      ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        _check(f(ctxh, self.h, which, int(L), idx, None, ctypes.byref(r), ctypes.byref(c)))
+        out = np.zeros((r.value, c.value), order="F")
+        _check(f(ctxh, self.h, which, int(L), idx, _p(out), ctypes.byref(r), ctypes.byref(c)))
+        return out
+
     def compute_yukawa(self, lam):
         """TwoDBasis::compute_yukawa (src/atomic/TwoDBasis.cpp:741): tables of exp(-lambda r12)/r12 (host)"""
         _check(lib().hfg_compute_rs_tei(self.h, 1, float(lam)))

@@ -396,8 +396,23 @@ int hfg_basis_get_prim(hfg_ctx *ctx, const hfg_basis *b, int which, int ilm, int
     // atomic basis: which 0 = prim_tei[L] (TwoDBasis.cpp:666-739), 8 = disjoint_L, 10 = disjoint_m1L; ilm = L
     const helfem::atomic::TwoDBasis &B = b->ab;
     const size_t E = B.Nel(), NL = (size_t)B.N_L();
-    if ((which != 0 && which != 8 && which != 10) || ilm < 0 || (size_t)ilm >= NL || iel < 0 || (size_t)iel >= E)
+    if (which != 4 && !(which >= 12 && which <= 15) && ((which != 0 && which != 8 && which != 10) || ilm < 0 || (size_t)ilm >= NL || iel < 0 || (size_t)iel >= E))
       throw std::logic_error("hfg_basis_get_prim: index out of range\n");
+    if (which == 4 || (which >= 12 && which <= 15)) {
+      // 4 = prim_ktei[L] (host tables); range-separated tables of compute_yukawa / compute_erfc (TwoDBasis.cpp:741-815):
+      // 12 = disjoint_iL, 13 = disjoint_kL, 14 = rs_tei, 15 = rs_ktei -- Yukawa: one table per (L, iel); erfc: one per
+      // (L, iel, kel), addressed with iel * Nel + kel in place of iel
+      const std::vector<helfem::Mat> &t = which == 4 ? B.prim_ktei : which == 12 ? B.disjoint_iL : which == 13 ? B.disjoint_kL : which == 14 ? B.rs_tei : B.rs_ktei;
+      const bool pairs = which >= 14 && B.rs_kind == 2;
+      if (ilm < 0 || (size_t)ilm >= NL || iel < 0 || (size_t)iel >= (pairs ? E * E : E)) throw std::logic_error("hfg_basis_get_prim: index out of range\n");
+      const size_t at = pairs ? (size_t)ilm * E * E + iel : (size_t)ilm * E + iel;
+      if (at >= t.size()) throw std::logic_error("hfg_basis_get_prim: this table has not been computed\n");
+      const helfem::Mat &m = t[at];
+      *rows = (int64_t)m.n_rows;
+      *cols = (int64_t)m.n_cols;
+      if (out) std::copy(m.d.begin(), m.d.end(), out);
+      return 0;
+    }
     const size_t idx = (size_t)ilm * E + iel;
     if (which >= 8) {
       if (!B.have_tei && !B.have_disjoint) throw std::logic_error("Primitive teis have not been computed!\n");

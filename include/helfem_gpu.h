@@ -132,7 +132,9 @@ int hfg_diis_weights(int n, const double *B, const double *T, const double *E, d
  *   hfg_basis_lm_map: the sorted (L,|M|) channel list of the constructor (basis.cpp:333-375); n in: capacity, out: count
  *   hfg_basis_get_prim: which 0-3 prim_tei00/02/20/22, 4-7 prim_ktei00/02/20/22, 8-11 disjoint_P0/P2/Q0/Q2 of channel ilm and
  *   element iel, column-major in the reference's shape (rows/cols returned; out may be NULL to query the shape).  Tables built
- *   by hfg_compute_tei_dev are copied back from the device (ctx required). */
+ *   by hfg_compute_tei_dev are copied back from the device (ctx required).  Atomic handles: ilm = L; which 0 prim_tei[L],
+ *   4 prim_ktei[L], 8 disjoint_L, 10 disjoint_m1L, and after hfg_compute_rs_tei 12 disjoint_iL, 13 disjoint_kL, 14 rs_tei,
+ *   15 rs_ktei (erfc tables, one per element pair: iel * Nel + kel in place of iel). */
 /* arma::mat TwoDBasis::overlap(const TwoDBasis &rh)   basis.cpp:713 and atomic/TwoDBasis.cpp:330: interbasis overlap
  * <a|b>, Nbf(a) x Nbf(b), of two bases of the same program (the projection of a checkpoint's orbitals onto another
  * basis, --load) */

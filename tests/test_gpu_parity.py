@@ -347,6 +347,20 @@ def test_tei_tables_against_the_independent_fixture(hf):
     assert __import__("common").relerr(gd.exchange(P), gh.exchange(P)) < 1e-12
 
 
+def test_atomic_device_tei_tables_against_the_independent_fixture(hf):
+    """hfg_compute_tei_dev on an ATOMIC basis (in-element tables of compute_tei built on the device, read back) against
+    tests/golden/atomic_tei.npz, the tables of the NumPy restatement oracle/atomic_tei.py (no product code)"""
+    import test_tei_golden_cpu as tg
+    g, ab, NL = tg._atomic_case(hf)
+    E = len(g["bval"]) - 1
+    ab.compute_tei(True, device=True)
+    le = [(L, e) for L in range(NL) for e in range(E)]
+    err = tg._worst(lambda L, e: ab.atomic_table("prim_tei", L, e), g, "prim_tei", le)
+    assert err < 1e-12, err
+    for name in ("disjoint_L",):
+        assert tg._worst(lambda L, e, n=name: ab.atomic_table(n, L, e), g, name, le) < 1e-12
+
+
 def test_device_tei_tables_at_the_bench_element_order(hf):
     """hfg_compute_tei_dev at the headline workload's element order (15-node LIPs, 75-point quadrature, channels up to
     L = 40) against tests/golden/diatomic_tei_p15.npz: seeded samples of the independent NumPy / mpmath restatement"""

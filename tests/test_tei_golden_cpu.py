@@ -230,3 +230,57 @@ def test_host_tables_at_the_bench_element_order(native_libs):
     assert max(v for k, v in exact.items() if not k.endswith("[0]")) < 2e-11, exact
     ref = p15_errors(gb.prim_table, g, "ref")
     assert max(v for k, v in ref.items() if not k.endswith("[0]")) < 1e-6, ref  # the reference Legendre library's own accuracy
+
+
+# ---- atomic program: compute_tei / compute_yukawa / compute_erfc (src/atomic/TwoDBasis.cpp:666-815) ---------------------------
+def _atomic_case(hf):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "atomic_tei.npz"))
+    NL = int(g["case_NL"])
+    lmax = (NL - 1) // 2  # N_L = 2 max(lval) + 1
+    lval = list(range(lmax + 1))
+    mval = [0] * len(lval)
+    ab = hf.AtomicTwoDBasis(2, int(g["case_nnodes"]), int(g["case_nquad"]), g["bval"], lval, mval)
+    return g, ab, NL
+
+
+def _worst(get, g, prefix, keys):
+    worst = 0.0
+    for key in keys:
+        ref = g[prefix + "_" + "_".join(str(q) for q in key)]
+        got = get(*key)
+        assert got.shape == ref.shape, (prefix, key, got.shape, ref.shape)
+        worst = max(worst, float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
+    return worst
+
+
+def test_atomic_host_tables_against_the_independent_fixture(native_libs):
+    """the atomic program's radial tables built by helfem_amd/csrc/host/atomic_basis.cpp + special.cpp (own Bessel series, the
+    published series of Phi_L) against tests/golden/atomic_tei.npz (oracle/atomic_tei.py: NumPy, scipy.special Bessel
+    functions, Phi_L from its defining Legendre projection by quadrature; no product code)"""
+    import helfem_amd as hf
+    g, ab, NL = _atomic_case(hf)
+    E = len(g["bval"]) - 1
+    le = [(L, e) for L in range(NL) for e in range(E)]
+    ab.compute_tei(True)
+    err = {}
+    for name in ("disjoint_L", "disjoint_m1L", "prim_tei", "prim_ktei"):
+        # int B_i B_j r^(-L-1) dr over the FIRST element is a sum dominated by its first quadrature point (1e17 at L = 4) and
+        # never read (r^(-L-1) belongs to the OUTER element of a disjoint pair, which is never element 0: TwoDBasis.cpp:885-910): loose bound there
+        keys = [k for k in le if not (name == "disjoint_m1L" and k[1] == 0)]
+        err[name] = _worst(lambda L, e, n=name: ab.atomic_table(n, L, e), g, name, keys)
+    assert _worst(lambda L, e: ab.atomic_table("disjoint_m1L", L, e), g, "disjoint_m1L", [k for k in le if k[1] == 0]) < 1e-9
+    ab.compute_yukawa(float(g["case_lam"]))
+    for name, fix in (("disjoint_iL", "disjoint_iL"), ("disjoint_kL", "disjoint_kL"), ("rs_tei", "yukawa_tei"), ("rs_ktei", "yukawa_ktei")):
+        err[fix] = _worst(lambda L, e, n=name: ab.atomic_table(n, L, e), g, fix, le)
+    ab.compute_erfc(float(g["case_mu"]))
+    lek = [(L, e, k) for L in range(NL) for e in range(E) for k in range(E)]
+    for name, fix in (("rs_tei", "erfc_tei"), ("rs_ktei", "erfc_ktei")):
+        err[fix] = _worst(lambda L, e, k, n=name: ab.atomic_table(n, L, e, k), g, fix, lek)
+    print("atomic host tables vs fixture:", err)
+    for k in ("disjoint_L", "disjoint_m1L", "prim_tei", "prim_ktei"):
+        assert err[k] < 1e-12, err
+    for k in ("disjoint_iL", "disjoint_kL", "yukawa_tei", "yukawa_ktei"):
+        assert err[k] < 1e-11, err
+    # Phi_L: the product sums the published series (exact binomials), the fixture integrates the projection numerically
+    for k in ("erfc_tei", "erfc_ktei"):
+        assert err[k] < 1e-9, err
