@@ -505,6 +505,31 @@ def test_eig_gsym_sub_many_small_and_odd_blocks(hf):
     assert np.max(np.abs(F @ C - S @ C * E)) < 1e-9
 
 
+@pytest.mark.parametrize("sizes", [[769, 513, 300], [1025], [257, 256, 255], [897, 896, 641, 640, 385], [1793, 3]])
+def test_persistent_tridiagonalisation_phase_boundaries(hf, sizes):
+    """block sets whose orders sit on and next to the tile widths of hip/trdp.hip (multiples of 128 / 256: where a phase
+    ends, where a matrix changes tile shape, where a block finishes inside a phase of the others; 255 and 3 take the
+    launch chain) through eig_gsym_sub with X = 1, against LAPACK; twice, bitwise the same"""
+    rng = np.random.RandomState(sum(sizes))
+    N = sum(sizes)
+    F = np.zeros((N, N), order="F")
+    blocks, off = [], 0
+    for n in sizes:
+        B = rng.standard_normal((n, n))
+        F[off:off + n, off:off + n] = B + B.T
+        blocks.append(np.arange(off, off + n))
+        off += n
+    X = np.asfortranarray(np.eye(N))
+    E, C = hf.scf.eig_gsym_sub(F, X, blocks)
+    Er = np.sort(np.concatenate([np.linalg.eigvalsh(F[np.ix_(b, b)]) for b in blocks]))
+    sc = np.max(np.abs(Er))
+    assert np.max(np.abs(E - Er)) < 1e-12 * sc
+    assert np.max(np.abs(F @ C - C * E)) < 1e-11 * sc
+    assert np.max(np.abs(C.T @ C - np.eye(N))) < 1e-11
+    E2, C2 = hf.scf.eig_gsym_sub(F, X, blocks)
+    assert np.array_equal(E, E2) and np.array_equal(C, C2)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Fock build parity: atomic J, K, XC against the oracle (BASELINE configs 1 and 2 run on this path)
 # ---------------------------------------------------------------------------------------------------
