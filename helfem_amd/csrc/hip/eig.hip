@@ -26,6 +26,7 @@ void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int max
 void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
+bool gemm_prefers_128(hfg_ctx *ctx, long tiles128);
 void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
 void gemm_mirror_lower_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxN);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restri
 
 struct EigWork {
   bool split_full = false;  // this batch's full products run as two half-K workgroups per tile
+  bool tile64 = false;
   DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
@@ -1142,6 +1144,16 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
       const bool split_low = force_split >= 0 ? force_split != 0 : (low_tiles < slots && nm >= 256);
       w.split_full = split_full;
       ProfScope pp3(ctx, "eig_products");  // the N^3 products alone (bench.py: MFMA fraction of the tile engine)
+      // 64 x 64 tiles unless the batch's 128 x 128 tiles would fill whole rounds of the chip (gemm_prefers_128): 386 large
+      // tiles on 512 slots ran at 34 TFLOP/s as two half-K workgroups each, 1452 small ones at 37 and without zeroing C.
+      // HELFEM_GEMM_SPLITK=1 / HELFEM_GEMM_TILE=128 bring the large tiles back (checkers).
+      const bool tile64 = force_split < 0 && !gemm_prefers_128(ctx, full_tiles);
+      w.tile64 = tile64;
+      if (tile64) {
+        gemm_tasklist64_dev(ctx, w.gtasks.p, nb, nm, nm);
+        gemm_tasklist64_dev(ctx, w.gtasks.p + nb, nb, nm, nm);
+        gemm_mirror_lower_dev(ctx, w.gtasks.p + nb, nb, nm);
+      } else {
       if (split_full) {
         for (int k = 0; k < nb; k++) HFG_HIP_CHECK(hipMemsetAsync(T1.p + (size_t)k * nmax * nmax, 0, sizeof(double) * (size_t)ns[k] * ns[k], s));
         gemm_tasklist_split2_dev(ctx, w.gtasks.p, nb, nm, nm);
@@ -1153,6 +1165,7 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
       } else
         gemm_tasklist_dev(ctx, w.gtasks.p + nb, nb, nm, nm);      // lower tiles of X^T (F X) only (GemmTask::sym)
       gemm_mirror_lower_dev(ctx, w.gtasks.p + nb, nb, nm);        // the tridiagonalisation sweeps the full square
+      }
     }
     eig_sym_batch(ctx, w, nb, ns.data());
     {
@@ -1160,7 +1173,8 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
       static const bool rect = getenv("HELFEM_GEMM_RECT") && atoi(getenv("HELFEM_GEMM_RECT"));
       {
         ProfScope pp3(ctx, "eig_products");
-        if (w.split_full) gemm_tasklist_split2_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);  // the block slots were zeroed above
+        if (w.tile64) gemm_tasklist64_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+        else if (w.split_full) gemm_tasklist_split2_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);  // the block slots were zeroed above
         else if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
         else gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
       }

@@ -530,12 +530,30 @@ void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int max
   HFG_HIP_CHECK(hipGetLastError());
 }
 
+/// 128 x 128 tiles (two workgroups per CU, 59-63 TFLOP/s when they fill the chip) or 64 x 64 tiles (three per CU, 52-56)?
+/// The large tiles only when their count fills whole rounds of the 2 x CU slots to 85 %: 484 tiles (n = 2816) 59.1
+/// against 56.1 TFLOP/s, 2304 (n = 6102) 55.8 against 54.1, 4096 (n = 8192) 63.5 against 58.5 -- but 1156 (n = 4230, 2.26
+/// rounds) 47.7 against 52.1, and the 386 tiles of the eigensolve's three blocks 34 against 37 (profiles/r03_gemm_bench.txt).
+/// HELFEM_GEMM_TILE = 64 / 128 forces one.
+bool gemm_prefers_128(hfg_ctx *ctx, long tiles128) {
+  static const int force_tile = getenv("HELFEM_GEMM_TILE") ? atoi(getenv("HELFEM_GEMM_TILE")) : 0;
+  if (force_tile) return force_tile == 128;
+  static int slots = 0;
+  if (!slots) {
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    slots = 2 * ncu;
+  }
+  const long rounds = (tiles128 + slots - 1) / slots;
+  return tiles128 >= slots / 2 && (double)tiles128 >= 0.85 * (double)(rounds * slots);
+}
+
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
               const double *B, int ldb, double beta, double *C, int ldc) {
   if (M <= 0 || N <= 0) return;
   ProfScope ps(ctx, "gemm");
   long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (big_tiles >= 512) {
+  if (gemm_prefers_128(ctx, big_tiles)) {
     if (mfma4())
       hipLaunchKernelGGL((k_dgemm<128, 128, 0>), dim3((unsigned)big_tiles), dim3(256), 0, ctx->stream, (int)tA, (int)tB, M, N, K,
                          alpha, A, lda, B, ldb, beta, C, ldc);

@@ -11,7 +11,7 @@ import helfem_amd as hf
 ctx = hf.default_context()
 L = hf.lib()
 shapes = [(1400, 1400, 1400, 0, 0), (1400, 1400, 1400, 1, 0), (4230, 4230, 4230, 0, 0), (2816, 2816, 2816, 0, 0), (1400, 1400, 64, 0, 1),
-          (225, 3000, 900, 0, 0)]
+          (225, 3000, 900, 0, 0), (6102, 6102, 6102, 0, 0), (8192, 8192, 8192, 0, 0)]
 for (m, n, k, tA, tB) in shapes:
     A = torch.randn((k, m) if not tA else (m, k), dtype=torch.float64, device="cuda")  # column-major m x k == row-major k x m
     B = torch.randn((n, k) if not tB else (k, n), dtype=torch.float64, device="cuda")
