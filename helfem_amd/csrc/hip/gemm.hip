@@ -518,10 +518,15 @@ void gemm_tasklist_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int nta
   HFG_HIP_CHECK(hipGetLastError());
 }
 
+bool gemm_prefers_128(hfg_ctx *ctx, long tiles128);
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN) {
   if (ntasks <= 0 || maxM <= 0 || maxN <= 0) return;
-  ProfScope ps(ctx, "gemm");
   const int tiles = ((maxM + 127) / 128) * ((maxN + 127) / 128);
+  if (ntasks <= 65535 && !gemm_prefers_128(ctx, (long)ntasks * tiles)) {  // (an upper bound of the tile count: tasks may be smaller)
+    gemm_tasklist64_dev(ctx, dtasks, ntasks, maxM, maxN);
+    return;
+  }
+  ProfScope ps(ctx, "gemm");
   for (int t0 = 0; t0 < ntasks; t0 += 65535) {
     int nt = std::min(65535, ntasks - t0);
     if (mfma4()) hipLaunchKernelGGL((k_dgemm_tasklist<128, 128, false, 0>), dim3(tiles, nt), dim3(256), 0, ctx->stream, dtasks + t0);
