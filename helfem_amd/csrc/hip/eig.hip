@@ -481,7 +481,7 @@ constexpr int BT_PW = 2 * BT_KB;  // rows of the pair's W
 constexpr int BT_WREP = 4;         // passes of 4 columns per workgroup of k_bt_wpair
 __global__ __launch_bounds__(256) void k_bt_wpair(EigBatch b, double *const *__restrict__ Wpart, double *const *__restrict__ W,
                                                   double *const *__restrict__ Cc, int S, int GS, int npair, int pair,
-                                                  int kb1_ofblk0) {
+                                                  int mirror) {
   __shared__ double sC[BT_KB][BT_KB + 1];
   __shared__ double s1[4][BT_KB];
   const int blk = blockIdx.y;
@@ -489,7 +489,6 @@ __global__ __launch_bounds__(256) void k_bt_wpair(EigBatch b, double *const *__r
   const int j0 = pair * BT_PW;
   if (j0 > n - 3) return;
   const int kb1 = min(BT_KB, n - 2 - (j0 + BT_KB));  // reflectors of the pair's second block (<= 0: there is none)
-  (void)kb1_ofblk0;
   const int tid = threadIdx.x, cl = tid >> 6, i = tid & 63;
   if (kb1 > 0) {
     // all loads of a slab in flight together (a rolled "load GS values, add, store" loop over the 16 elements of a
@@ -525,6 +524,29 @@ __global__ __launch_bounds__(256) void k_bt_wpair(EigBatch b, double *const *__r
         a1[rep] += Wpart[blk][(size_t)sl * tot + (size_t)col * BT_PW + BT_KB + i];
       }
     }
+  }
+  if (mirror) {
+    // right application (X Q_p Q_p+1, worked on Y = X^T): rows 0..63 pass through, rows 64.. get the coupling,
+    //   W1 = A1 - C^T A0   (C = V_p^T VT_p+1 as above)
+    const int kb0 = min(BT_KB, n - 2 - j0);
+#pragma unroll
+    for (int rep = 0; rep < BT_WREP; rep++) {
+      const int col = (blockIdx.x * BT_WREP + rep) * 4 + cl;
+      __syncthreads();
+      s1[cl][i] = (i < kb0) ? a0[rep] : 0.0;
+      __syncthreads();
+      if (col < n) {
+        double r1 = 0.0;
+        if (kb1 > 0 && i < kb1) {
+          double corr = 0.0;
+          for (int j = 0; j < kb0; j++) corr += sC[j][i] * s1[cl][j];
+          r1 = a1[rep] - corr;
+        }
+        W[blk][(size_t)col * BT_PW + i] = a0[rep];
+        W[blk][(size_t)col * BT_PW + BT_KB + i] = r1;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int rep = 0; rep < BT_WREP; rep++) {
@@ -609,6 +631,10 @@ __global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restri
 struct EigWork {
   bool split_full = false;  // this batch's full products run as two half-K workgroups per tile
   bool tile64 = false;
+  bool folded = false;      // the last batch formed Y = (X Q)^T beside the divide-and-conquer stage (bt_wy_fold_x)
+  DevBuf<double> Y[MAXB];
+  DevBuf<GemmTask> btslabR, btupdR;
+  std::vector<GemmTask> h_btslabR, h_btupdR;
   DevBuf<double> A[MAXB], d[MAXB], e[MAXB], tau[MAXB], v[MAXB], pp[MAXB], dots[MAXB], Z[MAXB], rot[MAXB];
   DevBuf<int> sweeps[MAXB];
   DevBuf<int> ibuf1, ibuf2;
@@ -647,7 +673,30 @@ void eig_release(hfg_ctx *ctx) {
 // (2) the part that needs only the reflectors -- explicit V, Gram matrices, T, V T -- queued on the context's side
 //     stream so that it runs beside the divide-and-conquer stage (which keeps few CUs busy),
 // (3) the sweep over the reflector blocks on the main stream.
-static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, const int *ns, int nmax) {
+// Y = X^T for every matrix of the batch (64 x 64 blocks through LDS)
+struct TrPtrs {
+  const double *src[MAXB];
+  double *dst[MAXB];
+  int n[MAXB];
+};
+__global__ __launch_bounds__(256) void k_transpose_batch(TrPtrs t) {
+  __shared__ double tile[64][65];
+  const int blk = blockIdx.z, n = t.n[blk];
+  const int bi = blockIdx.x * 64, bj = blockIdx.y * 64;
+  if (bi >= n || bj >= n) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) {
+    const int gm = bi + tx, gn = bj + c;
+    tile[c][tx] = (gm < n && gn < n) ? t.src[blk][(size_t)gn * n + gm] : 0.0;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int gm = bj + tx, gn = bi + c;  // dst(gm, gn) = src(gn, gm)
+    if (gm < n && gn < n) t.dst[blk][(size_t)gn * n + gm] = tile[tx][c];
+  }
+}
+
+static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, const int *ns, int nmax, bool fold = false) {
   hipStream_t s = ctx->stream;
   const int P = (nmax - 3) / BT_KB + 1;  // reflector blocks of the largest matrix
   const int NP = (P + 1) / 2;            // pairs of blocks, applied together (k_bt_wpair)
@@ -773,6 +822,50 @@ static void bt_wy_setup(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, c
   upload_cached(w.btcpl, w.h_btcpl, cpl, s);
   upload_cached(w.btslab, w.h_btslab, slab, s);
   upload_cached(w.btupd, w.h_btupd, upd, s);
+  if (fold) {
+    // ---- the same pairs applied from the RIGHT to X, worked on Y = X^T (eig_blocks_dev: C = (X Q) Z):
+    //   X Q_p Q_p+1 = X - B0 V_p^T - (B1 - B0 C) V_p+1^T,  B = X [VT_p | VT_p+1]   <=>
+    //   Y <- Y - [V_p | V_p+1] [W0; W1],  W0 = VT_p^T Y,  W1 = VT_p+1^T Y - C^T W0
+    // i.e. the tasks above with V and VT exchanged, on Y, pairs first to last; needs only the reflectors, not Z ----
+    std::vector<GemmTask> slabR((size_t)NP * BT_S * nblk, none), updR((size_t)NP * nblk, none);
+    for (int g2 = 0; g2 < NP; g2++)
+      for (int k = 0; k < nblk; k++) {
+        const int n = ns[k], p0 = 2 * g2, j0 = p0 * BT_KB;
+        const int kb0 = kb_of(k, p0), kb1 = (p0 + 1 < P) ? kb_of(k, p0 + 1) : 0;
+        if (kb0 <= 0) continue;
+        const int r0 = j0 + 1, mr = n - r0, kbp = kb0 + kb1;
+        const int chunk = chunk_of(mr, BT_S);
+        for (int sl = 0; sl < BT_S; sl++) {
+          GemmTask q = none;
+          const int k0 = sl * chunk, kk = std::max(0, std::min(chunk, mr - k0));
+          q.A = w.VT[k].p + (size_t)j0 * n + r0 + (kk > 0 ? k0 : 0);
+          q.B = w.Y[k].p + r0 + (kk > 0 ? k0 : 0);
+          q.C = w.Wp[k].p + (size_t)sl * BT_PW * n;
+          q.tA = 1;
+          q.M = kbp;
+          q.N = n;
+          q.K = kk;
+          q.lda = q.ldb = n;
+          q.ldc = BT_PW;
+          slabR[((size_t)g2 * BT_S + sl) * nblk + k] = q;
+        }
+        GemmTask u = none;
+        u.A = w.Vx[k].p + (size_t)j0 * n + r0;
+        u.B = w.Wb[k].p;
+        u.C = w.Y[k].p + r0;
+        u.M = mr;
+        u.N = n;
+        u.K = kbp;
+        u.lda = n;
+        u.ldb = BT_PW;
+        u.ldc = n;
+        u.alpha = -1.0;
+        u.beta = 1.0;
+        updR[(size_t)g2 * nblk + k] = u;
+      }
+    upload_cached(w.btslabR, w.h_btslabR, slabR, s);
+    upload_cached(w.btupdR, w.h_btupdR, updR, s);
+  }
 }
 
 static bool bt_use_side() {
@@ -780,12 +873,14 @@ static bool bt_use_side() {
   return v;
 }
 
-static void bt_wy_prepare(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, int nmax) {
+static void bt_wy_prepare(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, int nmax, bool on_side = false) {
   const int P = (nmax - 3) / BT_KB + 1;
   // HELFEM_BT_SIDE=1 queues this part on a second stream beside the divide-and-conquer stage.  Measured: the 0.25 ms it
   // hides are outweighed by what a second live stream costs every launch on the framework's null stream (the
   // tridiagonalisation alone went from 17.4 to 19.1 ms), so the default keeps everything on the context's stream.
-  const bool use_side = bt_use_side();
+  // (Round 3: with X Q folded beside the divide-and-conquer stage -- bt_wy_fold_x, which needs these operands -- the set-up
+  // goes to the side stream with it; the launch chain whose launches a second stream slowed is no longer the default.)
+  const bool use_side = bt_use_side() || on_side;
   hipStream_t main = ctx->stream, q = main;
   const bool prof = ctx->profiling;
   if (use_side) {
@@ -817,7 +912,7 @@ static void bt_wy_apply(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, i
   const int P = (nmax - 3) / BT_KB + 1, NP = (P + 1) / 2;
   constexpr int BT_S = 6;
   double *const *dptr = w.btptr.p;
-  if (bt_use_side()) HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));
+  if (bt_use_side()) HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));  // (not reached when X Q was folded)
   static const int acc_tile = getenv("HELFEM_ACC_TILE") ? atoi(getenv("HELFEM_ACC_TILE")) : 0;  // A/B runs: 64 or 128
   // pairs of reflector blocks, last to first: three launches and one read-modify-write of Z per 128 reflectors
   for (int g = NP - 1; g >= 0; g--) {
@@ -831,7 +926,46 @@ static void bt_wy_apply(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, i
   HFG_HIP_CHECK(hipGetLastError());
 }
 
-static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
+// X Q on the side stream, beside the divide-and-conquer stage (which needs d and e only and keeps few CUs busy):
+// the compact-WY set-up (bt_wy_prepare, same stream), Y = X^T, then the pairs of reflector blocks first to last.
+// side_ev[0]: reflectors and tau are complete (main stream); side_ev[1]: Y = (X Q)^T is complete.
+static void bt_wy_fold_x(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, const int *ns, int nmax, const double *const *X) {
+  const int P = (nmax - 3) / BT_KB + 1, NP = (P + 1) / 2;
+  constexpr int BT_S = 6;
+  hipStream_t main = ctx->stream, q = ctx->side();  // (bt_wy_prepare ran on q behind the tridiagonalisation: stream order)
+  const bool prof = ctx->profiling;
+  ctx->profiling = false;  // the profiling brackets are events of the main stream
+  ctx->stream = q;
+  try {
+    TrPtrs t;
+    for (int k = 0; k < MAXB; k++) {
+      t.src[k] = k < nblk ? X[k] : nullptr;
+      t.dst[k] = k < nblk ? w.Y[k].p : nullptr;
+      t.n[k] = k < nblk ? ns[k] : 0;
+    }
+    hipLaunchKernelGGL(k_transpose_batch, dim3((nmax + 63) / 64, (nmax + 63) / 64, nblk), dim3(256), 0, q, t);
+    double *const *dptr = w.btptr.p;
+    for (int g = 0; g < NP; g++) {
+      gemm_tasklist64_dev(ctx, w.btslabR.p + (size_t)g * BT_S * nblk, BT_S * nblk, BT_PW, nmax);
+      hipLaunchKernelGGL(k_bt_wpair, dim3((nmax + 4 * BT_WREP - 1) / (4 * BT_WREP), nblk), dim3(256), 0, q, b, dptr + 3 * nblk, dptr + 4 * nblk,
+                         dptr + 5 * nblk, BT_S, BT_GS, NP, g, 1);
+      gemm_tasklist_acc_dev(ctx, w.btupdR.p + (size_t)g * nblk, nblk, nmax, nmax, true);
+    }
+  } catch (...) {
+    ctx->stream = main;
+    ctx->profiling = prof;
+    throw;
+  }
+  ctx->stream = main;
+  ctx->profiling = prof;
+  HFG_HIP_CHECK(hipGetLastError());
+  HFG_HIP_CHECK(hipEventRecord(ctx->side_ev[1], q));
+}
+
+/// foldX != nullptr (device pointers of the blocks' X, n x n, ld n): the caller wants C = X Q Z; then X Q is formed beside
+/// the divide-and-conquer stage (w.Y = (X Q)^T, w.folded = true), w.Z keeps the tridiagonal matrix's eigenvectors and
+/// the caller multiplies Y^T Z.  Otherwise (and when the compact-WY path does not apply) Z <- Q Z as before.
+static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns, const double *const *foldX = nullptr) {
   EigBatch b;
   b.nblk = nblk;
   int nmax = 0;
@@ -864,7 +998,12 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
   hipStream_t s = ctx->stream;
   static const bool bt_column = (getenv("HELFEM_BT") && !strcmp(getenv("HELFEM_BT"), "column"));
   const bool bt_wy = !bt_column && nmax >= 4 * BT_KB;
-  if (bt_wy) bt_wy_setup(ctx, w, b, nblk, ns, nmax);
+  static const bool fold_on = !(getenv("HELFEM_BT_FOLD") && atoi(getenv("HELFEM_BT_FOLD")) == 0);
+  const bool fold = bt_wy && foldX != nullptr && fold_on;
+  w.folded = fold;
+  if (fold)
+    for (int i = 0; i < nblk; i++) w.Y[i].resize((size_t)ns[i] * ns[i]);
+  if (bt_wy) bt_wy_setup(ctx, w, b, nblk, ns, nmax, fold);
   {
     ProfScope ps(ctx, "eig_tridiag");
     static const bool unblocked = (getenv("HELFEM_TRD") && !strcmp(getenv("HELFEM_TRD"), "unblocked"));
@@ -891,7 +1030,8 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
       tridiagonalize_batch(ctx, nblk, ns, Ap, dp, ep, tp);
     }
   }
-  if (bt_wy) bt_wy_prepare(ctx, w, b, nblk, nmax);
+  if (bt_wy) bt_wy_prepare(ctx, w, b, nblk, nmax, fold);
+  if (fold) bt_wy_fold_x(ctx, w, b, nblk, ns, nmax, foldX);
   {
     ProfScope ps(ctx, "eig_tridiag_solve");
     static const bool use_ql = (getenv("HELFEM_TRIDIAG") && !strcmp(getenv("HELFEM_TRIDIAG"), "ql"));
@@ -913,7 +1053,9 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns) {
   }
   {
     ProfScope ps(ctx, "eig_backtransform");
-    if (bt_wy) {
+    if (fold) {
+      HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));  // Y = (X Q)^T is complete
+    } else if (bt_wy) {
       bt_wy_apply(ctx, w, b, nblk, nmax);
     } else {
     dim3 grid((nmax + 3) / 4, nblk);
@@ -1088,7 +1230,8 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
     std::vector<int> ns(nb);
     // the three products of every block (F X, X^T (F X), X Z) go through one task-list launch each, so that the
     // blocks fill the chip together with 128 x 128 tiles
-    std::vector<GemmTask> gt(3 * (size_t)nb);
+    std::vector<GemmTask> gt(4 * (size_t)nb);  // [3 nb + k]: the last product when X Q was folded (eig_sym_batch): (X Q) Z = Y^T Z
+    const double *Xptr[MAXB];
     int nm = 0;
     for (int k = 0; k < nb; k++) {
       const int ib = mine[c0 + k] % nblk;
@@ -1098,7 +1241,9 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
       nm = std::max(nm, n);
       w.A[k].resize((size_t)n * n + 2);  // + 2: the sweep's 16-byte row pairs may straddle the last element
       w.Z[k].resize((size_t)n * n);
+      w.Y[k].resize((size_t)n * n);
       double *Xb = Xall.p + (size_t)k * nmax * nmax, *Fk = Fb.p + (size_t)k * nmax * nmax, *Tk = T1.p + (size_t)k * nmax * nmax;
+      Xptr[k] = Xb;
       GemmTask g;
       g.M = g.N = g.K = n;
       g.lda = g.ldb = g.ldc = n;
@@ -1118,6 +1263,9 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
       g.B = w.Z[k].p;
       g.C = dBlockBuf + (size_t)ib * slot;
       gt[2 * nb + k] = g;
+      g.A = w.Y[k].p;
+      g.tA = 1;
+      gt[3 * nb + k] = g;
     }
     upload_cached(w.gtasks, w.h_gtasks, gt, s);
     {
@@ -1167,16 +1315,17 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
       gemm_mirror_lower_dev(ctx, w.gtasks.p + nb, nb, nm);        // the tridiagonalisation sweeps the full square
       }
     }
-    eig_sym_batch(ctx, w, nb, ns.data());
+    eig_sym_batch(ctx, w, nb, ns.data(), Xptr);
     {
       ProfScope ps(ctx, "eig_backtransform");
       static const bool rect = getenv("HELFEM_GEMM_RECT") && atoi(getenv("HELFEM_GEMM_RECT"));
       {
         ProfScope pp3(ctx, "eig_products");
-        if (w.tile64) gemm_tasklist64_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
-        else if (w.split_full) gemm_tasklist_split2_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);  // the block slots were zeroed above
-        else if (rect) gemm_tasklist_rect_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
-        else gemm_tasklist_dev(ctx, w.gtasks.p + 2 * nb, nb, nm, nm);
+        const GemmTask *last = w.gtasks.p + (w.folded ? 3 : 2) * (size_t)nb;
+        if (w.tile64) gemm_tasklist64_dev(ctx, last, nb, nm, nm);
+        else if (w.split_full) gemm_tasklist_split2_dev(ctx, last, nb, nm, nm);  // the block slots were zeroed above
+        else if (rect) gemm_tasklist_rect_dev(ctx, last, nb, nm, nm);
+        else gemm_tasklist_dev(ctx, last, nb, nm, nm);
       }
       for (int k = 0; k < nb; k++) {
         const int ib = mine[c0 + k] % nblk;
