@@ -422,9 +422,10 @@ def main():
         traffic = None
         traffic_file = None
         try:
-            if args.workload == "n2_pbe_nbf4230" and world == 1:
+            if world == 1:
                 import glob
-                traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]
+                pat = "r[0-9][0-9]_pmc_traffic.json" if args.workload == "n2_pbe_nbf4230" else "r[0-9][0-9]_exchange_pmc_traffic_%s.json" % args.workload
+                traffic_file = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]
                 with open(traffic_file) as fh:
                     tj = json.load(fh)
                 meta = tj.pop("_meta", {})
@@ -503,9 +504,9 @@ def main():
                         tj = json.load(fh)
                     meta = tj.pop("_meta", {})
                     if meta.get("kernel_sources_sha256", kernel_sources_sha()) == kernel_sources_sha():
-                        for kname, rec in tj.items():
-                            if "k_dgemm_tasklist_wl" in kname:
-                                ktraffic = rec.get("traffic_bytes_per_launch")
+                        for kname, rec in tj.items():  # the element GEMM is the <128, 128, false> (or <128, 64, false>) instance; <..., true> are the cross products
+                            if "k_dgemm_tasklist_wl" in kname and "false>" in kname and rec.get("traffic_bytes_per_launch") is not None:
+                                ktraffic = max(ktraffic or 0.0, rec["traffic_bytes_per_launch"])
             except Exception:
                 ktraffic = None
             out["roofline_tridiagonalisation"] = out["roofline"]
