@@ -1415,6 +1415,32 @@ void fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, co
   const size_t nc = fock_compact_size(basis);
   a.Pc.resize(nc);
   a.Jc.resize(nc);
+  // J and the XC matrix are independent given the compact density: the Coulomb kernels (one of them streams the 1 GB of
+  // primitive integrals: HBM-bound) run on the context's side stream beside the XC kernels (LDS- and latency-bound)
+  // -- HELFEM_FOCK_OVERLAP=0: one after the other on the main stream
+  static const bool overlap = !(getenv("HELFEM_FOCK_OVERLAP") && atoi(getenv("HELFEM_FOCK_OVERLAP")) == 0);
+  if ((x_func > 0 || c_func > 0) && overlap) {
+    hipStream_t main = ctx->stream, q = ctx->side();
+    gather_compact(ctx, basis, dP, a.Pc.p);
+    HFG_HIP_CHECK(hipEventRecord(ctx->side_ev[0], main));
+    HFG_HIP_CHECK(hipStreamWaitEvent(q, ctx->side_ev[0], 0));
+    ctx->stream = q;
+    try {
+      ProfScope ps(ctx, "coulomb");  // (its events go to the side stream with the kernels)
+      coulomb_compact(ctx, basis, a.Pc.p, dFc);
+    } catch (...) {
+      ctx->stream = main;
+      throw;
+    }
+    ctx->stream = main;
+    HFG_HIP_CHECK(hipEventRecord(ctx->side_ev[1], q));
+    ProfScope ps(ctx, "xc");
+    xc_compact(ctx, basis, x_func, c_func, a.Pc.p, a.Jc.p, dScal, thr);
+    HFG_HIP_CHECK(hipStreamWaitEvent(main, ctx->side_ev[1], 0));
+    hipLaunchKernelGGL(k_add_inplace, dim3(2048), dim3(256), 0, ctx->stream, dFc, a.Jc.p, nc);
+    HFG_HIP_CHECK(hipGetLastError());
+    return;
+  }
   {
     ProfScope ps(ctx, "coulomb");
     gather_compact(ctx, basis, dP, a.Pc.p);
