@@ -29,7 +29,7 @@ void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha,
 void gemm_tasklist_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
-void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg, bool rect);
+void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg, int tiles);
 void gemm_tasklist_wl_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg);
 void gemm_tasklist_split2_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 
@@ -1444,15 +1444,18 @@ bool exchange_lowrank_dev(hfg_ctx *ctx, hfg_dev_tables *t, const double *dP, dou
     }
     if (!wl_off) {
       // all tiles of a task on one XCD (its element table is then fetched from HBM once, not by all eight L2s)
-      const int BNt = rect_tiles ? 64 : 128;
+      // short pair lists: 64 x 64 tiles (three workgroups per CU; 5.71 against 6.08 ms with 128 x 64 at Nbf = 4230); long lists:
+      // 128 x 128 (15.5 against 15.8 ms with 64 x 64 at Nbf = 6102).  HELFEM_EXL_RECT = 0 / 1 / 2 forces 128 x 128 / 128 x 64 / 64 x 64
+      const int tile_mode = rect_env >= 0 ? rect_env : (rect_tiles ? 2 : 0);
+      const int BMt = tile_mode == 2 ? 64 : 128, BNt = tile_mode == 0 ? 128 : 64;
       std::vector<int2> &wl = a.h_gwl;
       wl.clear();
       for (size_t k = 0; k < tasks.size(); k++) {
-        const int nt = ((tasks[k].M + 127) / 128) * ((tasks[k].N + BNt - 1) / BNt);
+        const int nt = ((tasks[k].M + BMt - 1) / BMt) * ((tasks[k].N + BNt - 1) / BNt);
         for (int q = 0; q < nt; q++) wl.push_back(make_int2((int)k, q));
       }
       a.gwl.upload(wl, s);  // (h_gwl lives in the aux until the synchronisation at the end of the build)
-      gemm_tasklist_wl_dev(ctx, a.tasks.p, a.gwl.p, (int)wl.size(), rect_tiles);
+      gemm_tasklist_wl_dev(ctx, a.tasks.p, a.gwl.p, (int)wl.size(), tile_mode);
     } else if (rect_tiles) gemm_tasklist_rect_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
     else gemm_tasklist_dev(ctx, a.tasks.p, (int)tasks.size(), pp, maxN);
   }

@@ -492,11 +492,13 @@ void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, 
 }
 
 /// task list with a workgroup list (task, tile) in XCD order; rect: 128 x 64 tiles, else 128 x 128 (beta == 0 tasks, no sym)
-void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg, bool rect) {
+/// tiles: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64 (the work list must have been enumerated with the same tile shape)
+void gemm_tasklist_wl_dev(hfg_ctx *ctx, const GemmTask *dtasks, const int2 *dwl, int nwg, int tiles) {
   if (nwg <= 0) return;
   ProfScope ps(ctx, "gemm");
   const unsigned grid = 8u * (unsigned)((nwg + 7) / 8);
-  if (rect) hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 64>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
+  if (tiles == 2) hipLaunchKernelGGL((k_dgemm_tasklist_wl<64, 64>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
+  else if (tiles == 1) hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 64>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
   else hipLaunchKernelGGL((k_dgemm_tasklist_wl<128, 128>), dim3(grid), dim3(256), 0, ctx->stream, dtasks, dwl, nwg);
   HFG_HIP_CHECK(hipGetLastError());
 }
