@@ -375,10 +375,16 @@ def test_device_tei_tables_at_the_bench_element_order(hf):
 @pytest.mark.parametrize("env", [dict(HELFEM_TRD="twokernel"), dict(HELFEM_BT="column"),
                                  dict(HELFEM_TRD="unblocked", HELFEM_BT="column"), dict(HELFEM_TRDF_SYM="1"),
                                  dict(HELFEM_TRDF_SYM="0"), dict(HELFEM_TRDF_NTH="512", HELFEM_TRDF_SYM="1"),
-                                 dict(HELFEM_BT_SIDE="1"), dict(HELFEM_TRD_TAIL="0"), dict(HELFEM_TRD_TAIL="1")],
+                                 dict(HELFEM_BT_SIDE="1", HELFEM_BT_FOLD="0"), dict(HELFEM_TRD_TAIL="0"), dict(HELFEM_TRD_TAIL="1"),
+                                 dict(HELFEM_TRD="chain"), dict(HELFEM_TRD="chain", HELFEM_TRDF_SYM="0"),
+                                 dict(HELFEM_TRDP_PHASES="0"), dict(HELFEM_TRDP_STEP="1000"), dict(HELFEM_BT_FOLD="0"),
+                                 dict(HELFEM_DC_GEMM="small"), dict(HELFEM_GEMM_TILE="128"), dict(HELFEM_GEMM_TILE="64"),
+                                 dict(HELFEM_GEMM_SPLITK="1")],
                          ids=["two_launches_per_column", "column_backtransform", "unblocked_tridiagonalisation",
                               "symmetric_sweep_everywhere", "full_sweep_everywhere", "symmetric_sweep_512_threads",
-                              "wy_setup_on_side_stream", "no_tail_kernel", "lds_tail_kernel"])
+                              "wy_setup_on_side_stream", "no_tail_kernel", "lds_tail_kernel", "launch_chain",
+                              "launch_chain_full_sweep", "persistent_one_launch", "persistent_long_phases",
+                              "backtransform_on_Z", "small_dc_gemm", "tiles_128", "tiles_64", "split_k_products"])
 def test_fallback_variants(native_libs, env):
     """the earlier kernel variants stay selectable (environment, read once per process) and stay correct"""
     import os
