@@ -666,17 +666,17 @@ static int tp_columns_for(int nmax) {
   return 0;
 }
 
-/// Persistent path of tridiagonalize_batch.  The matrices are dealt into GROUPS that each fit the chip's register file
-/// (the three blocks 1380/1470/1380 of the bench workload are one group, the blocks 2100/2001/2001 of the LiF sizing two
-/// -- {2100} and {2001, 2001}), and a group is reduced in PHASES, one cooperative launch each, one after the other on the
-/// stream: a launch reduces the leading columns until the largest trailing matrix fits the next narrower tile, writes
-/// the trailing matrices back, and the next launch takes them up as matrices of their own -- fewer column chunks AND fewer
-/// rows per thread, all workgroups busy again.  (The time of a column follows the tile width the kernel is compiled
-/// for: 2.55 / 3.21 / 3.41 us per column for the same 700-row matrices with 6 / 12 / 16 chunks; a phase boundary costs a
-/// launch and one pass over the trailing matrix, some 20 us.)  done[i] says which matrices were factorised; the caller
-/// runs its chain of launches on the others (order beyond the register tiles, the runtime refusing a cooperative
-/// launch, HELFEM_TRD selecting another variant: nothing is touched then).  Same outputs as the chain: d, e, tau,
-/// reflectors below the subdiagonal.
+/// Persistent path of tridiagonalize_batch.  The matrices are reduced in PHASES, one cooperative launch each, one after
+/// the other on the stream: a launch takes the matrices with the largest trailing orders that fit the chip's register
+/// file together (the three blocks 1380/1470/1380 of the bench workload from the start; of the blocks 2100/2001/2001 of
+/// the LiF sizing first the largest alone, then pairs, and all three once they are down to 1536), reduces their leading
+/// columns until the largest trailing matrix fits the next narrower tile, writes the trailing matrices back, and the
+/// next launch takes them up as matrices of their own -- fewer column chunks AND fewer rows per thread, all workgroups
+/// busy again.  (The time of a column follows the tile width the kernel is compiled for: 2.55 / 3.21 / 3.41 us per
+/// column for the same 700-row matrices with 6 / 12 / 16 chunks; a phase boundary costs a launch and one pass over the
+/// trailing matrix, some 20 us.)  done[i] says which matrices were factorised; the caller runs its chain of launches on
+/// the others (order beyond the register tiles, the runtime refusing a cooperative launch, HELFEM_TRD selecting another
+/// variant: nothing is touched then).  Same outputs as the chain: d, e, tau, reflectors below the subdiagonal.
 void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *const *A, double *const *d, double *const *e,
                                double *const *tau, std::vector<char> &done) {
   done.assign(nblk, 0);
@@ -735,101 +735,100 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   for (int i = 0; i < nblk; i++)
     if (ns[i] >= 3 && ns[i] >= min_order) order.push_back(i);
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ns[x] > ns[y]; });
-  std::vector<std::vector<int>> groups;
-  {
-    std::vector<int> cur, cur_orders;
-    for (int i : order) {
-      std::vector<int> trial = cur_orders;
-      trial.push_back(ns[i]);
-      Shape t;
-      if (fit(trial, t)) {
-        cur.push_back(i);
-        cur_orders = trial;
-      } else {
-        if (!cur.empty()) groups.push_back(cur);
-        cur.clear();
-        cur_orders.clear();
-        if (fit(std::vector<int>(1, ns[i]), t)) {
-          cur.assign(1, i);
-          cur_orders.assign(1, ns[i]);
-        }  // else: this matrix stays with the chain
-      }
-    }
-    if (!cur.empty()) groups.push_back(cur);
-  }
-  if (groups.empty()) return;
-  // ---- launches: per group one per phase (descriptors identical from one SCF iteration to the next: uploaded once) ----
+  // ---- launches (descriptors identical from one SCF iteration to the next: uploaded once).  Before every launch the
+  // matrices still to be reduced are looked at again, largest trailing order first, and the launch takes every one of
+  // them that fits beside the ones already taken: the 2100-block of the LiF sizing runs alone until it is down to 1792,
+  // the two 2001-blocks as a pair until they are, pairs of the three until all are at 1536 -- and from there the three
+  // are reduced together, like the three blocks of the bench workload from the start (they used to be two groups that
+  // ran one after the other to the end: 14.9 ms). ----
   struct Launch {
     Shape sh;
     size_t ring_words;
     std::vector<int> idx;  // matrices in it
     int nmax;
   };
+  struct Act {
+    int i, rem, off;
+  };
+  std::vector<Act> act;
+  for (int i : order) {
+    Shape t;
+    if (fit(std::vector<int>(1, ns[i]), t)) act.push_back(Act{i, ns[i], 0});  // else: this matrix stays with the chain
+  }
+  if (act.empty()) return;
   std::vector<Launch> launches;
   std::vector<TrdpDesc> descs;
   size_t ring_words = 0;
   int nmax_all = 0;
-  for (const std::vector<int> &grp : groups) {
-    std::vector<int> act = grp, rem, off;
-    for (int i : grp) {
-      rem.push_back(ns[i]);
-      off.push_back(0);
-    }
-    while (!act.empty()) {
-      Launch L;
-      if (!fit(rem, L.sh)) return;  // cannot happen: a trailing matrix is smaller than the matrix that fitted
-      int nmax = 0;
-      for (int o : rem) nmax = std::max(nmax, o);
-      // columns of this phase: until the largest trailing matrix fits the next narrower tile (at least min_step columns)
-      int step = 0x3fffffff;
-      if (phases && !want_stamps)
-        for (int q = (int)(sizeof(tp_widths) / sizeof(int)) - 1; q >= 0; q--)
-          if (tp_widths[q] < L.sh.U && nmax - tp_widths[q] * TP_NCG >= min_step) {
-            step = nmax - tp_widths[q] * TP_NCG;
-            break;
-          }
-      const int M = TP_NRG * L.sh.R, NP = TP_NCG * L.sh.U;
-      TrdpDesc D = TrdpDesc{};
-      D.nblk = (int)act.size();
-      size_t words = 16;
-      int wg = 0;
-      std::vector<int> act2, rem2, off2;
-      for (int b = 0; b < D.nblk; b++) {
-        const int i = act[b];
-        const int G = (rem[b] + M - 1) / M;
-        const size_t o = (size_t)off[b];
-        D.wg0[b] = wg;
-        wg += G;
-        D.n[b] = rem[b];
-        D.G[b] = G;
-        D.lda[b] = ns[i];
-        D.A[b] = A[i] + o * (size_t)ns[i] + o;
-        D.d[b] = d[i] + o;
-        D.e[b] = e[i] + o;
-        D.tau[b] = tau[i] + o;
-        D.xb[b] = (unsigned long long *)words;  // offset for now, the base is added below
-        words += (size_t)TP_SLOTS * ((size_t)2 * NP + 64 + TP_MAXG);
-        if (rem[b] - step >= 3) {
-          D.jstop[b] = step;
-          act2.push_back(i);
-          rem2.push_back(rem[b] - step);
-          off2.push_back(off[b] + step);
-        } else
-          D.jstop[b] = 0x3fffffff;  // runs to its end in this launch
-        L.idx.push_back(i);
+  while (!act.empty()) {
+    std::stable_sort(act.begin(), act.end(), [](const Act &x, const Act &y) { return x.rem > y.rem; });
+    Launch L;
+    std::vector<int> take, orders;  // positions in act
+    for (size_t q = 0; q < act.size() && (int)take.size() < TP_MAXB; q++) {
+      std::vector<int> trial = orders;
+      trial.push_back(act[q].rem);
+      Shape t;
+      if (fit(trial, t)) {
+        take.push_back((int)q);
+        orders = trial;
+        L.sh = t;
       }
-      for (int b = D.nblk; b <= TP_MAXB; b++) D.wg0[b] = wg;
-      words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
-      L.ring_words = words;
-      L.nmax = nmax;
-      ring_words = std::max(ring_words, words);
-      nmax_all = std::max(nmax_all, nmax);
-      launches.push_back(L);
-      descs.push_back(D);
-      act = act2;
-      rem = rem2;
-      off = off2;
     }
+    if (take.empty()) return;  // cannot happen: every matrix fitted alone at its full order
+    const int nmax = orders[0];
+    // columns of this launch: until the largest trailing matrix fits the next narrower tile (at least min_step columns)
+    int step = 0x3fffffff;
+    if (phases && !want_stamps)
+      for (int q = (int)(sizeof(tp_widths) / sizeof(int)) - 1; q >= 0; q--)
+        if (tp_widths[q] < L.sh.U && nmax - tp_widths[q] * TP_NCG >= min_step) {
+          step = nmax - tp_widths[q] * TP_NCG;
+          break;
+        }
+    const int M = TP_NRG * L.sh.R, NP = TP_NCG * L.sh.U;
+    TrdpDesc D = TrdpDesc{};
+    D.nblk = (int)take.size();
+    size_t words = 16;
+    int wg = 0;
+    std::vector<char> finished(act.size(), 0);
+    for (int b = 0; b < D.nblk; b++) {
+      Act &a = act[take[b]];
+      const int i = a.i;
+      const int G = (a.rem + M - 1) / M;
+      const size_t o = (size_t)a.off;
+      D.wg0[b] = wg;
+      wg += G;
+      D.n[b] = a.rem;
+      D.G[b] = G;
+      D.lda[b] = ns[i];
+      D.A[b] = A[i] + o * (size_t)ns[i] + o;
+      D.d[b] = d[i] + o;
+      D.e[b] = e[i] + o;
+      D.tau[b] = tau[i] + o;
+      D.xb[b] = (unsigned long long *)words;  // offset for now, the base is added below
+      words += (size_t)TP_SLOTS * ((size_t)2 * NP + 64 + TP_MAXG);
+      if (a.rem - step >= 3) {
+        D.jstop[b] = step;
+        a.rem -= step;
+        a.off += step;
+      } else {
+        D.jstop[b] = 0x3fffffff;  // runs to its end in this launch
+        finished[take[b]] = 1;
+      }
+      L.idx.push_back(i);
+    }
+    for (int b = D.nblk; b <= TP_MAXB; b++) D.wg0[b] = wg;
+    words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
+    L.ring_words = words;
+    L.nmax = nmax;
+    ring_words = std::max(ring_words, words);
+    nmax_all = std::max(nmax_all, nmax);
+    launches.push_back(L);
+    descs.push_back(D);
+    std::vector<Act> rest;
+    for (size_t q = 0; q < act.size(); q++)
+      if (!finished[q]) rest.push_back(act[q]);
+    act = rest;
+    if ((int)launches.size() > TP_MAXLAUNCH) return;
   }
   if ((int)launches.size() > TP_MAXLAUNCH) return;
   w.ring.resize(ring_words);  // the launches run one after the other on the stream and share the ring
