@@ -549,7 +549,8 @@ struct TrdpWork {
   DevBuf<unsigned long long> stamps;
   DevBuf<TrdpDesc> desc;
   std::vector<TrdpDesc> h_desc;
-  int *h_status = nullptr;  // pinned: the status word of the last launch, copied back asynchronously
+  unsigned long long *h_status = nullptr;  // pinned: the status words of the last batch's launches, copied back asynchronously
+  bool pending_this_batch = false;
   bool pending = false;
   int ncu = 0;
   std::vector<int> last_ns;
@@ -574,8 +575,8 @@ void trdp_check_status(hfg_ctx *ctx) {
   w.pending = false;
   bool bad = false;
   for (int q = 0; q < TP_MAXLAUNCH; q++) {
-    bad = bad || w.h_status[q] == 1;
-    w.h_status[q] = -1;
+    bad = bad || (int)(w.h_status[q] & 0xffffffffull) == 1;
+    w.h_status[q] = ~0ull;
   }
   if (bad) throw std::runtime_error("persistent tridiagonalisation: an exchange between workgroups ran into its time limit");
   // HELFEM_TRDP_STAMPS=1 (measurement builds of the kernel): phase durations of the last launch, printed once per launch
@@ -690,8 +691,8 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     wp = new TrdpWork();
     g_trdp[ctx] = wp;
     HFG_HIP_CHECK(hipDeviceGetAttribute(&wp->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    HFG_HIP_CHECK(hipHostMalloc((void **)&wp->h_status, TP_MAXLAUNCH * sizeof(int), hipHostMallocDefault));
-    for (int i = 0; i < TP_MAXLAUNCH; i++) wp->h_status[i] = -1;
+    HFG_HIP_CHECK(hipHostMalloc((void **)&wp->h_status, TP_MAXLAUNCH * sizeof(unsigned long long), hipHostMallocDefault));
+    for (int i = 0; i < TP_MAXLAUNCH; i++) wp->h_status[i] = ~0ull;
   } else
     wp = it->second;
   TrdpWork &w = *wp;
@@ -758,7 +759,7 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
   if (act.empty()) return;
   std::vector<Launch> launches;
   std::vector<TrdpDesc> descs;
-  size_t ring_words = 0;
+  size_t ring_words = 2 * TP_MAXLAUNCH;  // status words of the launches first (one 8-byte word each, 16-byte aligned regions behind)
   int nmax_all = 0;
   while (!act.empty()) {
     std::stable_sort(act.begin(), act.end(), [](const Act &x, const Act &y) { return x.rem > y.rem; });
@@ -787,7 +788,7 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     const int M = TP_NRG * L.sh.R, NP = TP_NCG * L.sh.U;
     TrdpDesc D = TrdpDesc{};
     D.nblk = (int)take.size();
-    size_t words = 16;
+    size_t words = 0;
     int wg = 0;
     std::vector<char> finished(act.size(), 0);
     for (int b = 0; b < D.nblk; b++) {
@@ -818,9 +819,9 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     }
     for (int b = D.nblk; b <= TP_MAXB; b++) D.wg0[b] = wg;
     words = (words + 1) & ~(size_t)1;  // a multiple of 16 bytes for the poisoning memset
-    L.ring_words = words;
+    L.ring_words = ring_words;  // (here: the launch's offset in the ring; every launch has its own region)
     L.nmax = nmax;
-    ring_words = std::max(ring_words, words);
+    ring_words += words;
     nmax_all = std::max(nmax_all, nmax);
     launches.push_back(L);
     descs.push_back(D);
@@ -831,13 +832,14 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     if ((int)launches.size() > TP_MAXLAUNCH) return;
   }
   if ((int)launches.size() > TP_MAXLAUNCH) return;
-  w.ring.resize(ring_words);  // the launches run one after the other on the stream and share the ring
+  w.ring.resize(ring_words);  // one region per launch: ONE poisoning memset in front of the first launch, one copy of the status words behind the last
   const size_t win_off = (size_t)8 * (nmax_all + 2);
   if (want_stamps) w.stamps.resize(win_off + (size_t)TP_MAXG * TP_WIN_N * 4 + TP_MAXG);
   static const long long limit_ms = getenv("HELFEM_TRDP_LIMIT_MS") ? atoll(getenv("HELFEM_TRDP_LIMIT_MS")) : 200;
-  for (TrdpDesc &D : descs) {
-    for (int b = 0; b < D.nblk; b++) D.xb[b] = w.ring.p + (size_t)D.xb[b];
-    D.status = (int *)w.ring.p;
+  for (size_t q = 0; q < descs.size(); q++) {
+    TrdpDesc &D = descs[q];
+    for (int b = 0; b < D.nblk; b++) D.xb[b] = w.ring.p + launches[q].ring_words + (size_t)D.xb[b];
+    D.status = (int *)(w.ring.p + q);
     D.stamps = want_stamps ? w.stamps.p : nullptr;
     D.win_off = (long long)win_off;
     D.spin_limit = limit_ms * 100000ll;  // 100 MHz wall clock
@@ -853,7 +855,10 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
     if (skip) continue;
     trdp_kernel_t kern = trdp_pick(L.sh.R, L.sh.U, want_stamps);
     if (want_stamps && q == 0) HFG_HIP_CHECK(hipMemsetAsync(w.stamps.p, 0, w.stamps.n * 8, s));
-    HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, L.ring_words * sizeof(unsigned long long), s));
+    if (!w.pending_this_batch) {
+      HFG_HIP_CHECK(hipMemsetAsync(w.ring.p, 0xFF, ring_words * sizeof(unsigned long long), s));
+      w.pending_this_batch = true;
+    }
     const TrdpDesc *dptr = w.desc.p + q;
     void *args[] = {(void *)&dptr};
     hipError_t err;
@@ -881,7 +886,6 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
       for (int i : L.idx) failed[i] = 1;  // the chain takes these matrices
       continue;
     }
-    HFG_HIP_CHECK(hipMemcpyAsync(w.h_status + q, w.ring.p, sizeof(int), hipMemcpyDeviceToHost, s));
     w.pending = true;
     for (int i : L.idx) touched[i] = 1;
     if (w.last_ns.empty()) {
@@ -892,6 +896,8 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
       w.last_nmax = nmax_all;
     }
   }
+  if (w.pending_this_batch) HFG_HIP_CHECK(hipMemcpyAsync(w.h_status, w.ring.p, TP_MAXLAUNCH * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  w.pending_this_batch = false;
   for (int i = 0; i < nblk; i++) done[i] = touched[i] && !failed[i];
 }
 
