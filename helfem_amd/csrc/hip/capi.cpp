@@ -86,6 +86,15 @@ hipStream_t hfg_ctx::side() {
   }
   return side_stream;
 }
+void hfg_ctx::drop_side() {
+  if (!side_stream) return;
+  (void)hipStreamSynchronize(side_stream);
+  (void)hipStreamDestroy(side_stream);
+  (void)hipEventDestroy(side_ev[0]);
+  (void)hipEventDestroy(side_ev[1]);
+  side_stream = nullptr;
+  side_ev[0] = side_ev[1] = nullptr;
+}
 void *hfg_ctx::pinned_buf(size_t bytes) {
   if (bytes > pinned_bytes) {
     if (pinned) (void)hipHostFree(pinned);

@@ -85,6 +85,12 @@ struct hfg_ctx {
   hipStream_t side_stream = nullptr;
   hipEvent_t side_ev[2] = {nullptr, nullptr};
   hipStream_t side();
+  // A second live stream costs every launch of this context about 1.2 us (measured: the launch chain of the
+  // tridiagonalisation 12.05 -> 13.3 ms at 1380/1470/1380, 67.9 -> 72.9 ms for one 4230-matrix).  A batch that takes the
+  // chain for a large matrix therefore gives the side stream up for good: drop_side() destroys it, avoid_side keeps the
+  // Fock build and the eigensolve from creating it again (their overlaps are worth less than the chain loses).
+  bool avoid_side = false;
+  void drop_side();
   int shard_rank = 0, shard_n = 1;
   // hfg_ctx_fix_sinvh: the caller's promise that the device matrix at this address keeps its contents (S^{-1/2} of an
   // SCF run); eig_blocks_dev then derives the blocks' column supports from it once instead of in every iteration

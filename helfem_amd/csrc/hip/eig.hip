@@ -27,6 +27,7 @@ void gemm_tasklist_rect_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, in
 void gemm_tasklist_split2_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 void gemm_tasklist64_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN);
 bool gemm_prefers_128(hfg_ctx *ctx, long tiles128);
+bool tridiagonalize_takes_chain(int nblk, const int *ns);  // trdp.hip
 void gemm_tasklist_acc_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxM, int maxN, bool tile64);
 void gemm_mirror_lower_dev(hfg_ctx *ctx, const GemmTask *dtasks, int ntasks, int maxN);
 void gemm_dev(hfg_ctx *ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double *A, int lda,
@@ -880,7 +881,7 @@ static void bt_wy_prepare(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk,
   // tridiagonalisation alone went from 17.4 to 19.1 ms), so the default keeps everything on the context's stream.
   // (Round 3: with X Q folded beside the divide-and-conquer stage -- bt_wy_fold_x, which needs these operands -- the set-up
   // goes to the side stream with it; the launch chain whose launches a second stream slowed is no longer the default.)
-  const bool use_side = bt_use_side() || on_side;
+  const bool use_side = (bt_use_side() && !ctx->avoid_side) || on_side;
   hipStream_t main = ctx->stream, q = main;
   const bool prof = ctx->profiling;
   if (use_side) {
@@ -912,7 +913,7 @@ static void bt_wy_apply(hfg_ctx *ctx, EigWork &w, const EigBatch &b, int nblk, i
   const int P = (nmax - 3) / BT_KB + 1, NP = (P + 1) / 2;
   constexpr int BT_S = 6;
   double *const *dptr = w.btptr.p;
-  if (bt_use_side()) HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));  // (not reached when X Q was folded)
+  if (bt_use_side() && !ctx->avoid_side) HFG_HIP_CHECK(hipStreamWaitEvent(s, ctx->side_ev[1], 0));  // (not reached when X Q was folded)
   static const int acc_tile = getenv("HELFEM_ACC_TILE") ? atoi(getenv("HELFEM_ACC_TILE")) : 0;  // A/B runs: 64 or 128
   // pairs of reflector blocks, last to first: three launches and one read-modify-write of Z per 128 reflectors
   for (int g = NP - 1; g >= 0; g--) {
@@ -999,7 +1000,11 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns, con
   static const bool bt_column = (getenv("HELFEM_BT") && !strcmp(getenv("HELFEM_BT"), "column"));
   const bool bt_wy = !bt_column && nmax >= 4 * BT_KB;
   static const bool fold_on = !(getenv("HELFEM_BT_FOLD") && atoi(getenv("HELFEM_BT_FOLD")) == 0);
-  const bool fold = bt_wy && foldX != nullptr && fold_on;
+  if (tridiagonalize_takes_chain(nblk, ns)) {  // thousands of dependent launches ahead: no second stream beside them
+    ctx->avoid_side = true;
+    ctx->drop_side();
+  }
+  const bool fold = bt_wy && foldX != nullptr && fold_on && !ctx->avoid_side;
   w.folded = fold;
   if (fold)
     for (int i = 0; i < nblk; i++) w.Y[i].resize((size_t)ns[i] * ns[i]);
@@ -1075,7 +1080,8 @@ static void eig_sym_batch(hfg_ctx *ctx, EigWork &w, int nblk, const int *ns, con
   HFG_HIP_CHECK(hipGetLastError());
 }
 
-void trdp_check_status(hfg_ctx *ctx);  // trdp.hip
+bool tridiagonalize_takes_chain(int nblk, const int *ns);  // trdp.hip
+void trdp_check_status(hfg_ctx *ctx);        // trdp.hip
 static void check_status(hfg_ctx *ctx, EigWork &w, int nblk) {
   if (w.used_dc) {
     if (dc_status(ctx) != 0) throw std::logic_error("Eigendecomposition failed!\n");

@@ -1419,7 +1419,7 @@ void fock_compact_dev(hfg_ctx *ctx, hfg_basis *basis, int x_func, int c_func, co
   // primitive integrals: HBM-bound) run on the context's side stream beside the XC kernels (LDS- and latency-bound)
   // -- HELFEM_FOCK_OVERLAP=0: one after the other on the main stream
   static const bool overlap = !(getenv("HELFEM_FOCK_OVERLAP") && atoi(getenv("HELFEM_FOCK_OVERLAP")) == 0);
-  if ((x_func > 0 || c_func > 0) && overlap) {
+  if ((x_func > 0 || c_func > 0) && overlap && !ctx->avoid_side) {
     hipStream_t main = ctx->stream, q = ctx->side();
     gather_compact(ctx, basis, dP, a.Pc.p);
     HFG_HIP_CHECK(hipEventRecord(ctx->side_ev[0], main));

@@ -667,6 +667,16 @@ static int tp_columns_for(int nmax) {
   return 0;
 }
 
+/// true when a batch with these orders sends a LARGE matrix through the chain of launches (order beyond the register
+/// tiles, or HELFEM_TRD selecting another variant): eig.hip then keeps the context's side stream out of the way
+bool tridiagonalize_takes_chain(int nblk, const int *ns) {
+  static const char *mode = getenv("HELFEM_TRD");
+  const bool persistent = !(mode && strcmp(mode, "persistent") != 0);
+  for (int i = 0; i < nblk; i++)
+    if (ns[i] >= 1024 && (!persistent || tp_columns_for(ns[i]) == 0)) return true;
+  return false;
+}
+
 /// Persistent path of tridiagonalize_batch.  The matrices are reduced in PHASES, one cooperative launch each, one after
 /// the other on the stream: a launch takes the matrices with the largest trailing orders that fit the chip's register
 /// file together (the three blocks 1380/1470/1380 of the bench workload from the start; of the blocks 2100/2001/2001 of
