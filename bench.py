@@ -132,7 +132,9 @@ def stage_rooflines(basis, w, sizes, fams):
         if ms > 0:
             gbs = cbytes / (ms * 1e-3) / 1e9
             out.append({"stage": "coulomb (4 kernels)", "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
-                        "frac": gbs / 8000.0, "algorithmic_bytes": cbytes, "ms": ms})
+                        "frac": gbs / 8000.0, "algorithmic_bytes": cbytes, "ms": ms,
+                        "note": "HIP events on the side stream: the four kernels run beside the XC kernels of the main "
+                                "stream (HELFEM_FOCK_OVERLAP=0: alone, 0.41 ms = 3.3 TB/s)"})
     except Exception:
         pass
     ms = fams.get("eig_products", {}).get("ms_per_step", 0.0)
@@ -463,6 +465,9 @@ def main():
                        "name": args.workload, "parallelism": "shard%d" % world,
                        "density": "occupied orbitals of the core Hamiltonian" if args.density == "core"
                        else "seeded std::mt19937_64(20260130) block-diagonal orbitals (BASELINE.md section 2)",
+                       "streams": "two: the Coulomb kernels run beside the XC kernels, and X Q (the back-transformation folded "
+                                  "into X) beside the divide-and-conquer stage, on a side stream of the context; stages_ms "
+                                  "are HIP-event times on the stream a stage runs on and overlap where the stages do",
                        "timed_path": "device-resident step (hfg_*_dev entry points on HBM buffers: the loop body of hfg_scf_run, "
                                      "which the diatomic/atomic executables and helfem::gpu::run_scf call); the host-pointer "
                                      "entry points (hfg_coulomb, hfg_eig_gsym_sub, ...) add ~12 ms of PCIe per call"},
