@@ -879,7 +879,9 @@ void tridiagonalize_persistent(hfg_ctx *ctx, int nblk, const int *ns, double *co
       if (nm.empty()) nm = "k_trdp<" + std::to_string(L.sh.R) + ", " + std::to_string(L.sh.U) + ">";
       ProfScope pk(ctx, "k_trdp");
       ProfScope ps(ctx, nm.c_str());
-      err = hipLaunchCooperativeKernel((const void *)kern, dim3(L.sh.grid), dim3(TP_NT), args, 0, s);
+      static const bool coop = !(getenv("HELFEM_TRDP_COOP") && atoi(getenv("HELFEM_TRDP_COOP")) == 0);  // A/B: plain launch
+      if (coop) err = hipLaunchCooperativeKernel((const void *)kern, dim3(L.sh.grid), dim3(TP_NT), args, 0, s);
+      else err = hipLaunchKernel((const void *)kern, dim3(L.sh.grid), dim3(TP_NT), args, 0, s);
     }
     if (err != hipSuccess) {
       (void)hipGetLastError();  // refused (grid not co-resident on this device)
