@@ -6,7 +6,9 @@ registers for the whole factorisation).  Per Householder column there is ONE exc
   published by workgroup k  : y[R_k] = A^(j-1)[R_k, j+1:] x_j   (its rows of the product with the UNNORMALISED column x_j,
                               formed with a matrix that still lacks the rank-2 update of column j-1),
                               dot_k = sum_{r in R_k} x_j[r] y[r]
-  published by the owner of row j+1 : z = A^(j)[j+1, j+1:]       (that row fully updated)
+  published by the owner of row j+1 : z = A^(j)[j+1, j+1:]       (that row fully updated; the kernel publishes the same
+                              vector as COLUMN j+1 of the symmetric tile, every workgroup the entries of its own rows,
+                              raw and one exchange ahead -- who stores it does not change the algebra checked here)
 
 From (y, z, dots) and what it already has (x_j, v_{j-1}, w_{j-1} and three local sums) every workgroup derives
 redundantly, with the same arithmetic and the same summation orders, beta, tau, v_j, w_j, d[j+1] and the next column
