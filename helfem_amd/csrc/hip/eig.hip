@@ -632,6 +632,8 @@ __global__ __launch_bounds__(64) void k_bt_T(EigBatch b, double *const *__restri
 struct EigWork {
   bool split_full = false;  // this batch's full products run as two half-K workgroups per tile
   bool tile64 = false;
+  std::vector<int64_t> asm_rows;  // eig_assemble_dev: the index list whose device copy is asm_rows_dev
+  DevBuf<long long> asm_rows_dev;
   bool folded = false;      // the last batch formed Y = (X Q)^T beside the divide-and-conquer stage (bt_wy_fold_x)
   DevBuf<double> Y[MAXB];
   DevBuf<GemmTask> btslabR, btupdR;
@@ -674,6 +676,32 @@ void eig_release(hfg_ctx *ctx) {
 // (2) the part that needs only the reflectors -- explicit V, Gram matrices, T, V T -- queued on the context's side
 //     stream so that it runs beside the divide-and-conquer stage (which keeps few CUs busy),
 // (3) the sweep over the reflector blocks on the main stream.
+// up to 16 short vectors copied by ONE launch (eigenvalues into / out of the block slots: a device-to-device
+// hipMemcpyAsync costs 15-20 us of stream time each, seven of them 0.13 ms per step)
+struct CopySlices {
+  const double *src[16];
+  double *dst[16];
+  int n[16];
+};
+__global__ void k_copy_slices(CopySlices c) {
+  const int q = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n[q]; i += gridDim.x * blockDim.x) c.dst[q][i] = c.src[q][i];
+}
+static void copy_slices(hipStream_t s, const std::vector<const double *> &src, const std::vector<double *> &dst, const std::vector<int> &n) {
+  for (size_t q0 = 0; q0 < src.size(); q0 += 16) {
+    CopySlices c{};
+    const int m = (int)std::min<size_t>(16, src.size() - q0);
+    int nmax = 0;
+    for (int q = 0; q < m; q++) {
+      c.src[q] = src[q0 + q];
+      c.dst[q] = dst[q0 + q];
+      c.n[q] = n[q0 + q];
+      nmax = std::max(nmax, n[q0 + q]);
+    }
+    if (nmax > 0) hipLaunchKernelGGL(k_copy_slices, dim3((nmax + 255) / 256, m), dim3(256), 0, s, c);
+  }
+}
+
 // Y = X^T for every matrix of the batch (64 x 64 blocks through LDS)
 struct TrPtrs {
   const double *src[MAXB];
@@ -1333,12 +1361,17 @@ void eig_blocks_multi_dev(hfg_ctx *ctx, int N, int nF, const double *const *dFs,
         else if (rect) gemm_tasklist_rect_dev(ctx, last, nb, nm, nm);
         else gemm_tasklist_dev(ctx, last, nb, nm, nm);
       }
+      std::vector<const double *> csrc;
+      std::vector<double *> cdst;
+      std::vector<int> cn;
       for (int k = 0; k < nb; k++) {
         const int ib = mine[c0 + k] % nblk;
-        int n = ns[k];
         double *slotp = dBlockBufs[mine[c0 + k] / nblk] + (size_t)ib * slot;
-        HFG_HIP_CHECK(hipMemcpyAsync(slotp + nmax * nmax, w.d[k].p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        csrc.push_back(w.d[k].p);
+        cdst.push_back(slotp + nmax * nmax);
+        cn.push_back(ns[k]);
       }
+      copy_slices(s, csrc, cdst, cn);
     }
     check_status(ctx, w, nb);
   }
@@ -1351,19 +1384,29 @@ void eig_assemble_dev(hfg_ctx *ctx, int N, int nblk, const int64_t *blk_ptr, con
   EigWork &w = work_for(ctx);
   hipStream_t s = ctx->stream;
   ProfScope ps(ctx, "scatter");
-  DevBuf<double> &idxbuf = ctx->ws[2];
-  idxbuf.resize(2 * (size_t)N + 16);
-  int64_t *drows = (int64_t *)idxbuf.p;
-  HFG_HIP_CHECK(hipMemcpyAsync(drows, blk_idx, sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
+  // the row indices of the blocks: uploaded once per index list (an SCF run passes the same list every iteration; the copy
+  // from pageable host memory cost 25 us of stream time per call)
+  if (w.asm_rows.size() != (size_t)N || !std::equal(w.asm_rows.begin(), w.asm_rows.end(), blk_idx)) {
+    w.asm_rows.assign(blk_idx, blk_idx + N);
+    w.asm_rows_dev.resize((size_t)N + 2);
+    HFG_HIP_CHECK(hipMemcpyAsync(w.asm_rows_dev.p, w.asm_rows.data(), sizeof(int64_t) * N, hipMemcpyHostToDevice, s));
+  }
+  int64_t *drows = (int64_t *)w.asm_rows_dev.p;
   size_t nmax = 0;
   for (int ib = 0; ib < nblk; ib++) nmax = std::max<size_t>(nmax, blk_ptr[ib + 1] - blk_ptr[ib]);
   const size_t slot = nmax * nmax + nmax;
   DevBuf<double> &Etmp = ctx->ws[3];
   Etmp.resize(N);
-  for (int ib = 0; ib < nblk; ib++) {
-    size_t n = blk_ptr[ib + 1] - blk_ptr[ib];
-    HFG_HIP_CHECK(hipMemcpyAsync(Etmp.p + blk_ptr[ib], dBlockBuf + (size_t)ib * slot + nmax * nmax, sizeof(double) * n,
-                                 hipMemcpyDeviceToDevice, s));
+  {
+    std::vector<const double *> csrc;
+    std::vector<double *> cdst;
+    std::vector<int> cn;
+    for (int ib = 0; ib < nblk; ib++) {
+      csrc.push_back(dBlockBuf + (size_t)ib * slot + nmax * nmax);
+      cdst.push_back(Etmp.p + blk_ptr[ib]);
+      cn.push_back((int)(blk_ptr[ib + 1] - blk_ptr[ib]));
+    }
+    copy_slices(s, csrc, cdst, cn);
   }
   DevBuf<int> &rank = w.ibuf1;
   rank.resize(N + 8);
